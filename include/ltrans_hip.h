@@ -1,0 +1,254 @@
+/*
+ * ltrans_hip.h -- C ABI of the MI355X-native LTRANS particle-advection engine.
+ *
+ * This is the drop-in boundary for ONE path of LTRANS v.2b: the per-particle,
+ * per-internal-timestep loop
+ *
+ *     subroutine update_particles()            Model/LTRANS.f90:707-1419
+ *
+ * and everything it calls (find_currents :1422-1614, HYDRO_MOD search/interp
+ * hydrodynamic_module.f90:1414-2777, TENSION_MOD, INT_MOD, GRIDCELL_MOD,
+ * HTURB_MOD, VTURB_MOD, NORM_MOD, RANDOM_MOD, BOUNDARY_MOD runtime part
+ * boundary_module.f90:1515-1902, PIP_MOD, BEHAVIOR_MOD runtime part,
+ * SETTLEMENT_MOD runtime part settlement_module.f90:485-640).
+ *
+ * The reference has no FFI: update_particles() is an internal procedure of
+ * PROGRAM main with no arguments, reading host-associated variables of main
+ * (par, ex, ix, p, it, hitBottom, hitLand, ... LTRANS.f90:120-126) and
+ * PRIVATE SAVE module state.  The entry points below are therefore exactly
+ * what a Fortran ISO_C_BINDING interface for that path binds: one call per
+ * group of module state the path reads (uploaded once, at the place the
+ * reference initialises it) and one call, lt_step(), at the place the
+ * reference calls update_particles() (LTRANS.f90:596).
+ *
+ * Conventions (all taken from the reference so the Fortran host passes its
+ * arrays unchanged):
+ *   - INTEGER = int32_t, DOUBLE PRECISION = double, REAL = float,
+ *     LOGICAL = int32_t (0 = .FALSE., non-zero = .TRUE.).
+ *   - arrays are column-major with the extents written in the comments;
+ *     node / element / segment ids are 1-based, 0 = empty adjacency slot.
+ *   - every function returns an int status: LT_OK (0) or a negative LT_ERR_*;
+ *     lt_step() returns >= 0 = number of particles that raised an error code
+ *     in that step.  No host pointer is retained after a call returns.
+ *   - an engine is single-caller (like the reference: one thread); it owns one
+ *     HIP stream on one device.
+ *   - plain pointers and sizes only: no torch / C++ types cross this ABI.
+ */
+#ifndef LTRANS_HIP_H
+#define LTRANS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LT_ABI_VERSION 1
+
+/* status codes */
+#define LT_OK                 0
+#define LT_ERR_ARG           -1  /* NULL / out-of-range argument                   */
+#define LT_ERR_ABI           -2  /* struct_size / abi_version mismatch             */
+#define LT_ERR_STATE         -3  /* call order: grid / slabs / particles missing   */
+#define LT_ERR_UNSUPPORTED   -4  /* namelist option outside the implemented path   */
+#define LT_ERR_DEVICE        -5  /* HIP runtime error (see lt_last_error)          */
+#define LT_ERR_SLAB_NOT_F32  -6  /* slab_storage = F32 but a value is not a float  */
+#define LT_ERR_NOMEM         -7
+
+/* per-particle error codes written to err_code[] by lt_step().
+ * 4,5,6 : particle not in any neighbouring rho/u/v element at the START of
+ *         the step  (hydrodynamic_module.f90:1462-1510; ErrorLog formats 21-23,
+ *         LTRANS.f90:761-763,834-879)
+ * 24    : still crossing a boundary after the 3rd reflection (LTRANS.f90:1203)
+ * 25    : outside the main boundary after intersect_reflect  (LTRANS.f90:1241)
+ * 26    : inside an island after intersect_reflect           (LTRANS.f90:1276)
+ * 27-29 : jumped over a rho/u/v element (search after the move, :1319-1364)  */
+#define LT_PERR_NONE          0
+#define LT_PERR_NOT_IN_RHO    4
+#define LT_PERR_NOT_IN_U      5
+#define LT_PERR_NOT_IN_V      6
+#define LT_PERR_3RD_REFLECT  24
+#define LT_PERR_OUT_MAIN     25
+#define LT_PERR_IN_ISLAND    26
+#define LT_PERR_JUMP_RHO     27
+#define LT_PERR_JUMP_U       28
+#define LT_PERR_JUMP_V       29
+
+/* slab storage on the device */
+#define LT_SLAB_F32 0  /* ROMS history values are floats: stored as fp32, checked lossless */
+#define LT_SLAB_F64 1  /* stored as the reference holds them (fp64)                        */
+
+/* Scalars of LTRANS.data that the path reads (schema LTRANS.h:32-269, read by
+ * getParams parameter_module.f90:21-136).  Field names are the namelist names. */
+typedef struct lt_config {
+  int32_t struct_size;        /* = sizeof(lt_config)                                   */
+  int32_t abi_version;        /* = LT_ABI_VERSION                                      */
+  /* $numparticles */
+  int32_t numpar;             /* particles held by THIS engine (the local shard)       */
+  /* $timeparam */
+  int32_t dt;                 /* external time step (s)                                */
+  int32_t idt;                /* internal time step (s)                                */
+  /* $hydroparam */
+  int32_t us, ws;             /* rho / w s-levels; the path assumes ws = us+1
+                                 (LTRANS.f90:949-951)                                  */
+  float   hc;                 /* REAL in LTRANS.h:66                                   */
+  int32_t Vtransform;         /* 1,2,3 (hydrodynamic_module.f90:2691-2777)             */
+  double  z0;
+  /* $turbparam */
+  int32_t HTurbOn, VTurbOn;
+  double  ConstantHTurb;
+  /* $behavparam */
+  int32_t Behavior;           /* 0 passive, 6 constant sink/float; 1-5,7 unsupported   */
+  int32_t OpenOceanBoundary;
+  int32_t mortality;
+  double  deadage, pediage, swimstart, swimslow, swimfast, sink, Swimdepth;
+  /* $settleparam */
+  int32_t settlementon, holesExist;
+  /* $convparam */
+  double  PI;                 /* namelist value 3.14159265358979 (norm_module.f90:37)  */
+  /* $other */
+  int32_t seed;               /* init_genrand(seed) (LTRANS.f90:241)                   */
+  int32_t ErrorFlag;          /* 0 stop, 1 return to previous, 2 kill, 3 set out       */
+  int32_t SaltTempOn;         /* unsupported (must be 0)                               */
+  int32_t TrackCollisions;
+  int32_t FreeSlip;           /* unsupported (must be 0)                               */
+  /* build-specific (not in LTRANS.data) */
+  int32_t slab_storage;       /* LT_SLAB_F32 / LT_SLAB_F64                             */
+  int32_t device;             /* HIP device ordinal, -1 = current device               */
+  int32_t reserved0;
+} lt_config;
+
+/* Grid statics produced by initGrid (hydrodynamic_module.f90:88-657). */
+typedef struct lt_grid {
+  int32_t rho_nodes, u_nodes, v_nodes;
+  int32_t rho_elements, u_elements, v_elements;
+  const double  *rx, *ry;        /* (rho_nodes)                  :58,124-125        */
+  const double  *ux, *uy;        /* (u_nodes)                                       */
+  const double  *vx, *vy;        /* (v_nodes)                                       */
+  const double  *depth;          /* (rho_nodes) positive down    :38,116            */
+  const double  *rho_angle;      /* (rho_nodes)                  :58,123            */
+  const int32_t *rho_mask, *u_mask, *v_mask; /* may be NULL (FreeSlip only)         */
+  const int32_t *RE, *UE, *VE;   /* (4,elements) node ids        :49,117-119        */
+  const int32_t *r_Adjacent;     /* (rho_elements,10) self first, 0-terminated :54  */
+  const int32_t *u_Adjacent;     /* (u_elements,10)                                 */
+  const int32_t *v_Adjacent;     /* (v_elements,10)                                 */
+  const double  *SC, *CS;        /* (us)                         :35,112-113        */
+  const double  *SCW, *CSW;      /* (ws)                         :35,114-115        */
+} lt_grid;
+
+/* Boundary data produced by createBounds (boundary_module.f90:1148-1204). */
+typedef struct lt_bounds {
+  int32_t nbounds;               /* boundary segments                               */
+  int32_t maxbound;              /* points of the closed main polygon               */
+  int32_t maxisland;             /* points of all closed island polygons            */
+  int32_t numislands;
+  const double  *bnd_x, *bnd_y;  /* (2,nbounds)                  :41                */
+  const int32_t *land;           /* (nbounds) LOGICAL            :44                */
+  const double  *bx, *by;        /* (maxbound)                   :39                */
+  const double  *hx, *hy;        /* (maxisland)                                     */
+  const int32_t *hid;            /* (maxisland) island id per point :40             */
+} lt_bounds;
+
+/* Habitat polygons as organised by createPolySpecs (settlement_module.f90:
+ * 29-33,49-89,245-480).  Ragged Fortran derived types are passed as CSR. */
+typedef struct lt_habitat {
+  int32_t pedges, hedges;
+  int32_t minpolyid, maxpolyid, minholeid, maxholeid;
+  const double  *polys;          /* (pedges,5): id, centre x,y, edge x,y            */
+  const double  *holes;          /* (hedges,6): id, centre x,y, edge x,y, poly id   */
+  const int32_t *polyspecs;      /* (npoly,2) first row (1-based), #points; npoly = maxpolyid-minpolyid+1 */
+  const int32_t *holespecs;      /* (nhole,2)                                       */
+  const double  *maxbdis;        /* (npoly)                                         */
+  const double  *maxhdis;        /* (nhole)                                         */
+  const int32_t *elepolys_ptr;   /* (rho_elements+1) CSR offsets (0-based)          */
+  const int32_t *elepolys_ids;   /* polygon ids listed per rho element              */
+  const int32_t *polyholes_ptr;  /* (npoly+1) CSR offsets (0-based)                 */
+  const int32_t *polyholes_ids;  /* hole ids listed per polygon                     */
+} lt_habitat;
+
+/* Per-particle state.  Every pointer may be NULL = "do not transfer". */
+typedef struct lt_particles {
+  double  *par;                  /* par(numpar,13)               LTRANS.f90:104-120 */
+  int32_t *P_r_element;          /* (numpar) hydrodynamic_module.f90:23             */
+  int32_t *P_u_element;
+  int32_t *P_v_element;
+  int32_t *P_behave;             /* behavior_module.f90:64                          */
+  int32_t *dead;                 /* LOGICAL :83                                     */
+  int32_t *oob;                  /* LOGICAL :86                                     */
+  double  *P_swim;               /* (numpar,3) :77                                  */
+  double  *P_pediage;            /* :68                                             */
+  double  *P_deadage;            /* :69                                             */
+  int32_t *settle;               /* LOGICAL settlement_module.f90:32                */
+  double  *settletime;           /* :31                                             */
+  int32_t *endpoly;              /* LTRANS.f90:122                                  */
+  int32_t *hitBottom;            /* LTRANS.f90:122 (TrackCollisions)                */
+  int32_t *hitLand;
+  int32_t *err_code;             /* LT_PERR_* of the last step (build addition)     */
+} lt_particles;
+
+/* One time record of the hydrodynamic fields, as updateHydro scatters it into
+ * slot t_f (hydrodynamic_module.f90:1371-1403): values already multiplied by
+ * the land mask, node-numbered, level-last. */
+typedef struct lt_slab {
+  const double *zeta;            /* (rho_nodes)                                     */
+  const double *Uvel;            /* (u_nodes,us)                                    */
+  const double *Vvel;            /* (v_nodes,us)                                    */
+  const double *Wvel;            /* (rho_nodes,ws)                                  */
+  const double *Kh;              /* (rho_nodes,ws)  NULL allowed when VTurbOn = 0   */
+} lt_slab;
+
+/* Per-step counters (sums over the shard). */
+typedef struct lt_step_stats {
+  int64_t active;                /* particles that were tracked this step           */
+  int64_t errors;                /* particles with err_code != 0                    */
+  int64_t rng_draws;             /* MT19937 draws consumed by this shard            */
+} lt_step_stats;
+
+typedef struct lt_engine lt_engine;
+
+/* lifecycle ------------------------------------------------------------- */
+int lt_create(const lt_config *cfg, lt_engine **out);
+int lt_destroy(lt_engine *e);
+const char *lt_last_error(const lt_engine *e);     /* NUL-terminated, engine-owned */
+int lt_abi_version(void);
+
+/* uploads: replace the module state the path reads ----------------------- */
+int lt_set_grid(lt_engine *e, const lt_grid *g);            /* after initGrid      */
+int lt_set_bounds(lt_engine *e, const lt_bounds *b);        /* after createBounds  */
+int lt_set_habitat(lt_engine *e, const lt_habitat *h);      /* after initSettlement*/
+int lt_set_particles(lt_engine *e, const lt_particles *p);  /* after setEle_all    */
+/* slot = 1,2,3 = first index of t_zeta(3,:) etc.  initHydro loads slots 1,2,3;
+ * updateHydro rewrites slot t_f only. */
+int lt_set_slab(lt_engine *e, int32_t slot, const lt_slab *s);
+/* rotating indices t_b,t_c,t_f (hydrodynamic_module.f90:42,741-743,1080-1082) */
+int lt_set_time_slots(lt_engine *e, int32_t t_b, int32_t t_c, int32_t t_f);
+
+/* Mersenne Twister state (random_module.f90:98-99): mt(0:623), mti. */
+int lt_set_rng(lt_engine *e, const int32_t *mt624, int32_t mti);
+int lt_get_rng(lt_engine *e, int32_t *mt624, int32_t *mti);
+/* Multi-GPU: this shard's place in the single serial stream of one step:
+ * number of ACTIVE particles (those that draw) held by lower-ranked shards
+ * and the total over all shards.  Defaults: 0 and the shard's own count. */
+int lt_count_active(lt_engine *e, const double *ix3, int64_t *n_active);
+int lt_set_rng_window(lt_engine *e, int64_t active_before, int64_t active_total);
+
+/* the hot path ---------------------------------------------------------- */
+/* = update_particles() with main's ex(3), ix(3), p, it (LTRANS.f90:568-571,
+ * 588-590).  Asynchronous on the engine's stream; returns the error count of
+ * the PREVIOUS completed step only if sync = 0 is used by the host harness. */
+int lt_step(lt_engine *e, const double *ex3, const double *ix3, int32_t p, int32_t it);
+int lt_sync(lt_engine *e);
+int lt_get_stats(lt_engine *e, lt_step_stats *out);
+
+/* downloads ------------------------------------------------------------- */
+int lt_get_particles(lt_engine *e, lt_particles *out);
+/* Pack (x,y,z) of the shard as xyz(numpar,3) column-major into DEVICE memory
+ * dst (e.g. the send buffer of an RCCL all-gather); asynchronous. */
+int lt_pack_positions(lt_engine *e, void *dst_device);
+/* the engine's HIP stream (hipStream_t) for ordering external work */
+void *lt_stream(lt_engine *e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LTRANS_HIP_H */

@@ -1,0 +1,287 @@
+"""Engine: Python mirror of the reference's interface for the hot path.
+
+One method per C-ABI entry point of include/ltrans_hip.h; method names follow
+the reference procedures they stand in for (``update_particles`` =
+LTRANS.f90:707).  The default library is the in-tree HIP build
+``csrc/libltrans_hip.so``; it is REQUIRED -- there is no CPU fallback and the
+load fails loudly when the library is missing.  Tests may bind another
+implementation of the same ABI (the CPU oracle) by passing ``lib``/``prefix``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+from .abi import (LtBounds, LtConfig, LtError, LtGrid, LtHabitat, LtParticles, LtSlab,
+                  LtStepStats, PARTICLE_FIELDS)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIBRARY = os.path.join(_HERE, "csrc", "libltrans_hip.so")
+_hip_lib = None
+
+
+def load_hip_library(path=None):
+    """dlopen the HIP engine.  Raises if it has not been built (no fallback)."""
+    global _hip_lib
+    if path is None and _hip_lib is not None:
+        return _hip_lib
+    p = path or HIP_LIBRARY
+    if not os.path.exists(p):
+        raise RuntimeError(
+            f"{p} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()'); "
+            "this engine has no CPU fallback")
+    lib = C.CDLL(p, mode=C.RTLD_GLOBAL)
+    if path is None:
+        _hip_lib = lib
+    return lib
+
+
+def _f8(a, n=None, name="array"):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64).ravel(order="K"))
+    if n is not None and a.size != n:
+        raise ValueError(f"{name}: expected {n} values, got {a.size}")
+    return a
+
+
+def _i4(a, n=None, name="array"):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.int32).ravel(order="K"))
+    if n is not None and a.size != n:
+        raise ValueError(f"{name}: expected {n} values, got {a.size}")
+    return a
+
+
+def _fcol(a, dtype):
+    """Fortran (column-major) flattening of a 1-D/2-D array."""
+    a = np.asarray(a, dtype=dtype)
+    return np.ascontiguousarray(a.ravel(order="F"))
+
+
+def _dp(a):
+    return a.ctypes.data_as(abi.c_dp) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(abi.c_ip) if a is not None else None
+
+
+class Engine:
+    """Device-resident replacement of the module state + update_particles()."""
+
+    def __init__(self, cfg: LtConfig, lib=None, prefix="lt_"):
+        self.lib = lib if lib is not None else load_hip_library()
+        self.prefix = prefix
+        self.cfg = cfg.copy()
+        self._h = C.c_void_p()
+        self._fn = {}
+        for name in abi.ENTRY_POINTS:
+            f = getattr(self.lib, prefix + name)
+            f.restype = C.c_int
+            self._fn[name] = f
+        rc = self._fn["create"](C.byref(self.cfg), C.byref(self._h))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise LtError(rc, prefix + "create")
+        self.numpar = int(cfg.numpar)
+        self.us, self.ws = int(cfg.us), int(cfg.ws)
+        self._grid = None
+
+    # -- lifecycle ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._fn["destroy"](self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, where):
+        if rc < 0:
+            detail = ""
+            if self.prefix == "lt_":
+                f = self.lib.lt_last_error
+                f.restype = C.c_char_p
+                msg = f(self._h)
+                detail = msg.decode() if msg else ""
+            raise LtError(rc, self.prefix + where, detail)
+        return rc
+
+    # -- uploads -----------------------------------------------------------
+    def set_grid(self, g):
+        """g: mapping with the arrays initGrid builds (hydrodynamic_module.f90:88-657);
+        RE/UE/VE are (4,elements), *_Adjacent (elements,10) in Fortran index order."""
+        s = LtGrid()
+        keep = []
+        for k in ("rho_nodes", "u_nodes", "v_nodes", "rho_elements", "u_elements", "v_elements"):
+            setattr(s, k, int(g[k]))
+        sizes = {"rx": s.rho_nodes, "ry": s.rho_nodes, "ux": s.u_nodes, "uy": s.u_nodes,
+                 "vx": s.v_nodes, "vy": s.v_nodes, "depth": s.rho_nodes,
+                 "rho_angle": s.rho_nodes, "SC": self.us, "CS": self.us,
+                 "SCW": self.ws, "CSW": self.ws}
+        for k, n in sizes.items():
+            a = _f8(g[k], n, k)
+            keep.append(a)
+            setattr(s, k, _dp(a))
+        for k, n in (("rho_mask", s.rho_nodes), ("u_mask", s.u_nodes), ("v_mask", s.v_nodes)):
+            if g.get(k) is not None:
+                a = _i4(g[k], n, k)
+                keep.append(a)
+                setattr(s, k, _ip(a))
+        for k, n in (("RE", s.rho_elements), ("UE", s.u_elements), ("VE", s.v_elements)):
+            a = _fcol(np.asarray(g[k]).reshape(4, n, order="F"), np.int32)
+            keep.append(a)
+            setattr(s, k, _ip(a))
+        for k, n in (("r_Adjacent", s.rho_elements), ("u_Adjacent", s.u_elements),
+                     ("v_Adjacent", s.v_elements)):
+            a = _fcol(np.asarray(g[k]).reshape(n, 10, order="F"), np.int32)
+            keep.append(a)
+            setattr(s, k, _ip(a))
+        self._check(self._fn["set_grid"](self._h, C.byref(s)), "set_grid")
+        self._grid = {k: int(g[k]) for k in ("rho_nodes", "u_nodes", "v_nodes", "rho_elements")}
+
+    def set_bounds(self, b):
+        s = LtBounds()
+        keep = []
+        s.nbounds, s.maxbound = int(b["nbounds"]), int(b["maxbound"])
+        s.maxisland, s.numislands = int(b["maxisland"]), int(b["numislands"])
+        for k, n in (("bnd_x", 2 * s.nbounds), ("bnd_y", 2 * s.nbounds), ("bx", s.maxbound),
+                     ("by", s.maxbound), ("hx", s.maxisland), ("hy", s.maxisland)):
+            a = _fcol(b[k], np.float64)
+            if a.size != n:
+                raise ValueError(f"{k}: expected {n} values, got {a.size}")
+            keep.append(a)
+            setattr(s, k, _dp(a))
+        for k, n in (("land", s.nbounds), ("hid", s.maxisland)):
+            a = _i4(b[k], n, k)
+            keep.append(a)
+            setattr(s, k, _ip(a))
+        self._check(self._fn["set_bounds"](self._h, C.byref(s)), "set_bounds")
+
+    def set_habitat(self, h):
+        s = LtHabitat()
+        keep = []
+        for k in ("pedges", "hedges", "minpolyid", "maxpolyid", "minholeid", "maxholeid"):
+            setattr(s, k, int(h[k]))
+        for k in ("polys", "holes", "maxbdis", "maxhdis"):
+            a = _fcol(h[k], np.float64)
+            keep.append(a)
+            setattr(s, k, _dp(a))
+        for k in ("polyspecs", "holespecs", "elepolys_ptr", "elepolys_ids", "polyholes_ptr",
+                  "polyholes_ids"):
+            a = _fcol(h[k], np.int32)
+            keep.append(a)
+            setattr(s, k, _ip(a))
+        self._check(self._fn["set_habitat"](self._h, C.byref(s)), "set_habitat")
+
+    def set_particles(self, **arrays):
+        """par=(numpar,13), P_r_element=..., ... (names of abi.PARTICLE_FIELDS)."""
+        s = LtParticles()
+        keep = []
+        for name, _, dt, cols in PARTICLE_FIELDS:
+            if arrays.get(name) is None:
+                continue
+            a = np.asarray(arrays[name])
+            if cols > 1:
+                a = a.reshape(self.numpar, cols)
+            a = _fcol(a, np.dtype(dt))
+            if a.size != self.numpar * cols:
+                raise ValueError(f"{name}: expected {self.numpar * cols} values, got {a.size}")
+            keep.append(a)
+            setattr(s, name, _dp(a) if dt == "f8" else _ip(a))
+        unknown = set(arrays) - {f[0] for f in PARTICLE_FIELDS}
+        if unknown:
+            raise KeyError(f"unknown particle arrays {sorted(unknown)}")
+        self._check(self._fn["set_particles"](self._h, C.byref(s)), "set_particles")
+
+    def set_slab(self, slot, zeta, Uvel, Vvel, Wvel, Kh=None):
+        """One masked time record into slot 1..3 (updateHydro, hydrodynamic_module.f90:1371)."""
+        g = self._grid
+        if g is None:
+            raise LtError(-3, "set_slab", "set_grid first")
+        s = LtSlab()
+        z = _f8(zeta, g["rho_nodes"], "zeta")
+        u = _fcol(Uvel, np.float64)
+        v = _fcol(Vvel, np.float64)
+        w = _fcol(Wvel, np.float64)
+        if u.size != g["u_nodes"] * self.us or v.size != g["v_nodes"] * self.us \
+                or w.size != g["rho_nodes"] * self.ws:
+            raise ValueError("slab extents do not match the grid")
+        s.zeta, s.Uvel, s.Vvel, s.Wvel = _dp(z), _dp(u), _dp(v), _dp(w)
+        k = None
+        if Kh is not None:
+            k = _fcol(Kh, np.float64)
+            if k.size != g["rho_nodes"] * self.ws:
+                raise ValueError("Kh extent does not match the grid")
+            s.Kh = _dp(k)
+        self._check(self._fn["set_slab"](self._h, int(slot), C.byref(s)), "set_slab")
+
+    def set_time_slots(self, t_b, t_c, t_f):
+        self._check(self._fn["set_time_slots"](self._h, int(t_b), int(t_c), int(t_f)),
+                    "set_time_slots")
+
+    def set_rng(self, mt, mti):
+        a = np.ascontiguousarray(np.asarray(mt, dtype=np.uint32)).view(np.int32)
+        self._check(self._fn["set_rng"](self._h, _ip(a), int(mti)), "set_rng")
+
+    def get_rng(self):
+        a = np.zeros(624, dtype=np.int32)
+        mti = C.c_int32()
+        self._check(self._fn["get_rng"](self._h, _ip(a), C.byref(mti)), "get_rng")
+        return a.view(np.uint32), mti.value
+
+    def count_active(self, ix):
+        ix = _f8(ix, 3, "ix")
+        n = C.c_int64()
+        self._check(self._fn["count_active"](self._h, _dp(ix), C.byref(n)), "count_active")
+        return n.value
+
+    def set_rng_window(self, active_before, active_total):
+        self._check(self._fn["set_rng_window"](self._h, C.c_int64(int(active_before)),
+                                               C.c_int64(int(active_total))), "set_rng_window")
+
+    # -- the hot path --------------------------------------------------------
+    def update_particles(self, ex, ix, p, it):
+        """= update_particles() of LTRANS.f90:707 for main's ex, ix, p, it."""
+        ex = _f8(ex, 3, "ex")
+        ix = _f8(ix, 3, "ix")
+        return self._check(self._fn["step"](self._h, _dp(ex), _dp(ix), int(p), int(it)), "step")
+
+    step = update_particles
+
+    def sync(self):
+        self._check(self._fn["sync"](self._h), "sync")
+
+    def stats(self):
+        s = LtStepStats()
+        self._check(self._fn["get_stats"](self._h, C.byref(s)), "get_stats")
+        return {"active": s.active, "errors": s.errors, "rng_draws": s.rng_draws}
+
+    # -- downloads -----------------------------------------------------------
+    def get_particles(self, fields=None):
+        s = LtParticles()
+        out = {}
+        for name, _, dt, cols in PARTICLE_FIELDS:
+            if fields is not None and name not in fields:
+                continue
+            a = np.zeros(self.numpar * cols, dtype=np.dtype(dt))
+            out[name] = a
+            setattr(s, name, _dp(a) if dt == "f8" else _ip(a))
+        self._check(self._fn["get_particles"](self._h, C.byref(s)), "get_particles")
+        for name, _, dt, cols in PARTICLE_FIELDS:
+            if name in out and cols > 1:
+                out[name] = out[name].reshape(self.numpar, cols, order="F")
+        return out
+
+    def pack_positions(self, dst_device_ptr):
+        f = self.lib.lt_pack_positions
+        f.restype = C.c_int
+        self._check(f(self._h, C.c_void_p(int(dst_device_ptr))), "pack_positions")
+
+    def stream(self):
+        f = self.lib.lt_stream
+        f.restype = C.c_void_p
+        return f(self._h)

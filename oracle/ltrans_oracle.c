@@ -1,0 +1,770 @@
+/*
+ * ltrans_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE, see ltrans_oracle.h).
+ *
+ * Plain C restatement of the LTRANS v.2b particle-advection path.  Every
+ * function cites the reference file:line it follows (paths relative to
+ * /root/reference/Model).  Compile with -ffp-contract=off: the reference
+ * oracle build (oracle/_ref) uses the same flag, and bit-for-bit agreement of
+ * the leaf numerics depends on it.
+ *
+ * Literal-precision notes copied from the Fortran:
+ *   DBLE(0.001), DBLE(0.000001), 1.0E-6 in a DOUBLE PRECISION PARAMETER are
+ *   SINGLE-precision literals widened to double  -> (double)0.001f etc.
+ *   float(idt), float(j-4) are REAL                -> (double)(float)n.
+ *   hc is REAL (LTRANS.h:66)                       -> (double)cfg.hc.
+ */
+#include "ltrans_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ======================================================================== */
+/*  RANDOM_MOD  (random_module.f90)                                         */
+/* ======================================================================== */
+
+/* init_genrand, random_module.f90:108-119 */
+void lto_init_genrand(lto_mt *s, uint32_t seed) {
+  s->mt[0] = seed;
+  for (int i = 1; i < 624; i++)
+    s->mt[i] = 1812433253u * (s->mt[i - 1] ^ (s->mt[i - 1] >> 30)) + (uint32_t)i;
+  s->mti = 624; /* the DO loop leaves mti = N */
+}
+
+/* genrand_int32, random_module.f90:166-197 */
+uint32_t lto_genrand_int32(lto_mt *s) {
+  static const uint32_t mag01[2] = {0u, 0x9908b0dfu};
+  uint32_t y;
+  if (s->mti >= 624) {
+    int kk;
+    for (kk = 0; kk < 624 - 397; kk++) {
+      y = (s->mt[kk] & 0x80000000u) | (s->mt[kk + 1] & 0x7fffffffu);
+      s->mt[kk] = s->mt[kk + 397] ^ (y >> 1) ^ mag01[y & 1u];
+    }
+    for (; kk < 623; kk++) {
+      y = (s->mt[kk] & 0x80000000u) | (s->mt[kk + 1] & 0x7fffffffu);
+      s->mt[kk] = s->mt[kk + (397 - 624)] ^ (y >> 1) ^ mag01[y & 1u];
+    }
+    y = (s->mt[623] & 0x80000000u) | (s->mt[0] & 0x7fffffffu);
+    s->mt[623] = s->mt[396] ^ (y >> 1) ^ mag01[y & 1u];
+    s->mti = 0;
+  }
+  y = s->mt[s->mti++];
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
+
+/* genrand_real1, random_module.f90:213-220: [0,1] */
+double lto_genrand_real1(lto_mt *s) {
+  return (double)lto_genrand_int32(s) / 4294967295.0;
+}
+
+/* genrand_real3, random_module.f90:239-246: (0,1) */
+double lto_genrand_real3(lto_mt *s) {
+  return ((double)lto_genrand_int32(s) + 0.5) / 4294967296.0;
+}
+
+/* norm, norm_module.f90:25-39 (cos branch of Box-Muller, namelist PI) */
+double lto_norm(lto_mt *s, double PI) {
+  double dev1 = lto_genrand_real3(s);
+  double dev2 = lto_genrand_real3(s);
+  return sqrt(-2.0 * log(dev1)) * cos(2.0 * PI * dev2);
+}
+
+/* ======================================================================== */
+/*  INT_MOD  (interpolation_module.f90)                                     */
+/* ======================================================================== */
+
+/* linint, interpolation_module.f90:25-59 (1-based in the text) */
+void lto_linint(const double *xa, const double *ya, int n, double x, double *y, double *m) {
+  int jlo = 1, jhi = n, k;
+  double b;
+  for (;;) {
+    k = (jhi + jlo) / 2;
+    if (xa[k - 1] > x)
+      jhi = k;
+    else
+      jlo = k;
+    if (jhi - jlo == 1) break;
+  }
+  *m = (ya[jlo - 1] - ya[jhi - 1]) / (xa[jlo - 1] - xa[jhi - 1]);
+  b = ya[jlo - 1] - (*m) * xa[jlo - 1];
+  *y = (*m) * x + b;
+}
+
+/* polintd, interpolation_module.f90:70-107 (n = 3 at every call site) */
+double lto_polintd(const double *xa, const double *ya, double x) {
+  int ns = 1;
+  double dif = fabs(x - xa[0]), dift, a, b, c;
+  for (int i = 1; i <= 3; i++) {
+    dift = fabs(x - xa[i - 1]);
+    if (dift < dif) {
+      ns = i;
+      dif = dift;
+    }
+  }
+  c = (xa[1] - x) * ((ya[2] - ya[1]) / (xa[1] - xa[2]));
+  c = c - (xa[1] - x) * ((ya[1] - ya[0]) / (xa[0] - xa[1]));
+  c = c / (xa[0] - xa[2]);
+  if (ns == 3) {
+    a = (ya[2] - ya[1]) / (xa[1] - xa[2]);
+    b = xa[2] - x;
+  } else {
+    a = (ya[1] - ya[0]) / (xa[0] - xa[1]);
+    b = xa[0] - x;
+  }
+  return ya[ns - 1] + (xa[ns - 1] - x) * a + b * c;
+}
+
+/* ======================================================================== */
+/*  GRIDCELL_MOD  (gridcell_module.f90:26-257)                              */
+/* ======================================================================== */
+
+#define EX(k, i) ele_x[((k)-1) + 4 * ((size_t)(i)-1)]
+#define EY(k, i) ele_y[((k)-1) + 4 * ((size_t)(i)-1)]
+
+/* horizontal-edge special case, gridcell_module.f90:75-147 (one of 6 pairs).
+ * returns 1 = hit (exit), 2 = cycle, 0 = pair not applicable */
+static int gc_horiz(const double *ele_x, const double *ele_y, int i, int a, int b,
+                    double Xpos, double Ypos) {
+  if (EY(a, i) == EY(b, i) && Ypos == EY(a, i)) {
+    if ((EX(a, i) > EX(b, i) && Xpos > EX(b, i) && Xpos < EX(a, i)) ||
+        (EX(b, i) > EX(a, i) && Xpos > EX(a, i) && Xpos < EX(b, i)))
+      return 1;
+    return 2;
+  }
+  return 0;
+}
+
+void lto_gridcell(int elements, const double *ele_y, const double *ele_x, double Xpos,
+                  double Ypos, int *P_ele, int *triangle, int checkele) {
+  int elestart, eleend;
+  if (checkele > 0) {
+    elestart = eleend = checkele;
+  } else {
+    elestart = 1;
+    eleend = elements;
+  }
+  for (int i = elestart; i <= eleend; i++) {
+    int counter[5] = {0, 0, 0, 0, 0};
+    /* 1 :49-53 */
+    if ((Ypos < EY(1, i) && Ypos < EY(2, i) && Ypos < EY(3, i) && Ypos < EY(4, i)) ||
+        (Ypos > EY(1, i) && Ypos > EY(2, i) && Ypos > EY(3, i) && Ypos > EY(4, i)))
+      continue;
+    /* 2 :55-59 */
+    if ((Xpos < EX(1, i) && Xpos < EX(2, i) && Xpos < EX(3, i) && Xpos < EX(4, i)) ||
+        (Xpos > EX(1, i) && Xpos > EX(2, i) && Xpos > EX(3, i) && Xpos > EX(4, i)))
+      continue;
+    /* 3 :61-69 on a node */
+    if ((Xpos == EX(1, i) && Ypos == EY(1, i)) || (Xpos == EX(2, i) && Ypos == EY(2, i)) ||
+        (Xpos == EX(3, i) && Ypos == EY(3, i)) || (Xpos == EX(4, i) && Ypos == EY(4, i))) {
+      *P_ele = i;
+      *triangle = 1;
+      break;
+    }
+    /* 4 :71-149 horizontal segments */
+    if (EY(1, i) == EY(2, i) || EY(1, i) == EY(3, i) || EY(1, i) == EY(4, i) ||
+        EY(2, i) == EY(3, i) || EY(2, i) == EY(4, i) || EY(3, i) == EY(4, i)) {
+      static const int pa[6] = {1, 1, 1, 2, 2, 3}, pb[6] = {2, 3, 4, 3, 4, 4};
+      int r = 0;
+      for (int q = 0; q < 6 && r == 0; q++)
+        r = gc_horiz(ele_x, ele_y, i, pa[q], pb[q], Xpos, Ypos);
+      if (r == 1) {
+        *P_ele = i;
+        *triangle = 1;
+        break;
+      }
+      if (r == 2) continue;
+    }
+    /* 5 :151-183 */
+    if (Ypos == EY(1, i) || Ypos == EY(2, i) || Ypos == EY(3, i) || Ypos == EY(4, i)) {
+      double bhighy = EY(1, i), blowy = EY(1, i);
+      if (EY(2, i) > bhighy) bhighy = EY(2, i);
+      if (EY(3, i) > bhighy) bhighy = EY(3, i);
+      if (EY(4, i) > bhighy) bhighy = EY(4, i);
+      if (Ypos == bhighy) continue;
+      if (EY(2, i) < blowy) blowy = EY(2, i);
+      if (EY(3, i) < blowy) blowy = EY(3, i);
+      if (EY(4, i) < blowy) blowy = EY(4, i);
+      if (Ypos == blowy) continue;
+    }
+    /* 6 :185-247; the inner "exit" leaves only the edge loop */
+    for (int p = 1; p <= 4; p++) {
+      int q = (p == 4) ? 1 : p + 1;
+      double bx1 = EX(p, i), by1 = EY(p, i), bx2 = EX(q, i), by2 = EY(q, i);
+      if (Xpos <= bx1 || Xpos <= bx2) {
+        if ((by1 > by2 && Ypos >= by2 && Ypos <= by1) ||
+            (by2 > by1 && Ypos >= by1 && Ypos <= by2)) {
+          if (bx1 == bx2) {
+            if (Xpos == bx1) {
+              *P_ele = i;
+              *triangle = 1;
+              break;
+            } else {
+              counter[p] = 1;
+              if (Ypos == by2) counter[p] = 0;
+            }
+          } else {
+            double slope = ((by1 - by2) / (bx1 - bx2));
+            double xintersect = (Ypos - by1 + (slope * bx1)) / slope;
+            if (xintersect > Xpos) {
+              counter[p] = 1;
+              if (Ypos == by2) counter[p] = 0;
+            }
+            if (xintersect == Xpos) {
+              *P_ele = i;
+              *triangle = 1;
+              break;
+            }
+          }
+        }
+      }
+    }
+    if (((counter[1] + counter[2] + counter[3] + counter[4]) % 2) != 0) {
+      *P_ele = i;
+      *triangle = 1;
+      break;
+    }
+  }
+}
+#undef EX
+#undef EY
+
+/* ======================================================================== */
+/*  PIP_MOD  (point_in_polygon_module.f90:25-167)                           */
+/* ======================================================================== */
+
+int lto_inpoly(double x, double y, int n, const double *e, int onin) {
+#define E1(i) e[(size_t)(i)-1]             /* e(i,1) */
+#define E2(i) e[(size_t)(i)-1 + (size_t)n] /* e(i,2) */
+  int onout = (onin < 0) ? 0 : !onin;
+  int inpoly = 1, crossed = 0, on = 0;
+  int *hilo = (int *)calloc((size_t)n + 2, sizeof(int));
+  /* :49-58 */
+  for (int i = 1; i <= n; i++) {
+    if (E2(i) > y) hilo[i] = 1;
+    if (E2(i) < y) hilo[i] = -1;
+    if (E2(i) == y && E1(i) > x) on = 1;
+    if (E1(i) == x && E2(i) == y) {
+      if (onout) inpoly = 0;
+      free(hilo);
+      return inpoly;
+    }
+  }
+  /* :61-122 vertices on the ray */
+  if (on) {
+    int first = 1, i = 1, j;
+    for (;;) {
+      if (i > n) break;
+      if (hilo[i] == 0 && E1(i) > x) {
+        if (first) {
+          i = i + 1;
+          continue;
+        }
+        if (hilo[i - 1] == 0) {
+          if (onout) inpoly = 0;
+          free(hilo);
+          return inpoly;
+        }
+        j = 1;
+        for (;;) {
+          if ((i + j) == (n + 1)) j = 2 - i;
+          if (hilo[i + j] != 0) break;
+          if (E1(i + j) < x) {
+            if (onout) inpoly = 0;
+            free(hilo);
+            return inpoly;
+          }
+          j = j + 1;
+        }
+        if ((hilo[i - 1] + hilo[i + j]) == 0) crossed = crossed + 1;
+        if (j < 0) break;
+        i = i + j;
+      }
+      first = 0;
+      i = i + 1;
+    }
+  }
+  /* :125-160 */
+  for (int i = 1; i <= n - 1; i++) {
+    if (E1(i) <= x && E1(i + 1) <= x) continue;
+    if (E2(i) <= y && E2(i + 1) <= y) continue;
+    if (E2(i) >= y && E2(i + 1) >= y) continue;
+    if (E1(i) > x && E1(i + 1) > x) {
+      crossed = crossed + 1;
+      continue;
+    }
+    {
+      double m = (E2(i + 1) - E2(i)) / (E1(i + 1) - E1(i));
+      double b = E2(i) - m * E1(i);
+      double ix = (y - b) / m;
+      if (ix == x) {
+        if (onout) inpoly = 0;
+        free(hilo);
+        return inpoly;
+      }
+      if (ix > x) crossed = crossed + 1;
+    }
+  }
+  if ((crossed % 2) == 0) inpoly = 0;
+  free(hilo);
+  return inpoly;
+#undef E1
+#undef E2
+}
+
+/* ======================================================================== */
+/*  TENSION_MOD  (tension_module.f90, TSPACK subset)                        */
+/*  Restated from the algorithm; arrays 1-based in the text, 0-based here.  */
+/* ======================================================================== */
+
+/* SNHCSH, tension_module.f90:784-849 */
+void lto_snhcsh(double X, double *SINHM, double *COSHM, double *COSHMM) {
+  static const double P1 = -3.51754964808151394800e5, P2 = -1.15614435765005216044e4,
+                      P3 = -1.63725857525983828727e2, P4 = -7.89474443963537015605e-1;
+  static const double Q1 = -2.11052978884890840399e6, Q2 = 3.61578279834431989373e4,
+                      Q3 = -2.77711081420602794433e2, Q4 = 1.0;
+  double AX = fabs(X), XS = AX * AX;
+  if (AX <= .5) {
+    double XC = X * XS;
+    double P = ((P4 * XS + P3) * XS + P2) * XS + P1;
+    double Q = ((Q4 * XS + Q3) * XS + Q2) * XS + Q1;
+    double XSD4, XSD2, F;
+    *SINHM = XC * (P / Q);
+    XSD4 = .25 * XS;
+    XSD2 = XSD4 + XSD4;
+    P = ((P4 * XSD4 + P3) * XSD4 + P2) * XSD4 + P1;
+    Q = ((Q4 * XSD4 + Q3) * XSD4 + Q2) * XSD4 + Q1;
+    F = XSD4 * (P / Q);
+    *COSHMM = XSD2 * F * (F + 2.0);
+    *COSHM = *COSHMM + XSD2;
+  } else {
+    double EXPX = exp(AX);
+    *SINHM = -(((1.0 / EXPX + AX) + AX) - EXPX) / 2.0;
+    if (X < 0.0) *SINHM = -*SINHM;
+    *COSHM = ((1.0 / EXPX - 2.0) + EXPX) / 2.0;
+    *COSHMM = *COSHM - XS / 2.0;
+  }
+}
+
+static double dmin(double a, double b) { return (a < b) ? a : b; }
+static double dmax(double a, double b) { return (a > b) ? a : b; }
+static double dsign(double a, double b) { return (b >= 0.0 && !(b == 0.0 && signbit(b))) ? fabs(a) : -fabs(a); }
+
+/* YPC1, tension_module.f90:852-977 */
+void lto_ypc1(int N, const double *X, const double *Y, double *YP, int *IER) {
+  int NM1 = N - 1, I;
+  double ASI, ASIM1, DX2, DXI, DXIM1 = 0.0, S2, SGN, SI, SIM1 = 0.0, T;
+  I = 1;
+  DXI = X[1] - X[0];
+  if (DXI <= 0.0) {
+    *IER = I + 1;
+    return;
+  }
+  SI = (Y[1] - Y[0]) / DXI;
+  if (NM1 == 1) {
+    YP[0] = SI;
+    YP[1] = SI;
+    *IER = 0;
+    return;
+  }
+  I = 2;
+  DX2 = X[2] - X[1];
+  if (DX2 <= 0.0) {
+    *IER = I + 1;
+    return;
+  }
+  S2 = (Y[2] - Y[1]) / DX2;
+  T = SI + DXI * (SI - S2) / (DXI + DX2);
+  if (SI >= 0.0)
+    YP[0] = dmin(dmax(0.0, T), 3.0 * SI);
+  else
+    YP[0] = dmax(dmin(0.0, T), 3.0 * SI);
+  for (I = 2; I <= NM1; I++) {
+    DXIM1 = DXI;
+    DXI = X[I] - X[I - 1];
+    if (DXI <= 0.0) {
+      *IER = I + 1;
+      return;
+    }
+    SIM1 = SI;
+    SI = (Y[I] - Y[I - 1]) / DXI;
+    T = (DXIM1 * SI + DXI * SIM1) / (DXIM1 + DXI);
+    ASIM1 = fabs(SIM1);
+    ASI = fabs(SI);
+    SGN = dsign(1.0, SI);
+    if (ASIM1 > ASI) SGN = dsign(1.0, SIM1);
+    if (SGN > 0.0)
+      YP[I - 1] = dmin(dmax(0.0, T), 3.0 * dmin(ASIM1, ASI));
+    else
+      YP[I - 1] = dmax(dmin(0.0, T), -3.0 * dmin(ASIM1, ASI));
+  }
+  T = SI + DXI * (SI - SIM1) / (DXIM1 + DXI);
+  if (SI >= 0.0)
+    YP[N - 1] = dmin(dmax(0.0, T), 3.0 * SI);
+  else
+    YP[N - 1] = dmax(dmin(0.0, T), 3.0 * SI);
+  *IER = 0;
+}
+
+/* store-and-maybe-update tail shared by every exit of a SIGS interval,
+ * tension_module.f90:476-484 (repeated verbatim at each CYCLE) */
+static void sigs_update(double SIG, double SIGIN, double *sigma_i, int *ICNT, double *DSM) {
+  const double SBIG = 85.0;
+  SIG = dmin(SIG, SBIG);
+  if (SIG > SIGIN) {
+    double DSIG;
+    *sigma_i = SIG;
+    *ICNT = *ICNT + 1;
+    DSIG = SIG - SIGIN;
+    if (SIGIN > 0.0) DSIG = DSIG / SIGIN;
+    *DSM = dmax(*DSM, DSIG);
+  }
+}
+
+/* SIGS, tension_module.f90:314-781.
+ * UB pinned here: CONT is not assigned on the SIG <= .5 branch of the secant
+ * loop (:685-695); original TSPACK always evaluates F there, so CONT is taken
+ * as .TRUE. on that branch (verified equal to the flang build on random and
+ * adversarial profiles, tests/test_oracle_ref.py). */
+void lto_sigs(int N, const double *X, const double *Y, const double *YP, double *SIGMA,
+              int *IER, int *SigErr) {
+  const double SBIG = 85.0;
+  int NM1 = N - 1, I, ICNT, NIT;
+  double A = 0, C1, C2, COSHM, COSHMM, D0, D1, D1D2, D1PD2, D2, DMAX, DSIG, DSM, DX, E = 0,
+         EMS, EMS2, F, F0, FMAX, FNEG, FP, FTOL, RTOL, S, S1, S2, SCM, SGN, SIG, SIGIN,
+         SINHM, SSINH, SSM, STOL, T, T0, T1, T2, TM, TP1, TOL;
+  int CONT;
+  if (NM1 < 1) {
+    *IER = -1;
+    return;
+  }
+  TOL = 0.0;
+  for (I = 0; I < NM1; I++) SIGMA[I] = 0.0;
+  FTOL = fabs(TOL);
+  /* :433-439 RTOL = 200*eps via STORE loop */
+  RTOL = 1.0;
+  for (;;) {
+    volatile double st;
+    RTOL = RTOL / 2.0;
+    st = RTOL + 1.0;
+    if (st <= 1.0) break;
+  }
+  RTOL = RTOL * 200.0;
+  ICNT = 0;
+  DSM = 0.0;
+  for (I = 1; I <= NM1; I++) {
+    int IP1 = I + 1;
+    DX = X[IP1 - 1] - X[I - 1];
+    if (DX <= 0.0) {
+      *IER = -IP1;
+      return; /* EXIT of the interval loop; nothing follows it */
+    }
+    SIGIN = SIGMA[I - 1];
+    if (SIGIN >= SBIG) continue;
+    S1 = YP[I - 1];
+    S2 = YP[IP1 - 1];
+    S = (Y[IP1 - 1] - Y[I - 1]) / DX;
+    D1 = S - S1;
+    D2 = S2 - S;
+    D1D2 = D1 * D2;
+    /* infinite tension :470-485 */
+    SIG = SBIG;
+    if ((D1D2 == 0.0 && S1 != S2) || (S == 0.0 && S1 * S2 > 0.0)) {
+      sigs_update(SIG, SIGIN, &SIGMA[I - 1], &ICNT, &DSM);
+      continue;
+    }
+    /* SIGMA = 0 sufficient :490-519 */
+    SIG = 0.0;
+    if (D1D2 >= 0.0) {
+      if (D1D2 == 0.0) {
+        sigs_update(SIG, SIGIN, &SIGMA[I - 1], &ICNT, &DSM);
+        continue;
+      }
+      T = dmax(D1 / D2, D2 / D1);
+      if (T <= 2.0) {
+        sigs_update(SIG, SIGIN, &SIGMA[I - 1], &ICNT, &DSM);
+        continue;
+      }
+      TP1 = T + 1.0;
+      /* convexity Newton :531-580; every normal exit sets FLAG -> update+cycle */
+      SIG = sqrt(10.0 * T - 20.0);
+      NIT = 0;
+      for (;;) {
+        if (SIG <= .5) {
+          lto_snhcsh(SIG, &SINHM, &COSHM, &COSHMM);
+          T1 = COSHM / SINHM;
+          FP = T1 + SIG * (SIG / SINHM - T1 * T1 + 1.0);
+        } else {
+          EMS = exp(-SIG);
+          SSM = 1.0 - EMS * (EMS + SIG + SIG);
+          T1 = (1.0 - EMS) * (1.0 - EMS) / SSM;
+          FP = T1 + SIG * (2.0 * SIG * EMS / SSM - T1 * T1 + 1.0);
+        }
+        F = SIG * T1 - TP1;
+        NIT = NIT + 1;
+        if (NIT > 10000) {
+          *SigErr = *SigErr + 1;
+          return;
+        }
+        if (FP <= 0.0) break;
+        DSIG = -F / FP;
+        if (fabs(DSIG) <= RTOL * SIG || (F >= 0.0 && F <= FTOL) || fabs(F) <= RTOL) break;
+        SIG = SIG + DSIG;
+      }
+      sigs_update(SIG, SIGIN, &SIGMA[I - 1], &ICNT, &DSM);
+      continue;
+    }
+    /* convexity cannot be satisfied :597-624 (SIG = 0 here) */
+    if (S1 * S < 0.0 || S2 * S < 0.0) {
+      sigs_update(SIG, SIGIN, &SIGMA[I - 1], &ICNT, &DSM);
+      continue;
+    }
+    T0 = 3.0 * S - S1 - S2;
+    D0 = T0 * T0 - S1 * S2;
+    if (D0 <= 0.0 || S * T0 >= 0.0) {
+      sigs_update(SIG, SIGIN, &SIGMA[I - 1], &ICNT, &DSM);
+      continue;
+    }
+    /* monotonicity secant :638-760 */
+    SGN = dsign(1.0, S);
+    SIG = SBIG;
+    FMAX = SGN * (SIG * S - S1 - S2) / (SIG - 2.0);
+    if (FMAX <= 0.0) {
+      sigs_update(SIG, SIGIN, &SIGMA[I - 1], &ICNT, &DSM);
+      continue;
+    }
+    STOL = RTOL * SIG;
+    F = FMAX;
+    F0 = SGN * D0 / (3.0 * (D1 - D2));
+    FNEG = F0;
+    DSIG = SIG;
+    DMAX = SIG;
+    D1PD2 = D1 + D2;
+    NIT = 0;
+    for (;;) {
+      DSIG = -F * DSIG / (F - F0);
+      if (fabs(DSIG) > fabs(DMAX) || DSIG * DMAX > 0.) {
+        DSIG = DMAX;
+        F0 = FNEG;
+        continue;
+      }
+      if (fabs(DSIG) < STOL / 2.0) DSIG = -dsign(STOL / 2.0, DMAX);
+      SIG = SIG + DSIG;
+      F0 = F;
+      if (SIG <= .5) {
+        lto_snhcsh(SIG, &SINHM, &COSHM, &COSHMM);
+        C1 = SIG * COSHM * D2 - SINHM * D1PD2;
+        C2 = SIG * (SINHM + SIG) * D2 - COSHM * D1PD2;
+        A = C2 - C1;
+        E = SIG * SINHM - COSHMM - COSHMM;
+        CONT = 1; /* pinned UB, see header comment */
+      } else {
+        EMS = exp(-SIG);
+        EMS2 = EMS + EMS;
+        TM = 1.0 - EMS;
+        SSINH = TM * (1.0 + EMS);
+        SSM = SSINH - SIG * EMS2;
+        SCM = TM * TM;
+        C1 = SIG * SCM * D2 - SSM * D1PD2;
+        C2 = SIG * SSINH * D2 - SCM * D1PD2;
+        F = FMAX;
+        CONT = 1;
+        if (C1 * (SIG * SCM * D1 - SSM * D1PD2) >= 0.0) CONT = 0;
+        if (CONT) A = EMS2 * (SIG * TM * D2 + (TM - SIG) * D1PD2);
+        if (A * (C2 + C1) < 0.0) CONT = 0;
+        if (CONT) E = SIG * SSINH - SCM - SCM;
+      }
+      if (CONT) F = (SGN * (E * S2 - C2) + sqrt(A * (C2 + C1))) / E;
+      NIT = NIT + 1;
+      STOL = RTOL * SIG;
+      if (fabs(DMAX) <= STOL || (F >= 0.0 && F <= FTOL) || fabs(F) <= RTOL) break;
+      DMAX = DMAX + DSIG;
+      if (F0 * F > 0.0 && fabs(F) >= fabs(F0)) {
+        DSIG = DMAX;
+        F0 = FNEG;
+        continue;
+      }
+      if (F0 * F <= 0.0) {
+        T1 = DMAX;
+        T2 = FNEG;
+        DMAX = DSIG;
+        FNEG = F0;
+        if (fabs(DSIG) > fabs(T1) && fabs(F) < fabs(T2)) {
+          DSIG = T1;
+          F0 = T2;
+        }
+      }
+    }
+    sigs_update(SIG, SIGIN, &SIGMA[I - 1], &ICNT, &DSM);
+  }
+  (void)ICNT;
+  (void)DSM;
+}
+
+/* TSPSI, tension_module.f90:231-311 */
+void lto_tspsi(int N, const double *X, const double *Y, double *YP, double *SIGMA, int *IER,
+               int *SigErr) {
+  int IERR = 0;
+  *IER = 0;
+  if (N < 2) {
+    *IER = -1;
+  } else {
+    lto_ypc1(N, X, Y, YP, &IERR);
+    if (IERR != 0) {
+      *IER = -4;
+    } else {
+      lto_sigs(N, X, Y, YP, SIGMA, &IERR, SigErr);
+    }
+  }
+}
+
+/* INTRVL, tension_module.f90:1287-1354.  The SAVEd IL only short-cuts the
+ * search; the returned index is a pure function of (T,X). */
+static int intrvl(double T, int N, const double *X) {
+  int IL = 1, IH = N, K;
+  for (;;) {
+    if (IH <= IL + 1) break;
+    K = (IL + IH) / 2;
+    if (T < X[K - 1])
+      IH = K;
+    else
+      IL = K;
+  }
+  return IL;
+}
+
+/* HVAL, tension_module.f90:980-1121 */
+double lto_hval(double T, int N, const double *X, const double *Y, const double *YP,
+                const double *SIGMA, int *IER) {
+  const double SBIG = 85.0;
+  int I, IP1;
+  double B1, B2, CM, CM2, CMM, D1, D2, DUMMY, DX, E, E1, E2, EMS, S, S1, SB1, SB2, SIG, SM,
+      SM2, TM, TP, TS, U, Y1;
+  if (N < 2) {
+    *IER = -1;
+    return 0.0;
+  }
+  if (T < X[0]) {
+    I = 1;
+    *IER = 1;
+  } else if (T > X[N - 1]) {
+    I = N - 1;
+    *IER = 1;
+  } else {
+    I = intrvl(T, N, X);
+    *IER = 0;
+  }
+  IP1 = I + 1;
+  DX = X[IP1 - 1] - X[I - 1];
+  if (DX <= 0.0) {
+    *IER = -2;
+    return 0.0;
+  }
+  U = T - X[I - 1];
+  B2 = U / DX;
+  B1 = 1.0 - B2;
+  Y1 = Y[I - 1];
+  S1 = YP[I - 1];
+  S = (Y[IP1 - 1] - Y1) / DX;
+  D1 = S - S1;
+  D2 = YP[IP1 - 1] - S;
+  SIG = fabs(SIGMA[I - 1]);
+  if (SIG < 1.e-9) {
+    return Y1 + U * (S1 + B2 * (D1 + B1 * (D1 - D2)));
+  } else if (SIG <= .5) {
+    SB2 = SIG * B2;
+    lto_snhcsh(SIG, &SM, &CM, &CMM);
+    lto_snhcsh(SB2, &SM2, &CM2, &DUMMY);
+    E = SIG * SM - CMM - CMM;
+    return Y1 + S1 * U +
+           DX * ((CM * SM2 - SM * CM2) * (D1 + D2) + SIG * (CM * CM2 - (SM + SIG) * SM2) * D1) /
+               (SIG * E);
+  } else {
+    SB1 = SIG * B1;
+    SB2 = SIG - SB1;
+    if (-SB1 > SBIG || -SB2 > SBIG) {
+      return Y1 + S * U;
+    } else {
+      E1 = exp(-SB1);
+      E2 = exp(-SB2);
+      EMS = E1 * E2;
+      TM = 1.0 - EMS;
+      TS = TM * TM;
+      TP = 1.0 + EMS;
+      E = TM * (SIG * TP - TM - TM);
+      return Y1 + S * U +
+             DX * (TM * (TP - E1 - E2) * (D1 + D2) +
+                   SIG * ((E2 + EMS * (E1 - 2.0) - B1 * TS) * D1 +
+                          (E1 + EMS * (E2 - 2.0) - B2 * TS) * D2)) /
+                 (SIG * E);
+    }
+  }
+}
+
+/* HPVAL, tension_module.f90:1124-1253 */
+double lto_hpval(double T, int N, const double *X, const double *Y, const double *YP,
+                 const double *SIGMA, int *IER) {
+  const double SBIG = 85.0;
+  int I, IP1;
+  double B1, B2, CM, CM2, CMM, D1, D2, DUMMY, DX, E, E1, E2, EMS, S, S1, SB1, SB2, SIG, SINH2,
+      SM, SM2, TM;
+  if (N < 2) {
+    *IER = -1;
+    return 0.0;
+  }
+  if (T < X[0]) {
+    I = 1;
+    *IER = 1;
+  } else if (T > X[N - 1]) {
+    I = N - 1;
+    *IER = 1;
+  } else {
+    I = intrvl(T, N, X);
+    *IER = 0;
+  }
+  IP1 = I + 1;
+  DX = X[IP1 - 1] - X[I - 1];
+  if (DX <= 0.0) {
+    *IER = -2;
+    return 0.0;
+  }
+  B1 = (X[IP1 - 1] - T) / DX;
+  B2 = 1.0 - B1;
+  S1 = YP[I - 1];
+  S = (Y[IP1 - 1] - Y[I - 1]) / DX;
+  D1 = S - S1;
+  D2 = YP[IP1 - 1] - S;
+  SIG = fabs(SIGMA[I - 1]);
+  if (SIG < 1.e-9) {
+    return S1 + B2 * (D1 + D2 - 3.0 * B1 * (D2 - D1));
+  } else if (SIG <= .5) {
+    SB2 = SIG * B2;
+    lto_snhcsh(SIG, &SM, &CM, &CMM);
+    lto_snhcsh(SB2, &SM2, &CM2, &DUMMY);
+    SINH2 = SM2 + SB2;
+    E = SIG * SM - CMM - CMM;
+    return S1 + ((CM * CM2 - SM * SINH2) * (D1 + D2) + SIG * (CM * SINH2 - (SM + SIG) * CM2) * D1) / E;
+  } else {
+    SB1 = SIG * B1;
+    SB2 = SIG - SB1;
+    if (-SB1 > SBIG || -SB2 > SBIG) {
+      return S;
+    } else {
+      E1 = exp(-SB1);
+      E2 = exp(-SB2);
+      EMS = E1 * E2;
+      TM = 1.0 - EMS;
+      E = TM * (SIG * (1.0 + EMS) - TM - TM);
+      return S + (TM * ((E2 - E1) * (D1 + D2) + TM * (D1 - D2)) +
+                  SIG * ((E1 * EMS - E2) * D1 + (E1 - E2 * EMS) * D2)) /
+                     E;
+    }
+  }
+}
+
+#include "ltrans_oracle_engine.inc"

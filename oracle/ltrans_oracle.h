@@ -1,0 +1,95 @@
+/*
+ * ltrans_oracle.h -- CPU ORACLE for the LTRANS v.2b particle-advection path.
+ *
+ * TEST INFRASTRUCTURE.  This is a plain-C, double-precision restatement of the
+ * reference algorithm (Model/LTRANS.f90:707-1614 and the module procedures it
+ * calls), written to be read side by side with the Fortran: it keeps the
+ * reference's structure (per-call weight recomputation, O(nbounds) scans,
+ * 1-based ids, column-major arrays).  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it; the product (ltransv.2b_amd/)
+ * never does.
+ *
+ * Pinning (see DESIGN.md "Oracle"): the leaf numerics exported below
+ * (MT19937, polintd, linint, gridcell, inpoly, TSPSI/SIGS/YPC1/SNHCSH, HVAL,
+ * HPVAL) are checked bit-for-bit against the reference's own modules compiled
+ * with flang (oracle/_ref, tests/golden).  The procedures that cannot be
+ * compiled here because they USE PARAM_MOD -> netcdf (update_particles,
+ * find_currents, WCTS_ITPI, interp, setEle, VTurb, HTurb, norm,
+ * intersect_reflect, mbounds/ibounds, behave, testSettlement) are restated
+ * from the source text only: for those, parity is UNPINNED.
+ *
+ * The lto_* engine API mirrors include/ltrans_hip.h one to one so the same
+ * host code drives both.
+ */
+#ifndef LTRANS_ORACLE_H
+#define LTRANS_ORACLE_H
+
+#include "../include/ltrans_hip.h" /* struct definitions only */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lto_engine lto_engine;
+
+int lto_create(const lt_config *cfg, lto_engine **out);
+int lto_destroy(lto_engine *e);
+int lto_set_grid(lto_engine *e, const lt_grid *g);
+int lto_set_bounds(lto_engine *e, const lt_bounds *b);
+int lto_set_habitat(lto_engine *e, const lt_habitat *h);
+int lto_set_particles(lto_engine *e, const lt_particles *p);
+int lto_set_slab(lto_engine *e, int32_t slot, const lt_slab *s);
+int lto_set_time_slots(lto_engine *e, int32_t t_b, int32_t t_c, int32_t t_f);
+int lto_set_rng(lto_engine *e, const int32_t *mt624, int32_t mti);
+int lto_get_rng(lto_engine *e, int32_t *mt624, int32_t *mti);
+int lto_count_active(lto_engine *e, const double *ix3, int64_t *n_active);
+int lto_set_rng_window(lto_engine *e, int64_t active_before, int64_t active_total);
+int lto_step(lto_engine *e, const double *ex3, const double *ix3, int32_t p, int32_t it);
+int lto_sync(lto_engine *e);
+int lto_get_stats(lto_engine *e, lt_step_stats *out);
+int lto_get_particles(lto_engine *e, lt_particles *out);
+
+/* ---- leaf numerics, exported for pinning against oracle/_ref ------------ */
+typedef struct lto_mt { uint32_t mt[624]; int32_t mti; } lto_mt;
+void     lto_init_genrand(lto_mt *s, uint32_t seed);      /* random_module.f90:108 */
+uint32_t lto_genrand_int32(lto_mt *s);                    /* :166 */
+double   lto_genrand_real1(lto_mt *s);                    /* :213 */
+double   lto_genrand_real3(lto_mt *s);                    /* :239 */
+double   lto_norm(lto_mt *s, double PI);                  /* norm_module.f90:25 */
+
+double lto_polintd(const double *xa, const double *ya, double x); /* interpolation_module.f90:70 */
+void   lto_linint(const double *xa, const double *ya, int n, double x,
+                  double *y, double *m);                          /* :25 */
+/* gridcell_module.f90:26; ele_x/ele_y (4,elements) column-major;
+ * checkele <= 0 = full scan.  p_ele/triangle are only written on a hit. */
+void lto_gridcell(int elements, const double *ele_y, const double *ele_x,
+                  double Xpos, double Ypos, int *P_ele, int *triangle, int checkele);
+/* point_in_polygon_module.f90:25; e is (n,2) column-major; onin <0 absent */
+int lto_inpoly(double x, double y, int n, const double *e, int onin);
+
+void   lto_snhcsh(double x, double *sinhm, double *coshm, double *coshmm); /* tension_module.f90:784 */
+void   lto_ypc1(int n, const double *x, const double *y, double *yp, int *ier);   /* :852 */
+void   lto_sigs(int n, const double *x, const double *y, const double *yp,
+                double *sigma, int *ier, int *sigerr);                            /* :314 */
+void   lto_tspsi(int n, const double *x, const double *y, double *yp,
+                 double *sigma, int *ier, int *sigerr);                           /* :231 */
+double lto_hval(double t, int n, const double *x, const double *y,
+                const double *yp, const double *sigma, int *ier);                 /* :980 */
+double lto_hpval(double t, int n, const double *x, const double *y,
+                 const double *yp, const double *sigma, int *ier);                /* :1124 */
+
+/* composite pieces exported for unit tests (operate on an engine's state) */
+double lto_getSlevel(const lto_engine *e, double zeta, double depth, int i);
+double lto_getWlevel(const lto_engine *e, double zeta, double depth, int i);
+void   lto_intersect_reflect(const lto_engine *e, double Xpos, double Ypos,
+                             double nXpos, double nYpos, double *fix, double *fiy,
+                             double *frx, double *fry, int *intersectf,
+                             int *skipbound, int *isWater);
+void   lto_mbounds(const lto_engine *e, double Ypos, double Xpos, int *inbounds);
+void   lto_ibounds(const lto_engine *e, int *in_island, double claty, double clongx,
+                   double *island);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

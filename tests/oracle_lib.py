@@ -1,0 +1,128 @@
+"""ctypes access to the CPU checkers under oracle/ (test infrastructure only)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libltrans_oracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libltrans_ref.so")
+
+_vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+
+
+def build_oracle():
+    srcs = [os.path.join(ORACLE_DIR, f) for f in
+            ("ltrans_oracle.c", "ltrans_oracle.h", "ltrans_oracle_engine.inc")]
+    if (not os.path.exists(ORACLE_SO)
+            or os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(s) for s in srcs)):
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "-B", "liboracle"])
+    return ORACLE_SO
+
+
+def load_oracle():
+    lib = C.CDLL(build_oracle())
+    for f in ("lto_genrand_real1", "lto_genrand_real3", "lto_norm", "lto_polintd", "lto_hval",
+              "lto_hpval", "lto_getSlevel", "lto_getWlevel"):
+        getattr(lib, f).restype = C.c_double
+    lib.lto_genrand_int32.restype = C.c_uint32
+    return lib
+
+
+def load_ref():
+    if not os.path.exists(REF_SO):
+        return None
+    lib = C.CDLL(REF_SO)
+    for f in ("ref_polintd", "ref_hval", "ref_hpval"):
+        getattr(lib, f).restype = C.c_double
+    return lib
+
+
+class MT(C.Structure):
+    _fields_ = [("mt", C.c_uint32 * 624), ("mti", C.c_int32)]
+
+
+# ---- uniform wrappers: same python signature for oracle ("o") and reference ("r")
+class Leaf:
+    def __init__(self, lib, kind):
+        self.lib, self.kind = lib, kind
+        self._mt = MT()
+
+    def init_genrand(self, seed):
+        if self.kind == "o":
+            self.lib.lto_init_genrand(C.byref(self._mt), C.c_uint32(seed))
+        else:
+            self.lib.ref_init_genrand(C.c_int(np.int32(np.uint32(seed))))
+
+    def int32(self, n):
+        out = np.zeros(n, dtype=np.uint32)
+        if self.kind == "o":
+            for i in range(n):
+                out[i] = self.lib.lto_genrand_int32(C.byref(self._mt))
+        else:
+            self.lib.ref_genrand_int32(C.c_int(n), _vp(out))
+        return out
+
+    def real(self, which, n):
+        out = np.zeros(n)
+        if self.kind == "o":
+            f = self.lib.lto_genrand_real1 if which == 1 else self.lib.lto_genrand_real3
+            for i in range(n):
+                out[i] = f(C.byref(self._mt))
+        else:
+            f = self.lib.ref_genrand_real1 if which == 1 else self.lib.ref_genrand_real3
+            f(C.c_int(n), _vp(out))
+        return out
+
+    def polintd(self, xa, ya, x):
+        xa, ya = np.ascontiguousarray(xa, dtype=np.float64), np.ascontiguousarray(ya, dtype=np.float64)
+        f = self.lib.lto_polintd if self.kind == "o" else self.lib.ref_polintd
+        return f(_vp(xa), _vp(ya), C.c_double(x))
+
+    def linint(self, xa, ya, x):
+        xa, ya = np.ascontiguousarray(xa, dtype=np.float64), np.ascontiguousarray(ya, dtype=np.float64)
+        y, m = C.c_double(), C.c_double()
+        f = self.lib.lto_linint if self.kind == "o" else self.lib.ref_linint
+        f(_vp(xa), _vp(ya), C.c_int(xa.size), C.c_double(x), C.byref(y), C.byref(m))
+        return y.value, m.value
+
+    def gridcell(self, ele_x, ele_y, x, y, checkele=0):
+        """ele_x/ele_y: (4,elements). -> (P_ele, triangle) with P_ele=0 when nothing was set."""
+        ex = np.asfortranarray(ele_x, dtype=np.float64)
+        ey = np.asfortranarray(ele_y, dtype=np.float64)
+        p, t = C.c_int(0), C.c_int(0)
+        f = self.lib.lto_gridcell if self.kind == "o" else self.lib.ref_gridcell
+        f(C.c_int(ex.shape[1]), _vp(ey), _vp(ex), C.c_double(x), C.c_double(y), C.byref(p),
+          C.byref(t), C.c_int(checkele))
+        return p.value, t.value
+
+    def inpoly(self, x, y, e, onin=-1):
+        e = np.asfortranarray(e, dtype=np.float64)
+        if self.kind == "o":
+            return self.lib.lto_inpoly(C.c_double(x), C.c_double(y), C.c_int(e.shape[0]), _vp(e), C.c_int(onin))
+        return self.lib.ref_inpoly(C.c_double(x), C.c_double(y), C.c_int(e.shape[0]), _vp(e), C.c_int(onin))
+
+    def tspsi(self, x, y):
+        x, y = np.ascontiguousarray(x, dtype=np.float64), np.ascontiguousarray(y, dtype=np.float64)
+        n = x.size
+        yp, sig = np.zeros(n), np.zeros(n)
+        ier, se = C.c_int(0), C.c_int(0)
+        f = self.lib.lto_tspsi if self.kind == "o" else self.lib.ref_tspsi
+        f(C.c_int(n), _vp(x), _vp(y), _vp(yp), _vp(sig), C.byref(ier), C.byref(se))
+        return yp, sig, ier.value, se.value
+
+    def hval(self, t, x, y, yp, sig, deriv=False):
+        a = [np.ascontiguousarray(v, dtype=np.float64) for v in (x, y, yp, sig)]
+        ier = C.c_int(0)
+        name = ("lto_" if self.kind == "o" else "ref_") + ("hpval" if deriv else "hval")
+        v = getattr(self.lib, name)(C.c_double(t), C.c_int(a[0].size), _vp(a[0]), _vp(a[1]),
+                                    _vp(a[2]), _vp(a[3]), C.byref(ier))
+        return v, ier.value
+
+    def snhcsh(self, x):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        f = self.lib.lto_snhcsh if self.kind == "o" else self.lib.ref_snhcsh
+        f(C.c_double(x), C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
