@@ -1,0 +1,103 @@
+// lt_device.h -- device-resident data model of the engine (gfx950).
+//
+// HBM layout (see DESIGN.md "Data layout"):
+//   particles   par(numpar,13) exactly as the reference holds it: attribute-major
+//               SoA, so lane n reads par[k*numpar+n] coalesced (LTRANS.f90:104-120)
+//   rho nodes   one 32-byte record {x, y, depth, angle} per node (2 x dwordx4)
+//   u / v nodes one 16-byte record {x, y}
+//   elements    int4 node ids per wet element; adjacency rows [element][10]
+//   slabs       [node][level][slot] (slot = the reference's FIRST index of
+//               t_Uvel(3,node,level), hydrodynamic_module.f90:682-689): the 4
+//               levels x 3 time slots a spline window needs are 48 contiguous
+//               bytes in fp32 storage instead of 12 scattered 8-byte words
+//   zeta        [node][4] (3 slots + pad) -> one aligned dwordx4
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ltd {
+
+struct RhoNode { double x, y, depth, angle; };
+struct XYNode { double x, y; };
+
+enum Counter : int {
+  CNT_ACTIVE = 0,     // particles tracked this step
+  CNT_ERRORS = 1,     // particles that raised an err_code
+  CNT_SIGERR = 2,     // spline fits that fell back to linint (SigErr /= 0)
+  CNT_BRUTE = 3,      // boundary queries that used the full segment scan
+  CNT_PIP_SLOW = 4,   // point-in-polygon queries that used the full algorithm
+  CNT_COUNT = 8
+};
+
+// uniform-grid index over boundary segments: cell (cx,cy) lists, ascending and
+// de-duplicated, every segment whose bounding box overlaps the 2x2 block of
+// cells (cx..cx+1, cy..cy+1).  A particle move whose bounding box spans at
+// most 2 cells per axis therefore reads ONE list in reference order.
+struct SegIndex {
+  const int* ptr;   // (ncx*ncy+1)
+  const int* ids;   // 1-based segment ids
+  double x0, y0, inv_cw, inv_ch;
+  int ncx, ncy;
+};
+
+// y-slab index over polygon edges for the crossings test: bin b lists (ascending)
+// every edge i -> i+1 whose closed y-range overlaps the bin.
+struct PipIndex {
+  const int* ptr;   // (nbins+1)
+  const int* ids;   // 1-based index of the edge's first point
+  double y0, inv_h;
+  int nbins;
+};
+
+struct StepParams {
+  // ---- particle state (device copies of the reference's arrays)
+  double* par;
+  int numpar;
+  int *P_r_element, *P_u_element, *P_v_element;
+  int *P_behave, *dead, *oob, *settle, *endpoly, *hitBottom, *hitLand, *err_code;
+  double *P_swim, *P_pediage, *P_deadage, *settletime;
+  // ---- grid statics
+  const RhoNode* rnode;
+  const XYNode* unode;
+  const XYNode* vnode;
+  const int4* RE;
+  const int4* UE;
+  const int4* VE;
+  const int* rAdj;  // [element][10]
+  const int* uAdj;
+  const int* vAdj;
+  const double* lev;  // 6 tables of 64 doubles: hc*SC, CS, aux (rho) ; hc*SCW, CSW, aux (w)
+  int us, ws;
+  int Vtransform;
+  double hc, z0;
+  // ---- hydrodynamic slabs
+  const void *U, *V, *W, *Kh, *zeta;
+  int tb, tc, tf;  // 0-based physical slot of the back / centre / forward record
+  // ---- time
+  double ex0, ex1, ex2, ix0, ix1, ix2;
+  int p, it, idt;
+  // ---- options
+  int Behavior, OpenOceanBoundary, mortality, settlementon, holesExist, ErrorFlag, TrackCollisions;
+  double swimstart, swimfast, sink;
+  // ---- boundaries
+  const double* bnd;   // [nbounds][4] = x1, y1, x2, y2
+  const int* land;     // [nbounds]
+  int nbounds;
+  SegIndex seg;
+  int use_seg_index;
+  const double* bx; const double* by; int maxbound;
+  const double* hx; const double* hy; const int* hid; int maxisland; int numislands;
+  PipIndex pip_main, pip_isl;
+  int use_pip_index;
+  // ---- habitat
+  const double* polys; const double* holes; int pedges, hedges;
+  const int* polyspecs; const int* holespecs; int npoly, nhole;
+  const double* maxbdis; const double* maxhdis;
+  const int* elepolys_ptr; const int* elepolys_ids;
+  const int* polyholes_ptr; const int* polyholes_ids;
+  int minpolyid, minholeid;
+  // ---- counters
+  unsigned long long* counters;
+};
+
+}  // namespace ltd

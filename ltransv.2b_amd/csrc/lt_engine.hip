@@ -1,0 +1,705 @@
+// lt_engine.hip -- host side of the C ABI (include/ltrans_hip.h) for gfx950.
+//
+// Owns the device mirrors of the module state that update_particles() reads
+// (LTRANS.f90:707-1419), builds the boundary indexes once per lt_set_bounds,
+// and launches the step kernel of lt_kernels.h.  There is NO CPU fallback: every
+// entry point that computes runs on the HIP device or fails with LT_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/ltrans_hip.h"
+#include "lt_kernels.h"
+
+using namespace ltd;
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct HostIndex {
+  std::vector<int> ptr, ids;
+};
+
+}  // namespace
+
+struct lt_engine {
+  lt_config cfg;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  char err[512] = {0};
+  // grid
+  bool have_grid = false, have_bounds = false, have_habitat = false, have_particles = false;
+  int rho_nodes = 0, u_nodes = 0, v_nodes = 0, rho_elements = 0, u_elements = 0, v_elements = 0;
+  DevBuf rnode, unode, vnode, RE, UE, VE, rAdj, uAdj, vAdj, lev;
+  // slabs
+  DevBuf U, V, W, Kh, zeta, staging, flags;
+  bool slab_set[4] = {false, false, false, false};
+  int t_b = 1, t_c = 2, t_f = 3;
+  // bounds
+  DevBuf bnd, land, bx, by, hx, hy, hid, seg_ptr, seg_ids, pm_ptr, pm_ids, pi_ptr, pi_ids;
+  int nbounds = 0, maxbound = 0, maxisland = 0, numislands = 0;
+  SegIndex seg{};
+  PipIndex pip_main{}, pip_isl{};
+  int use_seg_index = 1, use_pip_index = 1;
+  // habitat
+  DevBuf polys, holes, polyspecs, holespecs, maxbdis, maxhdis, ep_ptr, ep_ids, ph_ptr, ph_ids;
+  lt_habitat hab{};
+  int npoly = 0, nhole = 0;
+  // particles
+  DevBuf par, pr, pu, pv, P_behave, dead, oob, settle, endpoly, hitBottom, hitLand, err_code,
+      P_swim, P_pediage, P_deadage, settletime;
+  // rng (host copy of the state; turbulence kernels are not part of this build yet)
+  uint32_t mt[624];
+  int32_t mti = 624;
+  int64_t rng_before = 0, rng_total = -1;
+  // counters
+  DevBuf counters;
+  unsigned long long* h_counters = nullptr;  // pinned
+  lt_step_stats stats{};
+  bool stats_valid = true;
+  std::vector<DevBuf*> all;
+};
+
+namespace {
+
+int fail(lt_engine* e, int code, const char* fmt, ...) {
+  if (e) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(e->err, sizeof(e->err), fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+#define HIPCHK(e, call)                                                                    \
+  do {                                                                                     \
+    hipError_t _r = (call);                                                                \
+    if (_r != hipSuccess)                                                                  \
+      return fail(e, LT_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_r), \
+                  __FILE__, __LINE__);                                                     \
+  } while (0)
+
+int dev_alloc(lt_engine* e, DevBuf& b, size_t bytes) {
+  if (b.p && b.bytes >= bytes && bytes > 0) return LT_OK;
+  if (b.p) {
+    (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+  }
+  size_t n = bytes ? bytes : 16;
+  HIPCHK(e, hipMalloc(&b.p, n));
+  b.bytes = n;
+  return LT_OK;
+}
+
+int upload(lt_engine* e, DevBuf& b, const void* src, size_t bytes) {
+  int rc = dev_alloc(e, b, bytes);
+  if (rc) return rc;
+  if (bytes) HIPCHK(e, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, e->stream));
+  return LT_OK;
+}
+
+#define TRY(x)            \
+  do {                    \
+    int _rc = (x);        \
+    if (_rc) return _rc;  \
+  } while (0)
+
+// adjacency: (elements,10) column-major -> [element][10]; verify that rows start
+// with the element itself and that zeros only trail (hydrodynamic_module.f90:590-647)
+int convert_adjacency(lt_engine* e, const int32_t* adj, int elements, std::vector<int>& out,
+                      const char* name) {
+  out.resize((size_t)elements * 10);
+  for (int i = 0; i < elements; i++) {
+    bool zero_seen = false;
+    for (int k = 0; k < 10; k++) {
+      int v = adj[(size_t)i + (size_t)elements * k];
+      if (v < 0 || v > elements) return fail(e, LT_ERR_ARG, "%s(%d,%d)=%d out of range", name, i + 1, k + 1, v);
+      if (v == 0) zero_seen = true;
+      else if (zero_seen) return fail(e, LT_ERR_ARG, "%s row %d: non-zero entry after a zero", name, i + 1);
+      out[(size_t)i * 10 + k] = v;
+    }
+    if (out[(size_t)i * 10] != i + 1)
+      return fail(e, LT_ERR_ARG, "%s row %d does not start with the element itself", name, i + 1);
+  }
+  return LT_OK;
+}
+
+int check_elements(lt_engine* e, const int32_t* E, int elements, int nodes, const char* name) {
+  for (size_t i = 0; i < (size_t)elements * 4; i++)
+    if (E[i] < 1 || E[i] > nodes) return fail(e, LT_ERR_ARG, "%s node id %d out of range", name, E[i]);
+  return LT_OK;
+}
+
+int check_particle_elements(lt_engine* e, const int32_t* pe, int numpar, int elements, const char* name) {
+  for (int i = 0; i < numpar; i++)
+    if (pe[i] < 1 || pe[i] > elements)
+      return fail(e, LT_ERR_ARG, "%s(%d)=%d is not a valid element id", name, i + 1, pe[i]);
+  return LT_OK;
+}
+
+size_t slab_elem(const lt_engine* e) { return e->cfg.slab_storage == LT_SLAB_F32 ? 4 : 8; }
+
+void fill_params(lt_engine* e, StepParams& P) {
+  memset(&P, 0, sizeof(P));
+  const lt_config& c = e->cfg;
+  P.par = (double*)e->par.p;
+  P.numpar = c.numpar;
+  P.P_r_element = (int*)e->pr.p; P.P_u_element = (int*)e->pu.p; P.P_v_element = (int*)e->pv.p;
+  P.P_behave = (int*)e->P_behave.p; P.dead = (int*)e->dead.p; P.oob = (int*)e->oob.p;
+  P.settle = (int*)e->settle.p; P.endpoly = (int*)e->endpoly.p;
+  P.hitBottom = (int*)e->hitBottom.p; P.hitLand = (int*)e->hitLand.p;
+  P.err_code = (int*)e->err_code.p;
+  P.P_swim = (double*)e->P_swim.p; P.P_pediage = (double*)e->P_pediage.p;
+  P.P_deadage = (double*)e->P_deadage.p; P.settletime = (double*)e->settletime.p;
+  P.rnode = (const RhoNode*)e->rnode.p; P.unode = (const XYNode*)e->unode.p;
+  P.vnode = (const XYNode*)e->vnode.p;
+  P.RE = (const int4*)e->RE.p; P.UE = (const int4*)e->UE.p; P.VE = (const int4*)e->VE.p;
+  P.rAdj = (const int*)e->rAdj.p; P.uAdj = (const int*)e->uAdj.p; P.vAdj = (const int*)e->vAdj.p;
+  P.lev = (const double*)e->lev.p;
+  P.us = c.us; P.ws = c.ws; P.Vtransform = c.Vtransform;
+  P.hc = (double)c.hc;  // REAL promoted (LTRANS.h:66)
+  P.z0 = c.z0;
+  P.U = e->U.p; P.V = e->V.p; P.W = e->W.p; P.Kh = e->Kh.p; P.zeta = e->zeta.p;
+  P.tb = e->t_b - 1; P.tc = e->t_c - 1; P.tf = e->t_f - 1;
+  P.idt = c.idt;
+  P.Behavior = c.Behavior; P.OpenOceanBoundary = c.OpenOceanBoundary; P.mortality = c.mortality;
+  P.settlementon = c.settlementon; P.holesExist = c.holesExist; P.ErrorFlag = c.ErrorFlag;
+  P.TrackCollisions = c.TrackCollisions;
+  P.swimstart = c.swimstart; P.swimfast = c.swimfast; P.sink = c.sink;
+  P.bnd = (const double*)e->bnd.p; P.land = (const int*)e->land.p; P.nbounds = e->nbounds;
+  P.seg = e->seg; P.use_seg_index = e->use_seg_index;
+  P.bx = (const double*)e->bx.p; P.by = (const double*)e->by.p; P.maxbound = e->maxbound;
+  P.hx = (const double*)e->hx.p; P.hy = (const double*)e->hy.p; P.hid = (const int*)e->hid.p;
+  P.maxisland = e->maxisland; P.numislands = e->numislands;
+  P.pip_main = e->pip_main; P.pip_isl = e->pip_isl; P.use_pip_index = e->use_pip_index;
+  P.polys = (const double*)e->polys.p; P.holes = (const double*)e->holes.p;
+  P.pedges = e->hab.pedges; P.hedges = e->hab.hedges;
+  P.polyspecs = (const int*)e->polyspecs.p; P.holespecs = (const int*)e->holespecs.p;
+  P.npoly = e->npoly; P.nhole = e->nhole;
+  P.maxbdis = (const double*)e->maxbdis.p; P.maxhdis = (const double*)e->maxhdis.p;
+  P.elepolys_ptr = (const int*)e->ep_ptr.p; P.elepolys_ids = (const int*)e->ep_ids.p;
+  P.polyholes_ptr = (const int*)e->ph_ptr.p; P.polyholes_ids = (const int*)e->ph_ids.p;
+  P.minpolyid = e->hab.minpolyid; P.minholeid = e->hab.minholeid;
+  P.counters = (unsigned long long*)e->counters.p;
+}
+
+// ---- boundary indexes (host, once per lt_set_bounds) --------------------
+// uniform grid over the segments' bounding box; the list of cell (cx,cy) is the
+// ascending union of the segments overlapping cells (cx..cx+1, cy..cy+1)
+void build_seg_index(const double* bnd_x, const double* bnd_y, int nb, SegIndex& S, HostIndex& H) {
+  double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300, len = 0.0;
+  for (int i = 0; i < nb; i++) {
+    double x1 = bnd_x[2 * i], x2 = bnd_x[2 * i + 1], y1 = bnd_y[2 * i], y2 = bnd_y[2 * i + 1];
+    xmin = std::min(xmin, std::min(x1, x2)); xmax = std::max(xmax, std::max(x1, x2));
+    ymin = std::min(ymin, std::min(y1, y2)); ymax = std::max(ymax, std::max(y1, y2));
+    len += std::sqrt((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2));
+  }
+  if (nb == 0) { xmin = ymin = 0.0; xmax = ymax = 1.0; len = 1.0; }
+  double cell = 2.0 * len / std::max(nb, 1);
+  if (!(cell > 0.0)) cell = 1.0;
+  double wx = std::max(xmax - xmin, cell), wy = std::max(ymax - ymin, cell);
+  while ((wx / cell + 1.0) * (wy / cell + 1.0) > 4.0e6) cell *= 2.0;
+  S.x0 = xmin; S.y0 = ymin;
+  S.inv_cw = 1.0 / cell; S.inv_ch = 1.0 / cell;
+  S.ncx = (int)std::floor(wx / cell) + 1;
+  S.ncy = (int)std::floor(wy / cell) + 1;
+  auto cellx = [&](double x) { double f = std::floor((x - S.x0) * S.inv_cw); return (int)std::min<double>(std::max(f, 0.0), S.ncx - 1); };
+  auto celly = [&](double y) { double f = std::floor((y - S.y0) * S.inv_ch); return (int)std::min<double>(std::max(f, 0.0), S.ncy - 1); };
+  std::vector<std::vector<int>> cells((size_t)S.ncx * S.ncy);
+  for (int i = 0; i < nb; i++) {
+    double x1 = bnd_x[2 * i], x2 = bnd_x[2 * i + 1], y1 = bnd_y[2 * i], y2 = bnd_y[2 * i + 1];
+    int cx0 = cellx(std::min(x1, x2)), cx1 = cellx(std::max(x1, x2));
+    int cy0 = celly(std::min(y1, y2)), cy1 = celly(std::max(y1, y2));
+    // a query block (bx,by) covers cells bx..bx+1, by..by+1
+    for (int by = std::max(cy0 - 1, 0); by <= cy1; by++)
+      for (int bx = std::max(cx0 - 1, 0); bx <= cx1; bx++) cells[(size_t)bx + (size_t)by * S.ncx].push_back(i + 1);
+  }
+  H.ptr.assign((size_t)S.ncx * S.ncy + 1, 0);
+  H.ids.clear();
+  for (size_t c = 0; c < cells.size(); c++) {
+    auto& v = cells[c];
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+    H.ptr[c] = (int)H.ids.size();
+    H.ids.insert(H.ids.end(), v.begin(), v.end());
+  }
+  H.ptr[cells.size()] = (int)H.ids.size();
+}
+
+// y-slab edge index of a chain of closed polygons given as consecutive points;
+// `same_poly(i)` tells whether points i and i+1 (0-based) belong to one polygon
+template <typename F>
+void build_pip_index(const double* py, int npts, F same_poly, PipIndex& I, HostIndex& H) {
+  double ymin = 1e300, ymax = -1e300;
+  for (int i = 0; i < npts; i++) { ymin = std::min(ymin, py[i]); ymax = std::max(ymax, py[i]); }
+  if (npts == 0) { ymin = 0.0; ymax = 1.0; }
+  int nb = std::min(8192, std::max(16, npts / 2));
+  double h = (ymax - ymin) / nb;
+  if (!(h > 0.0)) h = 1.0;
+  I.y0 = ymin; I.inv_h = 1.0 / h; I.nbins = nb;
+  auto bin = [&](double y) { double f = std::floor((y - I.y0) * I.inv_h); return (int)std::min<double>(std::max(f, 0.0), nb - 1); };
+  std::vector<std::vector<int>> bins(nb);
+  for (int i = 0; i + 1 < npts; i++) {
+    if (!same_poly(i)) continue;
+    int b0 = bin(std::min(py[i], py[i + 1])), b1 = bin(std::max(py[i], py[i + 1]));
+    for (int b = b0; b <= b1; b++) bins[b].push_back(i + 1);
+  }
+  H.ptr.assign(nb + 1, 0);
+  H.ids.clear();
+  for (int b = 0; b < nb; b++) {
+    H.ptr[b] = (int)H.ids.size();
+    H.ids.insert(H.ids.end(), bins[b].begin(), bins[b].end());
+  }
+  H.ptr[nb] = (int)H.ids.size();
+}
+
+template <typename SlabT>
+int scatter_field(lt_engine* e, const double* src, DevBuf& dst, int nodes, int L, int slot) {
+  size_t total = (size_t)nodes * L;
+  HIPCHK(e, hipMemcpyAsync(e->staging.p, src, total * 8, hipMemcpyHostToDevice, e->stream));
+  unsigned blocks = (unsigned)((total + 255) / 256);
+  hipLaunchKernelGGL((k_slab_scatter<SlabT>), dim3(blocks), dim3(256), 0, e->stream,
+                     (const double*)e->staging.p, (SlabT*)dst.p, nodes, L, slot - 1, (int*)e->flags.p);
+  HIPCHK(e, hipGetLastError());
+  return LT_OK;
+}
+
+template <typename SlabT>
+int set_slab_t(lt_engine* e, int slot, const lt_slab* s) {
+  const int us = e->cfg.us, ws = e->cfg.ws;
+  HIPCHK(e, hipMemcpyAsync(e->staging.p, s->zeta, (size_t)e->rho_nodes * 8, hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL((k_zeta_scatter<SlabT>), dim3((e->rho_nodes + 255) / 256), dim3(256), 0, e->stream,
+                     (const double*)e->staging.p, (SlabT*)e->zeta.p, e->rho_nodes, slot - 1, (int*)e->flags.p);
+  HIPCHK(e, hipGetLastError());
+  TRY(scatter_field<SlabT>(e, s->Uvel, e->U, e->u_nodes, us, slot));
+  TRY(scatter_field<SlabT>(e, s->Vvel, e->V, e->v_nodes, us, slot));
+  TRY(scatter_field<SlabT>(e, s->Wvel, e->W, e->rho_nodes, ws, slot));
+  if (s->Kh) TRY(scatter_field<SlabT>(e, s->Kh, e->Kh, e->rho_nodes, ws, slot));
+  int flag = 0;
+  HIPCHK(e, hipMemcpyAsync(&flag, e->flags.p, 4, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));  // the caller's arrays may change after return
+  if (flag) {
+    (void)hipMemsetAsync(e->flags.p, 0, 16, e->stream);
+    return fail(e, LT_ERR_SLAB_NOT_F32,
+                "slab value is not exactly representable in the device storage type; "
+                "use slab_storage = LT_SLAB_F64");
+  }
+  return LT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lt_abi_version(void) { return LT_ABI_VERSION; }
+
+const char* lt_last_error(const lt_engine* e) { return e ? e->err : "null engine"; }
+
+int lt_create(const lt_config* cfg, lt_engine** out) {
+  if (!cfg || !out) return LT_ERR_ARG;
+  *out = nullptr;
+  if (cfg->struct_size != (int32_t)sizeof(lt_config) || cfg->abi_version != LT_ABI_VERSION)
+    return LT_ERR_ABI;
+  if (cfg->numpar < 0 || cfg->us < 5 || cfg->ws != cfg->us + 1 || cfg->ws > LT_LEV_STRIDE ||
+      cfg->idt <= 0 || cfg->Vtransform < 1 || cfg->Vtransform > 3)
+    return LT_ERR_ARG;
+  if (cfg->FreeSlip || cfg->SaltTempOn) return LT_ERR_UNSUPPORTED;
+  if (!(cfg->Behavior == 0 || cfg->Behavior == 6)) return LT_ERR_UNSUPPORTED;
+  if (cfg->HTurbOn || cfg->VTurbOn) return LT_ERR_UNSUPPORTED;  // device MT19937 stream: next milestone
+  if (cfg->slab_storage != LT_SLAB_F32 && cfg->slab_storage != LT_SLAB_F64) return LT_ERR_ARG;
+  lt_engine* e = new (std::nothrow) lt_engine();
+  if (!e) return LT_ERR_NOMEM;
+  e->cfg = *cfg;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    delete e;
+    return LT_ERR_DEVICE;
+  }
+  int dev = cfg->device;
+  if (dev < 0) {
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  }
+  if (dev >= ndev || hipSetDevice(dev) != hipSuccess ||
+      hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete e;
+    return LT_ERR_DEVICE;
+  }
+  e->device = dev;
+  if (hipMalloc(&e->counters.p, CNT_COUNT * sizeof(unsigned long long)) != hipSuccess ||
+      hipHostMalloc((void**)&e->h_counters, CNT_COUNT * sizeof(unsigned long long)) != hipSuccess ||
+      hipMalloc(&e->flags.p, 16) != hipSuccess) {
+    lt_destroy(e);
+    return LT_ERR_DEVICE;
+  }
+  e->counters.bytes = CNT_COUNT * sizeof(unsigned long long);
+  e->flags.bytes = 16;
+  (void)hipMemsetAsync(e->flags.p, 0, 16, e->stream);
+  const char* env = getenv("LT_BRUTE_BOUNDS");
+  if (env && atoi(env) != 0) { e->use_seg_index = 0; e->use_pip_index = 0; }
+  // init_genrand(seed), random_module.f90:108-119 / LTRANS.f90:241
+  e->mt[0] = (uint32_t)cfg->seed;
+  for (int i = 1; i < 624; i++) e->mt[i] = 1812433253u * (e->mt[i - 1] ^ (e->mt[i - 1] >> 30)) + (uint32_t)i;
+  e->mti = 624;
+  *out = e;
+  return LT_OK;
+}
+
+int lt_destroy(lt_engine* e) {
+  if (!e) return LT_ERR_ARG;
+  (void)hipSetDevice(e->device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  DevBuf* bufs[] = {&e->rnode, &e->unode, &e->vnode, &e->RE, &e->UE, &e->VE, &e->rAdj, &e->uAdj,
+                    &e->vAdj, &e->lev, &e->U, &e->V, &e->W, &e->Kh, &e->zeta, &e->staging,
+                    &e->flags, &e->bnd, &e->land, &e->bx, &e->by, &e->hx, &e->hy, &e->hid,
+                    &e->seg_ptr, &e->seg_ids, &e->pm_ptr, &e->pm_ids, &e->pi_ptr, &e->pi_ids,
+                    &e->polys, &e->holes, &e->polyspecs, &e->holespecs, &e->maxbdis, &e->maxhdis,
+                    &e->ep_ptr, &e->ep_ids, &e->ph_ptr, &e->ph_ids, &e->par, &e->pr, &e->pu,
+                    &e->pv, &e->P_behave, &e->dead, &e->oob, &e->settle, &e->endpoly,
+                    &e->hitBottom, &e->hitLand, &e->err_code, &e->P_swim, &e->P_pediage,
+                    &e->P_deadage, &e->settletime, &e->counters};
+  for (DevBuf* b : bufs)
+    if (b->p) (void)hipFree(b->p);
+  if (e->h_counters) (void)hipHostFree(e->h_counters);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+  return LT_OK;
+}
+
+int lt_set_grid(lt_engine* e, const lt_grid* g) {
+  if (!e || !g) return LT_ERR_ARG;
+  if (!g->rx || !g->ry || !g->ux || !g->uy || !g->vx || !g->vy || !g->depth || !g->rho_angle ||
+      !g->RE || !g->UE || !g->VE || !g->r_Adjacent || !g->u_Adjacent || !g->v_Adjacent ||
+      !g->SC || !g->CS || !g->SCW || !g->CSW)
+    return fail(e, LT_ERR_ARG, "lt_set_grid: NULL array");
+  if (g->rho_nodes <= 0 || g->u_nodes <= 0 || g->v_nodes <= 0 || g->rho_elements <= 0 ||
+      g->u_elements <= 0 || g->v_elements <= 0)
+    return fail(e, LT_ERR_ARG, "lt_set_grid: bad extents");
+  HIPCHK(e, hipSetDevice(e->device));
+  TRY(check_elements(e, g->RE, g->rho_elements, g->rho_nodes, "RE"));
+  TRY(check_elements(e, g->UE, g->u_elements, g->u_nodes, "UE"));
+  TRY(check_elements(e, g->VE, g->v_elements, g->v_nodes, "VE"));
+  std::vector<RhoNode> rn(g->rho_nodes);
+  for (int i = 0; i < g->rho_nodes; i++) rn[i] = {g->rx[i], g->ry[i], g->depth[i], g->rho_angle[i]};
+  std::vector<XYNode> un(g->u_nodes), vn(g->v_nodes);
+  for (int i = 0; i < g->u_nodes; i++) un[i] = {g->ux[i], g->uy[i]};
+  for (int i = 0; i < g->v_nodes; i++) vn[i] = {g->vx[i], g->vy[i]};
+  std::vector<int> ra, ua, va;
+  TRY(convert_adjacency(e, g->r_Adjacent, g->rho_elements, ra, "r_Adjacent"));
+  TRY(convert_adjacency(e, g->u_Adjacent, g->u_elements, ua, "u_Adjacent"));
+  TRY(convert_adjacency(e, g->v_Adjacent, g->v_elements, va, "v_Adjacent"));
+  // level tables: hc*SC, CS, SC | hc*SCW, CSW, SCW (hc is REAL promoted to double)
+  std::vector<double> lev(6 * LT_LEV_STRIDE, 0.0);
+  const double hc = (double)e->cfg.hc;
+  for (int k = 0; k < e->cfg.us; k++) {
+    lev[0 * LT_LEV_STRIDE + k] = hc * g->SC[k];
+    lev[1 * LT_LEV_STRIDE + k] = g->CS[k];
+    lev[2 * LT_LEV_STRIDE + k] = g->SC[k];
+  }
+  for (int k = 0; k < e->cfg.ws; k++) {
+    lev[3 * LT_LEV_STRIDE + k] = hc * g->SCW[k];
+    lev[4 * LT_LEV_STRIDE + k] = g->CSW[k];
+    lev[5 * LT_LEV_STRIDE + k] = g->SCW[k];
+  }
+  TRY(upload(e, e->rnode, rn.data(), rn.size() * sizeof(RhoNode)));
+  TRY(upload(e, e->unode, un.data(), un.size() * sizeof(XYNode)));
+  TRY(upload(e, e->vnode, vn.data(), vn.size() * sizeof(XYNode)));
+  TRY(upload(e, e->RE, g->RE, (size_t)g->rho_elements * 16));
+  TRY(upload(e, e->UE, g->UE, (size_t)g->u_elements * 16));
+  TRY(upload(e, e->VE, g->VE, (size_t)g->v_elements * 16));
+  TRY(upload(e, e->rAdj, ra.data(), ra.size() * 4));
+  TRY(upload(e, e->uAdj, ua.data(), ua.size() * 4));
+  TRY(upload(e, e->vAdj, va.data(), va.size() * 4));
+  TRY(upload(e, e->lev, lev.data(), lev.size() * 8));
+  e->rho_nodes = g->rho_nodes; e->u_nodes = g->u_nodes; e->v_nodes = g->v_nodes;
+  e->rho_elements = g->rho_elements; e->u_elements = g->u_elements; e->v_elements = g->v_elements;
+  // slabs: ALLOCATE + zero (hydrodynamic_module.f90:682-698)
+  const size_t se = slab_elem(e);
+  const size_t us = e->cfg.us, ws = e->cfg.ws;
+  TRY(dev_alloc(e, e->U, (size_t)e->u_nodes * us * 3 * se));
+  TRY(dev_alloc(e, e->V, (size_t)e->v_nodes * us * 3 * se));
+  TRY(dev_alloc(e, e->W, (size_t)e->rho_nodes * ws * 3 * se));
+  TRY(dev_alloc(e, e->Kh, (size_t)e->rho_nodes * ws * 3 * se));
+  TRY(dev_alloc(e, e->zeta, (size_t)e->rho_nodes * 4 * se));
+  HIPCHK(e, hipMemsetAsync(e->U.p, 0, e->U.bytes, e->stream));
+  HIPCHK(e, hipMemsetAsync(e->V.p, 0, e->V.bytes, e->stream));
+  HIPCHK(e, hipMemsetAsync(e->W.p, 0, e->W.bytes, e->stream));
+  HIPCHK(e, hipMemsetAsync(e->Kh.p, 0, e->Kh.bytes, e->stream));
+  HIPCHK(e, hipMemsetAsync(e->zeta.p, 0, e->zeta.bytes, e->stream));
+  size_t stage = std::max((size_t)e->rho_nodes * ws, (size_t)e->u_nodes * us) * 8;
+  TRY(dev_alloc(e, e->staging, stage));
+  HIPCHK(e, hipStreamSynchronize(e->stream));  // host vectors go out of scope
+  e->have_grid = true;
+  e->slab_set[1] = e->slab_set[2] = e->slab_set[3] = false;
+  return LT_OK;
+}
+
+int lt_set_bounds(lt_engine* e, const lt_bounds* b) {
+  if (!e || !b) return LT_ERR_ARG;
+  if (b->nbounds < 0 || b->maxbound < 0 || b->maxisland < 0 || b->numislands < 0 ||
+      (b->nbounds > 0 && (!b->bnd_x || !b->bnd_y || !b->land)) ||
+      (b->maxbound > 0 && (!b->bx || !b->by)) ||
+      (b->maxisland > 0 && (!b->hx || !b->hy || !b->hid)))
+    return fail(e, LT_ERR_ARG, "lt_set_bounds: bad arguments");
+  HIPCHK(e, hipSetDevice(e->device));
+  std::vector<double> seg((size_t)b->nbounds * 4);
+  for (int i = 0; i < b->nbounds; i++) {
+    seg[4 * (size_t)i + 0] = b->bnd_x[2 * (size_t)i];
+    seg[4 * (size_t)i + 1] = b->bnd_y[2 * (size_t)i];
+    seg[4 * (size_t)i + 2] = b->bnd_x[2 * (size_t)i + 1];
+    seg[4 * (size_t)i + 3] = b->bnd_y[2 * (size_t)i + 1];
+  }
+  HostIndex hs, hm, hi;
+  build_seg_index(b->bnd_x, b->bnd_y, b->nbounds, e->seg, hs);
+  build_pip_index(b->by, b->maxbound, [](int) { return true; }, e->pip_main, hm);
+  const int32_t* hid = b->hid;
+  build_pip_index(b->hy, b->maxisland, [hid](int i) { return hid[i] == hid[i + 1]; }, e->pip_isl, hi);
+  TRY(upload(e, e->bnd, seg.data(), seg.size() * 8));
+  TRY(upload(e, e->land, b->land, (size_t)b->nbounds * 4));
+  TRY(upload(e, e->bx, b->bx, (size_t)b->maxbound * 8));
+  TRY(upload(e, e->by, b->by, (size_t)b->maxbound * 8));
+  TRY(upload(e, e->hx, b->hx, (size_t)b->maxisland * 8));
+  TRY(upload(e, e->hy, b->hy, (size_t)b->maxisland * 8));
+  TRY(upload(e, e->hid, b->hid, (size_t)b->maxisland * 4));
+  TRY(upload(e, e->seg_ptr, hs.ptr.data(), hs.ptr.size() * 4));
+  TRY(upload(e, e->seg_ids, hs.ids.data(), hs.ids.size() * 4));
+  TRY(upload(e, e->pm_ptr, hm.ptr.data(), hm.ptr.size() * 4));
+  TRY(upload(e, e->pm_ids, hm.ids.data(), hm.ids.size() * 4));
+  TRY(upload(e, e->pi_ptr, hi.ptr.data(), hi.ptr.size() * 4));
+  TRY(upload(e, e->pi_ids, hi.ids.data(), hi.ids.size() * 4));
+  e->seg.ptr = (const int*)e->seg_ptr.p; e->seg.ids = (const int*)e->seg_ids.p;
+  e->pip_main.ptr = (const int*)e->pm_ptr.p; e->pip_main.ids = (const int*)e->pm_ids.p;
+  e->pip_isl.ptr = (const int*)e->pi_ptr.p; e->pip_isl.ids = (const int*)e->pi_ids.p;
+  e->nbounds = b->nbounds; e->maxbound = b->maxbound; e->maxisland = b->maxisland;
+  e->numislands = b->numislands;
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  e->have_bounds = true;
+  return LT_OK;
+}
+
+int lt_set_habitat(lt_engine* e, const lt_habitat* h) {
+  if (!e || !h) return LT_ERR_ARG;
+  if (!e->have_grid) return fail(e, LT_ERR_STATE, "lt_set_habitat before lt_set_grid");
+  if (h->pedges <= 0 || !h->polys || !h->polyspecs || !h->maxbdis || !h->elepolys_ptr ||
+      !h->polyholes_ptr || h->maxpolyid < h->minpolyid)
+    return fail(e, LT_ERR_ARG, "lt_set_habitat: bad arguments");
+  HIPCHK(e, hipSetDevice(e->device));
+  e->hab = *h;
+  e->npoly = h->maxpolyid - h->minpolyid + 1;
+  e->nhole = (h->hedges > 0) ? h->maxholeid - h->minholeid + 1 : 0;
+  int nlist = h->elepolys_ptr[e->rho_elements], nph = h->polyholes_ptr[e->npoly];
+  TRY(upload(e, e->polys, h->polys, (size_t)h->pedges * 5 * 8));
+  TRY(upload(e, e->holes, h->holes, (size_t)h->hedges * 6 * 8));
+  TRY(upload(e, e->polyspecs, h->polyspecs, (size_t)e->npoly * 2 * 4));
+  TRY(upload(e, e->holespecs, h->holespecs, (size_t)e->nhole * 2 * 4));
+  TRY(upload(e, e->maxbdis, h->maxbdis, (size_t)e->npoly * 8));
+  TRY(upload(e, e->maxhdis, h->maxhdis, (size_t)e->nhole * 8));
+  TRY(upload(e, e->ep_ptr, h->elepolys_ptr, ((size_t)e->rho_elements + 1) * 4));
+  TRY(upload(e, e->ep_ids, h->elepolys_ids, (size_t)nlist * 4));
+  TRY(upload(e, e->ph_ptr, h->polyholes_ptr, ((size_t)e->npoly + 1) * 4));
+  TRY(upload(e, e->ph_ids, h->polyholes_ids, (size_t)nph * 4));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  e->have_habitat = true;
+  return LT_OK;
+}
+
+#define PUP(buf, field, count, elem)                                                \
+  do {                                                                              \
+    size_t _bytes = (size_t)(count) * (elem);                                       \
+    if (p->field) {                                                                 \
+      TRY(upload(e, e->buf, p->field, _bytes));                                     \
+    } else if (!e->buf.p) {                                                         \
+      TRY(dev_alloc(e, e->buf, _bytes));                                            \
+      HIPCHK(e, hipMemsetAsync(e->buf.p, 0, e->buf.bytes, e->stream));              \
+    }                                                                               \
+  } while (0)
+
+int lt_set_particles(lt_engine* e, const lt_particles* p) {
+  if (!e || !p) return LT_ERR_ARG;
+  if (!e->have_grid) return fail(e, LT_ERR_STATE, "lt_set_particles before lt_set_grid");
+  if (!e->par.p && !p->par) return fail(e, LT_ERR_ARG, "lt_set_particles: par is required");
+  HIPCHK(e, hipSetDevice(e->device));
+  const size_t n = (size_t)e->cfg.numpar;
+  if (p->P_r_element) TRY(check_particle_elements(e, p->P_r_element, (int)n, e->rho_elements, "P_r_element"));
+  if (p->P_u_element) TRY(check_particle_elements(e, p->P_u_element, (int)n, e->u_elements, "P_u_element"));
+  if (p->P_v_element) TRY(check_particle_elements(e, p->P_v_element, (int)n, e->v_elements, "P_v_element"));
+  if (!e->pr.p && !(p->P_r_element && p->P_u_element && p->P_v_element))
+    return fail(e, LT_ERR_ARG, "lt_set_particles: element ids are required on first upload");
+  PUP(par, par, 13 * n, 8);
+  PUP(pr, P_r_element, n, 4); PUP(pu, P_u_element, n, 4); PUP(pv, P_v_element, n, 4);
+  PUP(P_behave, P_behave, n, 4); PUP(dead, dead, n, 4); PUP(oob, oob, n, 4);
+  PUP(P_swim, P_swim, 3 * n, 8); PUP(P_pediage, P_pediage, n, 8); PUP(P_deadage, P_deadage, n, 8);
+  PUP(settle, settle, n, 4); PUP(settletime, settletime, n, 8); PUP(endpoly, endpoly, n, 4);
+  PUP(hitBottom, hitBottom, n, 4); PUP(hitLand, hitLand, n, 4); PUP(err_code, err_code, n, 4);
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  e->have_particles = true;
+  return LT_OK;
+}
+
+#define PDOWN(buf, field, count, elem)                                                          \
+  do {                                                                                          \
+    if (out->field && e->buf.p)                                                                 \
+      HIPCHK(e, hipMemcpyAsync(out->field, e->buf.p, (size_t)(count) * (elem),                  \
+                               hipMemcpyDeviceToHost, e->stream));                              \
+  } while (0)
+
+int lt_get_particles(lt_engine* e, lt_particles* out) {
+  if (!e || !out) return LT_ERR_ARG;
+  if (!e->have_particles) return fail(e, LT_ERR_STATE, "no particles uploaded");
+  HIPCHK(e, hipSetDevice(e->device));
+  const size_t n = (size_t)e->cfg.numpar;
+  PDOWN(par, par, 13 * n, 8);
+  PDOWN(pr, P_r_element, n, 4); PDOWN(pu, P_u_element, n, 4); PDOWN(pv, P_v_element, n, 4);
+  PDOWN(P_behave, P_behave, n, 4); PDOWN(dead, dead, n, 4); PDOWN(oob, oob, n, 4);
+  PDOWN(P_swim, P_swim, 3 * n, 8); PDOWN(P_pediage, P_pediage, n, 8); PDOWN(P_deadage, P_deadage, n, 8);
+  PDOWN(settle, settle, n, 4); PDOWN(settletime, settletime, n, 8); PDOWN(endpoly, endpoly, n, 4);
+  PDOWN(hitBottom, hitBottom, n, 4); PDOWN(hitLand, hitLand, n, 4); PDOWN(err_code, err_code, n, 4);
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return LT_OK;
+}
+
+int lt_set_slab(lt_engine* e, int32_t slot, const lt_slab* s) {
+  if (!e || !s) return LT_ERR_ARG;
+  if (!e->have_grid) return fail(e, LT_ERR_STATE, "lt_set_slab before lt_set_grid");
+  if (slot < 1 || slot > 3 || !s->zeta || !s->Uvel || !s->Vvel || !s->Wvel)
+    return fail(e, LT_ERR_ARG, "lt_set_slab: bad arguments");
+  HIPCHK(e, hipSetDevice(e->device));
+  int rc = (e->cfg.slab_storage == LT_SLAB_F32) ? set_slab_t<float>(e, slot, s)
+                                                : set_slab_t<double>(e, slot, s);
+  if (rc == LT_OK) e->slab_set[slot] = true;
+  return rc;
+}
+
+int lt_set_time_slots(lt_engine* e, int32_t t_b, int32_t t_c, int32_t t_f) {
+  if (!e) return LT_ERR_ARG;
+  if (t_b < 1 || t_b > 3 || t_c < 1 || t_c > 3 || t_f < 1 || t_f > 3)
+    return fail(e, LT_ERR_ARG, "time slots must be 1..3");
+  e->t_b = t_b; e->t_c = t_c; e->t_f = t_f;
+  return LT_OK;
+}
+
+int lt_set_rng(lt_engine* e, const int32_t* mt624, int32_t mti) {
+  if (!e || !mt624 || mti < 0 || mti > 624) return LT_ERR_ARG;
+  for (int i = 0; i < 624; i++) e->mt[i] = (uint32_t)mt624[i];
+  e->mti = mti;
+  return LT_OK;
+}
+
+int lt_get_rng(lt_engine* e, int32_t* mt624, int32_t* mti) {
+  if (!e || !mt624 || !mti) return LT_ERR_ARG;
+  for (int i = 0; i < 624; i++) mt624[i] = (int32_t)e->mt[i];
+  *mti = e->mti;
+  return LT_OK;
+}
+
+static int ready_to_step(lt_engine* e) {
+  if (!e->have_grid || !e->have_particles) return fail(e, LT_ERR_STATE, "grid / particles missing");
+  if (!e->slab_set[1] || !e->slab_set[2] || !e->slab_set[3]) return fail(e, LT_ERR_STATE, "three slabs must be loaded");
+  if (!e->have_bounds) return fail(e, LT_ERR_STATE, "bounds missing");
+  if (e->cfg.settlementon && !e->have_habitat) return fail(e, LT_ERR_STATE, "habitat missing");
+  return LT_OK;
+}
+
+int lt_count_active(lt_engine* e, const double* ix3, int64_t* n_active) {
+  if (!e || !ix3 || !n_active) return LT_ERR_ARG;
+  if (!e->have_grid || !e->have_particles) return fail(e, LT_ERR_STATE, "grid / particles missing");
+  HIPCHK(e, hipSetDevice(e->device));
+  StepParams P;
+  fill_params(e, P);
+  P.ix0 = ix3[0]; P.ix1 = ix3[1]; P.ix2 = ix3[2];
+  unsigned long long* slot = (unsigned long long*)e->counters.p + (CNT_COUNT - 1);
+  HIPCHK(e, hipMemsetAsync(slot, 0, 8, e->stream));
+  unsigned blocks = (unsigned)((e->cfg.numpar + 255) / 256);
+  if (blocks) hipLaunchKernelGGL(k_count_active, dim3(blocks), dim3(256), 0, e->stream, P, slot);
+  HIPCHK(e, hipGetLastError());
+  unsigned long long v = 0;
+  HIPCHK(e, hipMemcpyAsync(&v, slot, 8, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  *n_active = (int64_t)v;
+  return LT_OK;
+}
+
+int lt_set_rng_window(lt_engine* e, int64_t active_before, int64_t active_total) {
+  if (!e || active_before < 0 || active_total < active_before) return LT_ERR_ARG;
+  e->rng_before = active_before;
+  e->rng_total = active_total;
+  return LT_OK;
+}
+
+int lt_step(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32_t it) {
+  if (!e || !ex3 || !ix3) return LT_ERR_ARG;
+  TRY(ready_to_step(e));
+  HIPCHK(e, hipSetDevice(e->device));
+  StepParams P;
+  fill_params(e, P);
+  P.ex0 = ex3[0]; P.ex1 = ex3[1]; P.ex2 = ex3[2];
+  P.ix0 = ix3[0]; P.ix1 = ix3[1]; P.ix2 = ix3[2];
+  P.p = p; P.it = it;
+  HIPCHK(e, hipMemsetAsync(e->counters.p, 0, CNT_COUNT * sizeof(unsigned long long), e->stream));
+  unsigned blocks = (unsigned)((e->cfg.numpar + 255) / 256);
+  if (blocks) {
+    if (e->cfg.slab_storage == LT_SLAB_F32)
+      hipLaunchKernelGGL((k_step<float>), dim3(blocks), dim3(256), 0, e->stream, P);
+    else
+      hipLaunchKernelGGL((k_step<double>), dim3(blocks), dim3(256), 0, e->stream, P);
+    HIPCHK(e, hipGetLastError());
+  }
+  HIPCHK(e, hipMemcpyAsync(e->h_counters, e->counters.p, CNT_COUNT * sizeof(unsigned long long),
+                           hipMemcpyDeviceToHost, e->stream));
+  e->stats_valid = false;
+  return LT_OK;
+}
+
+int lt_sync(lt_engine* e) {
+  if (!e) return LT_ERR_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return LT_OK;
+}
+
+int lt_get_stats(lt_engine* e, lt_step_stats* out) {
+  if (!e || !out) return LT_ERR_ARG;
+  TRY(lt_sync(e));
+  if (!e->stats_valid) {
+    e->stats.active = (int64_t)e->h_counters[CNT_ACTIVE];
+    e->stats.errors = (int64_t)e->h_counters[CNT_ERRORS];
+    e->stats.rng_draws = 0;
+    e->stats_valid = true;
+  }
+  *out = e->stats;
+  return LT_OK;
+}
+
+/* diagnostics of the last step: [0] active [1] errors [2] SigErr fallbacks
+ * [3] brute-force boundary scans [4] full point-in-polygon evaluations */
+int lt_get_counters(lt_engine* e, uint64_t* out8) {
+  if (!e || !out8) return LT_ERR_ARG;
+  TRY(lt_sync(e));
+  for (int i = 0; i < CNT_COUNT; i++) out8[i] = e->h_counters[i];
+  return LT_OK;
+}
+
+int lt_pack_positions(lt_engine* e, void* dst_device) {
+  if (!e || !dst_device) return LT_ERR_ARG;
+  if (!e->have_particles) return fail(e, LT_ERR_STATE, "no particles uploaded");
+  HIPCHK(e, hipSetDevice(e->device));
+  // par(:,1:3) is contiguous in the column-major array
+  HIPCHK(e, hipMemcpyAsync(dst_device, e->par.p, (size_t)e->cfg.numpar * 3 * 8,
+                           hipMemcpyDeviceToDevice, e->stream));
+  return LT_OK;
+}
+
+void* lt_stream(lt_engine* e) { return e ? (void*)e->stream : nullptr; }
+
+}  // extern "C"

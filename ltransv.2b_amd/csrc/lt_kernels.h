@@ -1,0 +1,888 @@
+// lt_kernels.h -- HIP kernels of the LTRANS hot path for gfx950 (CDNA4).
+//
+// k_step: one wavefront lane per particle does the whole of
+// update_particles() (LTRANS.f90:707-1419) for its particle:
+//   gates -> setEle -> setInterp/getInterp -> z clamps -> RK4 over
+//   find_currents/WCTS_ITPI -> behaviour -> vertical reflect -> horizontal
+//   boundary reflection -> in-bounds tests -> setEle -> settlement -> commit.
+// No MFMA: the path is gather + scalar fp64 spline arithmetic.
+//
+// Shape decisions that differ from the reference (results do not):
+//   * interpolation weights are computed once per (stage, grid) instead of at
+//     each of the 144 interp() calls (hydrodynamic_module.f90:2527-2563 is a
+//     pure function of position and element);
+//   * s-level columns (LTRANS.f90:934-951) are never materialised: the level
+//     windows are found by bisection on the (monotone) level depths, and the
+//     4-level windows are recomputed from hc*SC / CS tables held in LDS;
+//   * boundary segments are visited through a uniform-grid index in reference
+//     order (ascending segment id) instead of scanning all nbounds; the
+//     point-in-polygon tests read a y-slab edge index and fall back to the
+//     full crossings algorithm whenever a polygon vertex lies exactly on the
+//     particle's ray (the only case where the two differ);
+//   * the 36 TSPSI(4)+HVAL fits per particle-step run through ONE loop body
+//     (stage x variable x slot) so the instruction footprint stays in the
+//     instruction cache.
+#pragma once
+#include "lt_device.h"
+#include "lt_math.h"
+
+namespace ltd {
+
+// par(n,k) column indices (LTRANS.f90:106-118), 0-based
+enum { pX = 0, pY, pZ, pnX, pnY, pnZ, ppX, ppY, ppZ, pStatus, pDOB, pAge, pLifespan };
+
+#define LT_LEV_STRIDE 64
+
+template <typename SlabT> struct SlabTraits;
+template <> struct SlabTraits<float> { using zeta4 = float4; };
+template <> struct SlabTraits<double> { using zeta4 = double4; };
+
+// -------------------------------------------------------------- s-levels
+// getSlevel / getWlevel, hydrodynamic_module.f90:2691-2777.  tab points at the
+// three tables {hc*SC, CS, SC} of the rho or the w grid in LDS; k is 1-based;
+// h = -P_depth > 0.
+LT_DEV double level_z(const double* tab, int k, double zeta, double h, double hc, int Vtransform) {
+  double A = tab[k - 1];
+  double B = tab[LT_LEV_STRIDE + k - 1];
+  if (Vtransform == 1) {
+    double S = A + (h - hc) * B;
+    return S + zeta * (1.0 + S / h);
+  } else if (Vtransform == 2) {
+    double S = (A + h * B) / (hc + h);
+    return zeta + (zeta + h) * S;
+  } else {
+    double C = tab[2 * LT_LEV_STRIDE + k - 1];
+    return zeta * (1.0 + C) + A + (h - hc) * B;
+  }
+}
+
+// Lowest level i in [3, n-2] with Z below any of the three level depths,
+// else n-1: the loops of find_currents LTRANS.f90:1451-1467 (the level depths
+// increase with i, so the first hit is found by bisection).  Returns i-2.
+LT_DEV int level_window(const double* tab, int n, double Z, double zb, double zc, double zf,
+                        double h, double hc, int Vtransform) {
+  int lo = 3, hi = n - 1;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    bool below = (Z < level_z(tab, mid, zb, h, hc, Vtransform)) ||
+                 (Z < level_z(tab, mid, zc, h, hc, Vtransform)) ||
+                 (Z < level_z(tab, mid, zf, h, hc, Vtransform));
+    if (below) hi = mid; else lo = mid + 1;
+  }
+  return lo - 2;
+}
+
+// -------------------------------------------------------- element search
+struct Quad {
+  double x[4], y[4];
+};
+
+LT_DEV Quad load_quad_xy(const XYNode* nodes, int4 n) {
+  Quad q;
+  XYNode a = nodes[n.x - 1], b = nodes[n.y - 1], c = nodes[n.z - 1], d = nodes[n.w - 1];
+  q.x[0] = a.x; q.y[0] = a.y; q.x[1] = b.x; q.y[1] = b.y;
+  q.x[2] = c.x; q.y[2] = c.y; q.x[3] = d.x; q.y[3] = d.y;
+  return q;
+}
+LT_DEV Quad load_quad_rho(const RhoNode* nodes, int4 n) {
+  Quad q;
+  q.x[0] = nodes[n.x - 1].x; q.y[0] = nodes[n.x - 1].y;
+  q.x[1] = nodes[n.y - 1].x; q.y[1] = nodes[n.y - 1].y;
+  q.x[2] = nodes[n.z - 1].x; q.y[2] = nodes[n.z - 1].y;
+  q.x[3] = nodes[n.w - 1].x; q.y[3] = nodes[n.w - 1].y;
+  return q;
+}
+
+// one grid of setEle's neighbour walk, hydrodynamic_module.f90:1462-1475.
+// Adjacency rows start with the element itself (checked at upload), so the
+// first probe needs no adjacency read.  Returns false when no listed element
+// contains the point (the reference then reports error 4/5/6).
+template <bool RHO>
+LT_DEV bool find_element(const void* nodes, const int4* EL, const int* Adj, double X, double Y,
+                         int& ele, int4& nd) {
+  int cand = ele;
+#pragma unroll 1
+  for (int i = 0; i < 10; i++) {
+    if (i > 0) {
+      cand = Adj[(size_t)(ele - 1) * 10 + i];
+      if (cand == 0) break;  // zero-filled tail: nothing further to probe
+    }
+    int4 n = EL[cand - 1];
+    Quad q = RHO ? load_quad_rho((const RhoNode*)nodes, n) : load_quad_xy((const XYNode*)nodes, n);
+    if (gridcell_one(q.x, q.y, X, Y)) {
+      ele = cand;
+      nd = n;
+      return true;
+    }
+  }
+  nd = EL[ele - 1];
+  return false;
+}
+
+// --------------------------------------------------- point in polygon
+// inpoly, point_in_polygon_module.f90:25-167, for a polygon whose points are
+// ex[i], ey[i], i = 0..n-1 (closed: last point repeats the first).  The hilo
+// array of the reference is recomputed on the fly.
+__device__ __noinline__ bool inpoly_full(double x, double y, int n, const double* ex,
+                                         const double* ey, bool onout) {
+  bool on = false;
+  for (int i = 0; i < n; i++) {
+    double py = ey[i], px = ex[i];
+    if (py == y && px > x) on = true;
+    if (px == x && py == y) return !onout;
+  }
+  int crossed = 0;
+#define LT_HILO(i1) ((ey[(i1)-1] > y) ? 1 : ((ey[(i1)-1] < y) ? -1 : 0))
+  if (on) {
+    bool first = true;
+    int i = 1;
+    for (;;) {
+      if (i > n) break;
+      if (LT_HILO(i) == 0 && ex[i - 1] > x) {
+        if (first) {
+          i = i + 1;
+          continue;
+        }
+        if (LT_HILO(i - 1) == 0) return !onout;
+        int j = 1;
+        for (;;) {
+          if ((i + j) == (n + 1)) j = 2 - i;
+          if (LT_HILO(i + j) != 0) break;
+          if (ex[i + j - 1] < x) return !onout;
+          j = j + 1;
+        }
+        if ((LT_HILO(i - 1) + LT_HILO(i + j)) == 0) crossed = crossed + 1;
+        if (j < 0) break;
+        i = i + j;
+      }
+      first = false;
+      i = i + 1;
+    }
+  }
+#undef LT_HILO
+  for (int i = 0; i < n - 1; i++) {
+    double x1 = ex[i], y1 = ey[i], x2 = ex[i + 1], y2 = ey[i + 1];
+    if (x1 <= x && x2 <= x) continue;
+    if (y1 <= y && y2 <= y) continue;
+    if (y1 >= y && y2 >= y) continue;
+    if (x1 > x && x2 > x) {
+      crossed = crossed + 1;
+      continue;
+    }
+    double m = (y2 - y1) / (x2 - x1);
+    double b = y1 - m * x1;
+    double ix = (y - b) / m;
+    if (ix == x) return !onout;
+    if (ix > x) crossed = crossed + 1;
+  }
+  return (crossed & 1) != 0;
+}
+
+// crossings test of ONE edge (point_in_polygon_module.f90:125-160).
+// returns 0 no crossing, 1 crossing, 2 point lies on the edge
+LT_DEV int pip_edge(double x, double y, double x1, double y1, double x2, double y2) {
+  if (x1 <= x && x2 <= x) return 0;
+  if (y1 <= y && y2 <= y) return 0;
+  if (y1 >= y && y2 >= y) return 0;
+  if (x1 > x && x2 > x) return 1;
+  double m = (y2 - y1) / (x2 - x1);
+  double b = y1 - m * x1;
+  double ix = (y - b) / m;
+  if (ix == x) return 2;
+  return (ix > x) ? 1 : 0;
+}
+
+// mbounds (boundary_module.f90:1515-1540) through the y-slab index; `slow` is
+// set when a vertex shares the particle's y exactly (then the full algorithm
+// must decide).
+LT_DEV bool mbounds_indexed(const StepParams& P, double x, double y, bool& slow) {
+  const PipIndex& ix = P.pip_main;
+  double fb = floor((y - ix.y0) * ix.inv_h);
+  int b = (fb < 0.0) ? 0 : (fb >= (double)ix.nbins ? ix.nbins - 1 : (int)fb);
+  int crossed = 0;
+  for (int q = ix.ptr[b]; q < ix.ptr[b + 1]; q++) {
+    int i = ix.ids[q];
+    double x1 = P.bx[i - 1], y1 = P.by[i - 1], x2 = P.bx[i], y2 = P.by[i];
+    if (y1 == y || y2 == y) {
+      slow = true;
+      return false;
+    }
+    int r = pip_edge(x, y, x1, y1, x2, y2);
+    if (r == 2) return true;
+    crossed += r;
+  }
+  return (crossed & 1) != 0;
+}
+
+// ibounds (boundary_module.f90:1548-1614): inside ANY island?
+LT_DEV bool ibounds_indexed(const StepParams& P, double x, double y, bool& slow) {
+  const PipIndex& ix = P.pip_isl;
+  double fb = floor((y - ix.y0) * ix.inv_h);
+  int b = (fb < 0.0) ? 0 : (fb >= (double)ix.nbins ? ix.nbins - 1 : (int)fb);
+  int cur = -1, crossed = 0;
+  for (int q = ix.ptr[b]; q < ix.ptr[b + 1]; q++) {
+    int i = ix.ids[q];
+    int id = P.hid[i - 1];
+    if (id != cur) {
+      if (crossed & 1) return true;
+      cur = id;
+      crossed = 0;
+    }
+    double x1 = P.hx[i - 1], y1 = P.hy[i - 1], x2 = P.hx[i], y2 = P.hy[i];
+    if (y1 == y || y2 == y) {
+      slow = true;
+      return false;
+    }
+    int r = pip_edge(x, y, x1, y1, x2, y2);
+    if (r == 2) return true;
+    crossed += r;
+  }
+  return (crossed & 1) != 0;
+}
+
+// ibounds by the reference's own island loop (slow path)
+__device__ __noinline__ bool ibounds_full(const double* hx, const double* hy, const int* hid,
+                                          int maxisland, int numislands, double x, double y) {
+  if (numislands <= 0) return false;
+  int i = 1, start = 0;
+  int isle = hid[0];
+  for (;;) {
+    i = i + 1;
+    bool endIsle = false;
+    if (i == maxisland) endIsle = true;
+    else if (hid[i] != isle) endIsle = true;  // hid(i+1)
+    if (endIsle) {
+      int count = i - start;
+      if (inpoly_full(x, y, count, hx + start, hy + start, false)) return true;
+      if (i == maxisland) break;
+      start = i;
+      isle = hid[i];
+    }
+  }
+  return false;
+}
+
+// ------------------------------------------------ intersect_reflect
+struct Hit {
+  double fix, fiy, frx, fry;
+  double dtest;
+  double rPx, rPy;  // rPxyzX/Y: carried across segments within one call
+  int seg;          // skipboundi
+  int found;
+  int water;
+};
+
+// body of the segment loop of intersect_reflect, boundary_module.f90:1664-1898
+LT_DEV void segment_test(const StepParams& P, int i, double Xpos, double Ypos, double nXpos,
+                         double nYpos, double xlow, double xhigh, double ylow, double yhigh,
+                         Hit& H) {
+  const double* s = P.bnd + (size_t)(i - 1) * 4;
+  double bcx1 = s[0], bcy1 = s[1], bcx2 = s[2], bcy2 = s[3];
+  if (((bcx1 > xhigh) && (bcx2 > xhigh)) || ((bcx1 < xlow) && (bcx2 < xlow)) ||
+      ((bcy1 > yhigh) && (bcy2 > yhigh)) || ((bcy1 < ylow) && (bcy2 < ylow)))
+    return;
+  double bxhigh, bxlow, byhigh, bylow;
+  if (bcx1 >= bcx2) { bxhigh = bcx1; bxlow = bcx2; } else { bxhigh = bcx2; bxlow = bcx1; }
+  if (bcy1 >= bcy2) { byhigh = bcy1; bylow = bcy2; } else { byhigh = bcy2; bylow = bcy1; }
+  double intersctx = 0.0, interscty = 0.0, rx1 = 0.0, ry1 = 0.0, rx2 = 0.0, ry2 = 0.0;
+  bool candidate = false;  // passed the in-box test: reflection points are defined
+  // kind of reflection geometry: 0 mirror in x, 1 mirror in y, 2 general
+  int kind = -1;
+  double dPBC = 0.0, Mbc = 0.0;
+  if (bcx1 == bcx2 || nXpos == Xpos) {
+    if (bcx1 == bcx2 && nXpos == Xpos) return;
+    if (bcx1 == bcx2 && nYpos == Ypos) {
+      intersctx = bcx1;
+      interscty = nYpos;
+      kind = 10;
+    } else if (nXpos == Xpos && bcy1 == bcy2) {
+      intersctx = nXpos;
+      interscty = bcy1;
+      kind = 11;
+    } else if (bcx1 == bcx2 && nYpos != Ypos) {
+      double Mp = (nYpos - Ypos) / (nXpos - Xpos);
+      double Bp = Ypos - Mp * Xpos;
+      intersctx = bcx1;
+      interscty = Mp * intersctx + Bp;
+      kind = 12;
+    } else if (nXpos == Xpos && bcy1 != bcy2) {
+      Mbc = (bcy2 - bcy1) / (bcx2 - bcx1);
+      double Bbc = bcy2 - Mbc * bcx2;
+      intersctx = nXpos;
+      interscty = Mbc * intersctx + Bbc;
+      kind = 2;
+    } else {
+      return;  // no branch of the source applies (e.g. vertical move, horizontal... handled above)
+    }
+  } else {
+    Mbc = (bcy2 - bcy1) / (bcx2 - bcx1);
+    double Bbc = bcy2 - Mbc * bcx2;
+    double Mp = (nYpos - Ypos) / (nXpos - Xpos);
+    double Bp = Ypos - Mp * Xpos;
+    intersctx = (Bbc - Bp) / (Mp - Mbc);
+    interscty = Mp * intersctx + Bp;
+    if (Mbc == 0.0) interscty = byhigh;
+    kind = (Mbc == 0.0) ? 13 : 2;
+  }
+  candidate = intersctx <= xhigh && intersctx >= xlow && interscty <= yhigh && interscty >= ylow &&
+              intersctx <= bxhigh && intersctx >= bxlow && interscty <= byhigh && interscty >= bylow;
+  if (!candidate) return;
+  if (kind == 10) {
+    dPBC = sqrt((intersctx - nXpos) * (intersctx - nXpos) + (interscty - nYpos) * (interscty - nYpos));
+    rx1 = nXpos + (2.0 * dPBC); ry1 = nYpos;
+    rx2 = nXpos - (2.0 * dPBC); ry2 = nYpos;
+  } else if (kind == 11) {
+    dPBC = sqrt((intersctx - nXpos) * (intersctx - nXpos) + (interscty - nYpos) * (interscty - nYpos));
+    rx1 = nXpos; ry1 = nYpos + (2.0 * dPBC);
+    rx2 = nXpos; ry2 = nYpos - (2.0 * dPBC);
+  } else if (kind == 12) {
+    dPBC = nXpos - intersctx;
+    rx1 = nXpos + (2.0 * dPBC); ry1 = nYpos;
+    rx2 = nXpos - (2.0 * dPBC); ry2 = nYpos;
+  } else if (kind == 13) {
+    dPBC = nYpos - bcy1;
+    rx1 = nXpos; ry1 = nYpos + (2.0 * dPBC);
+    rx2 = nXpos; ry2 = nYpos - (2.0 * dPBC);
+  } else {
+    double distBC = sqrt((bcx1 - bcx2) * (bcx1 - bcx2) + (bcy1 - bcy2) * (bcy1 - bcy2));
+    double crossk = ((nXpos - bcx1) * (bcy2 - bcy1)) - ((bcx2 - bcx1) * (nYpos - bcy1));
+    dPBC = sqrt(crossk * crossk) / distBC;
+    double mBCperp = -1.0 / Mbc;
+    double bBCperp = nYpos - mBCperp * nXpos;
+    rx1 = sqrt(((2.0 * dPBC) * (2.0 * dPBC)) / (1.0 + mBCperp * mBCperp)) + nXpos;
+    ry1 = mBCperp * rx1 + bBCperp;
+    rx2 = sqrt(((2.0 * dPBC) * (2.0 * dPBC)) / (1.0 + mBCperp * mBCperp)) * -1.0 + nXpos;
+    ry2 = mBCperp * rx2 + bBCperp;
+  }
+  double dist1 = sqrt((intersctx - rx1) * (intersctx - rx1) + (interscty - ry1) * (interscty - ry1));
+  double dist2 = sqrt((intersctx - rx2) * (intersctx - rx2) + (interscty - ry2) * (interscty - ry2));
+  if (dist1 < dist2) { H.rPx = rx1; H.rPy = ry1; }
+  else if (dist1 > dist2) { H.rPx = rx2; H.rPy = ry2; }
+  double d_Pinter = sqrt((Xpos - intersctx) * (Xpos - intersctx) + (Ypos - interscty) * (Ypos - interscty));
+  if (d_Pinter < H.dtest) {
+    H.fix = intersctx;
+    H.fiy = interscty;
+    H.frx = H.rPx;
+    H.fry = H.rPy;
+    H.found = 1;
+    H.dtest = d_Pinter;
+    H.seg = i;
+    H.water = !P.land[i - 1];
+  }
+}
+
+// intersect_reflect, boundary_module.f90:1620-1902
+LT_DEV void intersect_reflect(const StepParams& P, double Xpos, double Ypos, double nXpos,
+                              double nYpos, int skipbound, Hit& H, unsigned& brute_count) {
+  H.fix = H.fiy = H.frx = H.fry = -999999.;
+  H.rPx = H.rPy = -999999.;
+  H.dtest = 999999.;
+  H.seg = skipbound;
+  H.found = 0;
+  H.water = 0;
+  double xhigh, xlow, yhigh, ylow;
+  if (Xpos >= nXpos) { xhigh = Xpos; xlow = nXpos; } else { xhigh = nXpos; xlow = Xpos; }
+  if (Ypos >= nYpos) { yhigh = Ypos; ylow = nYpos; } else { yhigh = nYpos; ylow = Ypos; }
+  // candidate list: one cell list of the index (reference order), or all segments
+  int q0 = 0, q1 = P.nbounds;
+  bool indexed = false;
+  if (P.use_seg_index) {
+    const SegIndex& S = P.seg;
+    double fx0 = floor((xlow - S.x0) * S.inv_cw), fx1 = floor((xhigh - S.x0) * S.inv_cw);
+    double fy0 = floor((ylow - S.y0) * S.inv_ch), fy1 = floor((yhigh - S.y0) * S.inv_ch);
+    // clamp to the grid (monotone, so overlap is preserved); NaN fails every test
+    double mx = (double)(S.ncx - 1), my = (double)(S.ncy - 1);
+    fx0 = fx0 < 0.0 ? 0.0 : (fx0 > mx ? mx : fx0);
+    fx1 = fx1 < 0.0 ? 0.0 : (fx1 > mx ? mx : fx1);
+    fy0 = fy0 < 0.0 ? 0.0 : (fy0 > my ? my : fy0);
+    fy1 = fy1 < 0.0 ? 0.0 : (fy1 > my ? my : fy1);
+    if (fx1 - fx0 <= 1.0 && fy1 - fy0 <= 1.0) {
+      indexed = true;
+      int c = (int)fx0 + (int)fy0 * S.ncx;
+      q0 = S.ptr[c];
+      q1 = S.ptr[c + 1];
+    }
+  }
+  if (!indexed) brute_count += 1;
+#pragma unroll 1
+  for (int q = q0; q < q1; q++) {
+    int i = indexed ? P.seg.ids[q] : q + 1;
+    if (i == skipbound) continue;
+    segment_test(P, i, Xpos, Ypos, nXpos, nYpos, xlow, xhigh, ylow, yhigh, H);
+  }
+}
+
+// ------------------------------------------------------- settlement
+// testSettlement / psettle / hsettle, settlement_module.f90:485-624
+LT_DEV int test_settlement(const StepParams& P, double Px, double Py, int R_ele) {
+  int polyin = 0;
+  for (int q = P.elepolys_ptr[R_ele - 1]; q < P.elepolys_ptr[R_ele]; q++) {
+    int pid = P.elepolys_ids[q];
+    int start = P.polyspecs[pid - P.minpolyid];
+    int size = P.polyspecs[(pid - P.minpolyid) + P.npoly];
+    const double* base = P.polys + (start - 1);
+    double cx = base[(size_t)P.pedges * 1], cy = base[(size_t)P.pedges * 2];
+    double dis = sqrt((Px - cx) * (Px - cx) + (Py - cy) * (Py - cy));
+    int idnum = (int)llrint(base[0]);
+    if (dis > P.maxbdis[idnum - P.minpolyid]) continue;
+    if (inpoly_full(Px, Py, size, base + (size_t)P.pedges * 3, base + (size_t)P.pedges * 4, false)) {
+      polyin = idnum;
+      break;
+    }
+  }
+  if (polyin > 0 && P.holesExist) {
+    int pi = polyin - P.minpolyid;
+    for (int q = P.polyholes_ptr[pi]; q < P.polyholes_ptr[pi + 1]; q++) {
+      int hidx = P.polyholes_ids[q];
+      int start = P.holespecs[hidx - P.minholeid];
+      int size = P.holespecs[(hidx - P.minholeid) + P.nhole];
+      const double* base = P.holes + (start - 1);
+      double cx = base[(size_t)P.hedges * 1], cy = base[(size_t)P.hedges * 2];
+      double dis = sqrt((Px - cx) * (Px - cx) + (Py - cy) * (Py - cy));
+      int idnum = (int)llrint(base[0]);
+      if (dis > P.maxhdis[idnum - P.minholeid]) continue;
+      // onin = .FALSE.: a particle on the edge of a hole still settles (:609)
+      if (inpoly_full(Px, Py, size, base + (size_t)P.hedges * 3, base + (size_t)P.hedges * 4, true)) {
+        return 0;
+      }
+    }
+  }
+  return polyin;
+}
+
+// ---------------------------------------------------- field access
+template <typename SlabT>
+LT_DEV double fld(const SlabT* F, int node, int L, int k, int ps) {
+  return (double)F[((size_t)(node - 1) * L + (k - 1)) * 3 + ps];
+}
+
+// the per-particle context that find_currents needs (registers)
+struct Column {
+  double zeta[3];   // zetab, zetac, zetaf at the particle (roles b,c,f)
+  double h;         // -P_depth
+  double Pz[3];     // P_zb, P_zc, P_zf
+  double wz1[3];    // Pwc_wz{b,c,f}(1)
+  double z1[3];     // Pwc_z{b,c,f}(1)
+};
+
+// find_currents, LTRANS.f90:1422-1614
+template <typename SlabT>
+LT_DEV void find_currents(const StepParams& P, const double* lev, const Column& C, int4 rn, int4 un,
+                          int4 vn, double Xs, double Ys, double Zs, int version, double& Uad,
+                          double& Vad, double& Wad, int& sigerr_count) {
+  const double* rtab = lev;
+  const double* wtab = lev + 3 * LT_LEV_STRIDE;
+  const double ixv = (version == 1) ? P.ix0 : (version == 2) ? P.ix1 : P.ix2;
+  // regime tests :1481-1491
+  if ((Zs < C.wz1[0] + P.z0) || (Zs < C.wz1[1] + P.z0) || (Zs < C.wz1[2] + P.z0)) {
+    Uad = 0.0; Vad = 0.0; Wad = 0.0;
+    return;
+  }
+  const bool loglayer = (Zs < C.z1[0]) || (Zs < C.z1[1]) || (Zs < C.z1[2]);
+  const int ii = level_window(rtab, P.us, Zs, C.zeta[0], C.zeta[1], C.zeta[2], C.h, P.hc, P.Vtransform);
+  const int iii = level_window(wtab, P.ws, Zs, C.zeta[0], C.zeta[1], C.zeta[2], C.h, P.hc, P.Vtransform);
+#pragma unroll 1
+  for (int var = 0; var < 3; var++) {
+    const int4 nd = (var == 0) ? un : (var == 1) ? vn : rn;
+    Quad q = (var == 2) ? load_quad_rho(P.rnode, nd)
+                        : load_quad_xy((var == 0) ? P.unode : P.vnode, nd);
+    const QuadWeights w = quad_weights(Xs, Ys, q.x, q.y);
+    const SlabT* F = (const SlabT*)((var == 0) ? P.U : (var == 1) ? P.V : P.W);
+    const int L = (var == 2) ? P.ws : P.us;
+    const double* tab = (var == 2) ? wtab : rtab;
+    double Pv[3];
+    if (loglayer) {
+      // log layer :1493-1522: level 1 of u,v; level 2 of w
+      const int k = (var == 2) ? 2 : 1;
+#pragma unroll
+      for (int s = 0; s < 3; s++) {
+        const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
+        double val = apply_interp(w, fld(F, nd.x, L, k, ps), fld(F, nd.y, L, k, ps),
+                                  fld(F, nd.z, L, k, ps), fld(F, nd.w, L, k, ps));
+        // u(z) = u(z1) * log10((z-zb)/z0) / log10((z1-zb)/z0); zb = Pwc_wzb(1) for all slots
+        double ztop = (var == 2) ? level_z(wtab, 2, C.zeta[s], C.h, P.hc, P.Vtransform) : C.z1[s];
+        Pv[s] = val * log10((Zs - C.wz1[0]) / P.z0) / log10((ztop - C.wz1[0]) / P.z0);
+      }
+    } else {
+      const int k0 = (var == 2) ? iii : ii;
+#pragma unroll 1
+      for (int s = 0; s < 3; s++) {
+        const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
+        const double zeta = (s == 0) ? C.zeta[0] : (s == 1) ? C.zeta[1] : C.zeta[2];
+        const double Pzs = (s == 0) ? C.Pz[0] : (s == 1) ? C.Pz[1] : C.Pz[2];
+        double az[4], av[4];
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+          az[l] = level_z(tab, k0 + l, zeta, C.h, P.hc, P.Vtransform);
+          av[l] = apply_interp(w, fld(F, nd.x, L, k0 + l, ps), fld(F, nd.y, L, k0 + l, ps),
+                               fld(F, nd.z, L, k0 + l, ps), fld(F, nd.w, L, k0 + l, ps));
+        }
+        double r = spline4_eval(az, av, Pzs, sigerr_count);
+        if (s == 0) Pv[0] = r; else if (s == 1) Pv[1] = r; else Pv[2] = r;
+      }
+    }
+    // time interpolation :1534-1598 / hydrodynamic_module.f90:2653-2670
+    double e1 = Pv[0], e2 = (P.p == 1) ? Pv[0] : Pv[1], e3 = (P.p == 1) ? Pv[1] : Pv[2];
+    double val = polintd3(P.ex0, P.ex1, P.ex2, e1, e2, e3, ixv);
+    if (var == 0) Uad = val; else if (var == 1) Vad = val; else Wad = val;
+  }
+}
+
+// ------------------------------------------------------------ the step
+template <typename SlabT>
+__global__ __launch_bounds__(256) void k_step(const StepParams P) {
+  __shared__ double lev[6 * LT_LEV_STRIDE];
+  for (int i = threadIdx.x; i < 6 * LT_LEV_STRIDE; i += blockDim.x) lev[i] = P.lev[i];
+  __syncthreads();
+
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned c_active = 0, c_err = 0, c_brute = 0, c_pipslow = 0;
+  int sigerr_count = 0;
+
+  if (n < P.numpar) {
+    const size_t N = (size_t)P.numpar;
+    double* par = P.par + n;
+#define PARV(k) par[(size_t)(k) * N]
+    const double X = PARV(pX), Y = PARV(pY);
+    double Z = PARV(pZ);
+    double nX = X, nY = Y, nZ = Z;  // the new position to commit
+    bool keep_pn = false;           // true: pn stays what memory holds
+    int err = 0;
+    int er = P.P_r_element[n], eu = P.P_u_element[n], ev = P.P_v_element[n];
+    bool ele_dirty = false;
+    double lifespan = 0.0;
+    bool set_lifespan = false;
+
+    // the gates of LTRANS.f90:790-816
+    const bool released = !(P.ix2 <= PARV(pDOB));
+    bool track = released;
+    double age = 0.0;
+    if (released) {
+      age = PARV(pAge) + (double)(float)P.idt;
+      PARV(pAge) = age;
+      // updateStatus, behavior_module.f90:162-179
+      bool settled = P.settlementon ? (P.settle[n] != 0) : false;
+      if (P.mortality && age >= P.P_deadage[n]) {
+        if (!(P.settlementon && settled)) P.dead[n] = 1;
+      }
+      if (P.settlementon && settled) track = false;
+      if (track && P.mortality && P.dead[n] != 0) track = false;
+      if (track && P.OpenOceanBoundary && P.oob[n] != 0) track = false;
+      if (!track) keep_pn = true;
+    }
+
+    if (track) {
+      int4 rn, un, vn;
+      // setEle :830 (all three grids are searched even after a miss)
+      bool okr = find_element<true>(P.rnode, P.RE, P.rAdj, X, Y, er, rn);
+      bool oku = find_element<false>(P.unode, P.UE, P.uAdj, X, Y, eu, un);
+      bool okv = find_element<false>(P.vnode, P.VE, P.vAdj, X, Y, ev, vn);
+      ele_dirty = true;
+      if (!okv) err = 6; else if (!oku) err = 5; else if (!okr) err = 4;  // last assignment wins
+      if (err == 0) {
+        c_active = 1;
+        // setInterp + getInterp :882-896
+        RhoNode r1 = P.rnode[rn.x - 1], r2 = P.rnode[rn.y - 1], r3 = P.rnode[rn.z - 1],
+                r4 = P.rnode[rn.w - 1];
+        double qx[4] = {r1.x, r2.x, r3.x, r4.x}, qy[4] = {r1.y, r2.y, r3.y, r4.y};
+        const QuadWeights w0 = quad_weights(X, Y, qx, qy);
+        const double P_depth = -1.0 * apply_getinterp(w0, r1.depth, r2.depth, r3.depth, r4.depth);
+        const double P_angle = apply_getinterp(w0, r1.angle, r2.angle, r3.angle, r4.angle);
+        using Z4 = typename SlabTraits<SlabT>::zeta4;
+        const Z4* zt = (const Z4*)P.zeta;
+        Z4 z1 = zt[rn.x - 1], z2 = zt[rn.y - 1], z3 = zt[rn.z - 1], z4 = zt[rn.w - 1];
+        auto pick = [](const Z4& v, int s) -> double {
+          return (double)((s == 0) ? v.x : (s == 1) ? v.y : v.z);
+        };
+        Column C;
+        C.zeta[0] = apply_getinterp(w0, pick(z1, P.tb), pick(z2, P.tb), pick(z3, P.tb), pick(z4, P.tb));
+        C.zeta[1] = apply_getinterp(w0, pick(z1, P.tc), pick(z2, P.tc), pick(z3, P.tc), pick(z4, P.tc));
+        C.zeta[2] = apply_getinterp(w0, pick(z1, P.tf), pick(z2, P.tf), pick(z3, P.tf), pick(z4, P.tf));
+        const double P_zetac = C.zeta[1];
+        // vertical clamps :900-922
+        if (Z < P_depth) {
+          Z = P_depth + (double)0.001f;
+          if (P.TrackCollisions) P.hitBottom[n] += 1;
+        }
+        C.Pz[0] = C.Pz[1] = C.Pz[2] = Z;
+        if (Z > C.zeta[0]) C.Pz[0] = C.zeta[0] - (double)0.001f;
+        if (Z > C.zeta[1]) C.Pz[1] = C.zeta[1] - (double)0.001f;
+        if (Z > C.zeta[2]) C.Pz[2] = C.zeta[2] - (double)0.001f;
+        const double Zpar = polintd3(P.ex0, P.ex1, P.ex2, C.Pz[0], C.Pz[1], C.Pz[2], P.ix1);
+        Z = Zpar;  // par(n,pZ) = Zpar :922
+        C.h = -1.0 * P_depth;
+        const double* rtab = lev;
+        const double* wtab = lev + 3 * LT_LEV_STRIDE;
+        double maxpartdepth, minpartdepth;
+        {
+#pragma unroll
+          for (int s = 0; s < 3; s++) {
+            C.wz1[s] = level_z(wtab, 1, C.zeta[s], C.h, P.hc, P.Vtransform);
+            C.z1[s] = level_z(rtab, 1, C.zeta[s], C.h, P.hc, P.Vtransform);
+          }
+          double t0 = level_z(wtab, P.ws, C.zeta[0], C.h, P.hc, P.Vtransform);
+          double t1 = level_z(wtab, P.ws, C.zeta[1], C.h, P.hc, P.Vtransform);
+          double t2 = level_z(wtab, P.ws, C.zeta[2], C.h, P.hc, P.Vtransform);
+          maxpartdepth = C.wz1[0];
+          if (C.wz1[1] > maxpartdepth) maxpartdepth = C.wz1[1];
+          if (C.wz1[2] > maxpartdepth) maxpartdepth = C.wz1[2];
+          minpartdepth = t0;
+          if (t1 < minpartdepth) minpartdepth = t1;
+          if (t2 < minpartdepth) minpartdepth = t2;
+        }
+        // RK4 :990-1053
+        const double cosA = cos(P_angle), sinA = sin(P_angle);
+        double sumU = 0.0, sumV = 0.0, sumW = 0.0;
+        double Xs = X, Ys = Y, Zs = Zpar;
+#pragma unroll 1
+        for (int st = 0; st < 4; st++) {
+          const int version = (st == 0) ? 1 : (st == 3) ? 3 : 2;
+          double Uad, Vad, Wad;
+          find_currents<SlabT>(P, lev, C, rn, un, vn, Xs, Ys, Zs, version, Uad, Vad, Wad,
+                               sigerr_count);
+          if (st == 0) { sumU = Uad; sumV = Vad; sumW = Wad; }
+          else if (st == 3) { sumU = sumU + Uad; sumV = sumV + Vad; sumW = sumW + Wad; }
+          else { sumU = sumU + 2.0 * Uad; sumV = sumV + 2.0 * Vad; sumW = sumW + 2.0 * Wad; }
+          if (st < 3) {
+            const double dtf = (double)P.idt;
+            if (st < 2) {
+              Xs = X + (Uad * cosA - Vad * sinA) * dtf / 2.0;
+              Ys = Y + (Uad * sinA + Vad * cosA) * dtf / 2.0;
+              Zs = Zpar + Wad * dtf / 2.0;
+            } else {
+              Xs = X + (Uad * cosA - Vad * sinA) * dtf;
+              Ys = Y + (Uad * sinA + Vad * cosA) * dtf;
+              Zs = Zpar + Wad * dtf;
+            }
+            if (Zs > minpartdepth) Zs = minpartdepth - (double)0.000001f;
+            if (Zs < maxpartdepth) Zs = maxpartdepth + (double)0.000001f;
+          }
+        }
+        const double P_U = sumU / 6.0, P_V = sumV / 6.0, P_W = sumW / 6.0;
+        const double AdvectX = P.idt * (P_U * cosA - P_V * sinA);
+        const double AdvectY = P.idt * (P_U * sinA + P_V * cosA);
+        const double AdvectZ = P.idt * P_W;
+        const double TurbHx = 0.0, TurbHy = 0.0, TurbV = 0.0;
+        // behave (types 0 and 6), behavior_module.f90:181-551
+        double ZBehav = 0.0;
+        if (P.Behavior != 0) {
+          const size_t np = (size_t)P.numpar;
+          double sw3 = P.P_swim[n + 2 * np];
+          bool sw_dirty = false;
+          if (age >= P.swimstart) { sw3 = P.P_swim[n] * age + P.P_swim[n + np]; sw_dirty = true; }
+          if (age >= P.P_pediage[n]) { sw3 = P.swimfast; sw_dirty = true; }
+          if (sw_dirty) P.P_swim[n + 2 * np] = sw3;
+          double parBehav = 0.0;
+          if (P.P_behave[n] == 6) parBehav = (age >= P.swimstart) ? P.sink : sw3;
+          ZBehav = parBehav * P.idt;
+        }
+        // new position, vertical reflection :1128-1176
+        double newXpos = X + AdvectX + TurbHx;
+        double newYpos = Y + AdvectY + TurbHy;
+        double newZpos = Z + AdvectZ + TurbV;
+        if (newZpos > P_zetac) {
+          double reflect = P_zetac - newZpos;
+          newZpos = P_zetac + reflect;
+        }
+        if (newZpos < P_depth) {
+          double reflect = P_depth - newZpos;
+          newZpos = P_depth + reflect;
+          if (P.TrackCollisions) P.hitBottom[n] += 1;
+        }
+        newZpos = newZpos + ZBehav;
+        if (newZpos > P_zetac) newZpos = P_zetac - (double)0.000001f;
+        if (newZpos < P_depth) {
+          newZpos = P_depth + (double)0.000001f;
+          if (P.TrackCollisions) P.hitBottom[n] += 1;
+        }
+        // horizontal boundaries :1180-1232
+        double Xpos = X, Ypos = Y, nXpos = newXpos, nYpos = newYpos;
+        int skipbound = -1, reflects = 0;
+        bool done = false;  // waterFlag
+        for (;;) {
+          Hit H;
+          intersect_reflect(P, Xpos, Ypos, nXpos, nYpos, skipbound, H, c_brute);
+          skipbound = H.seg;
+          if (!H.found) break;
+          if (P.TrackCollisions) P.hitLand[n] += 1;
+          if (P.OpenOceanBoundary && H.water) {
+            nX = H.fix; nY = H.fiy; nZ = newZpos;
+            P.oob[n] = 1;
+            done = true;
+            break;
+          }
+          reflects += 1;
+          if (reflects > 3) {
+            err = 24;
+            done = true;
+            break;
+          }
+          Xpos = H.fix; Ypos = H.fiy; nXpos = H.frx; nYpos = H.fry;
+        }
+        if (!done) {
+          newXpos = nXpos;
+          newYpos = nYpos;
+          // mbounds :1240, ibounds :1275
+          bool slow = false, inb;
+          if (P.use_pip_index) {
+            inb = mbounds_indexed(P, newXpos, newYpos, slow);
+          } else {
+            slow = true;
+            inb = false;
+          }
+          if (slow) {
+            c_pipslow += 1;
+            inb = inpoly_full(newXpos, newYpos, P.maxbound, P.bx, P.by, false);
+          }
+          if (!inb) {
+            err = 25;
+          } else {
+            bool inisl = false;
+            if (P.numislands > 0) {
+              slow = false;
+              if (P.use_pip_index) inisl = ibounds_indexed(P, newXpos, newYpos, slow);
+              else slow = true;
+              if (slow) {
+                c_pipslow += 1;
+                inisl = ibounds_full(P.hx, P.hy, P.hid, P.maxisland, P.numislands, newXpos, newYpos);
+              }
+            }
+            if (inisl) {
+              err = 26;
+            } else {
+              nX = newXpos; nY = newYpos; nZ = newZpos;  // :1312-1314
+              // setEle on the new position :1317
+              bool okr2 = find_element<true>(P.rnode, P.RE, P.rAdj, nXpos, nYpos, er, rn);
+              bool oku2 = find_element<false>(P.unode, P.UE, P.uAdj, nXpos, nYpos, eu, un);
+              bool okv2 = find_element<false>(P.vnode, P.VE, P.vAdj, nXpos, nYpos, ev, vn);
+              if (!okv2) err = 29; else if (!oku2) err = 28; else if (!okr2) err = 27;
+              if (err == 0 && P.settlementon) {
+                // testSettlement with the OLD position and the NEW element :1375
+                if (age >= P.settletime[n]) {
+                  int inpoly = test_settlement(P, X, Y, er);
+                  if (inpoly > 0) {
+                    P.settle[n] = 1;
+                    nZ = P_depth;
+                    P.endpoly[n] = inpoly;
+                    lifespan = age;
+                    set_lifespan = true;
+                  }
+                }
+              }
+            }
+          }
+        }
+      }
+      // ErrorFlag handling :858-877 etc.  (ErrorFlag 0 = the host stops; the
+      // particle is returned to its previous location as under ErrorFlag 1)
+      if (err != 0) {
+        c_err = 1;
+        if (P.ErrorFlag == 2) { P.dead[n] = 1; keep_pn = true; }
+        else if (P.ErrorFlag == 3) { P.oob[n] = 1; keep_pn = true; }
+        else { nX = X; nY = Y; nZ = Z; keep_pn = false; }
+      }
+    }
+    P.err_code[n] = err;
+    if (ele_dirty) {
+      P.P_r_element[n] = er;
+      P.P_u_element[n] = eu;
+      P.P_v_element[n] = ev;
+    }
+    // commit loop :1407-1414 fused: pp <- p, p <- pn
+    if (keep_pn) {
+      nX = PARV(pnX); nY = PARV(pnY); nZ = PARV(pnZ);
+    } else {
+      PARV(pnX) = nX; PARV(pnY) = nY; PARV(pnZ) = nZ;
+    }
+    PARV(ppX) = X; PARV(ppY) = Y; PARV(ppZ) = Z;
+    PARV(pX) = nX; PARV(pY) = nY; PARV(pZ) = nZ;
+    if (set_lifespan) PARV(pLifespan) = lifespan;
+#undef PARV
+  }
+
+  // block-level counter reduction -> one atomic per counter per block
+  __shared__ unsigned red[5];
+  if (threadIdx.x < 5) red[threadIdx.x] = 0;
+  __syncthreads();
+  unsigned vals[5] = {c_active, c_err, (unsigned)sigerr_count, c_brute, c_pipslow};
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    unsigned v = vals[k];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&red[k], v);
+  }
+  __syncthreads();
+  if (threadIdx.x < 5 && red[threadIdx.x]) {
+    atomicAdd(&P.counters[threadIdx.x], (unsigned long long)red[threadIdx.x]);
+  }
+}
+
+// ------------------------------------------------------ slab upload
+// staging (node,level) column-major doubles -> [node][level][slot] SlabT.
+// flags[0] is set when a value is not exactly representable in SlabT.
+template <typename SlabT>
+__global__ void k_slab_scatter(const double* __restrict__ src, SlabT* __restrict__ dst, int nodes,
+                               int L, int slot, int* flags) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)nodes * L;
+  if (idx >= total) return;
+  // idx enumerates the destination (node-major, level fastest) so that the
+  // strided writes of one slot stay within a few cache lines per wave
+  size_t node = idx / L;
+  int k = (int)(idx - node * L);
+  double v = src[node + (size_t)nodes * k];
+  SlabT c = (SlabT)v;
+  if ((double)c != v && !(v != v)) atomicOr(flags, 1);
+  dst[idx * 3 + slot] = c;
+}
+
+template <typename SlabT>
+__global__ void k_zeta_scatter(const double* __restrict__ src, SlabT* __restrict__ dst, int nodes,
+                               int slot, int* flags) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)nodes) return;
+  double v = src[idx];
+  SlabT c = (SlabT)v;
+  if ((double)c != v && !(v != v)) atomicOr(flags, 1);
+  dst[idx * 4 + slot] = c;
+}
+
+// xyz(numpar,3) column-major <- par(:,1:3)
+__global__ void k_pack_positions(const double* __restrict__ par, double* __restrict__ dst, int numpar) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)numpar * 3) return;
+  dst[idx] = par[idx];  // columns 1..3 are the first 3*numpar values
+}
+
+// number of particles that pass the gates and the first setEle (= draw RNG)
+__global__ void k_count_active(const StepParams P, unsigned long long* out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned c = 0;
+  if (n < P.numpar) {
+    const size_t N = (size_t)P.numpar;
+    const double* par = P.par + n;
+    bool track = !(P.ix2 <= par[(size_t)pDOB * N]);
+    if (track) {
+      double age = par[(size_t)pAge * N] + (double)(float)P.idt;
+      bool settled = P.settlementon ? (P.settle[n] != 0) : false;
+      bool deadn = P.dead[n] != 0;
+      if (P.mortality && age >= P.P_deadage[n] && !(P.settlementon && settled)) deadn = true;
+      if (P.settlementon && settled) track = false;
+      if (track && P.mortality && deadn) track = false;
+      if (track && P.OpenOceanBoundary && P.oob[n] != 0) track = false;
+    }
+    if (track) {
+      double X = par[(size_t)pX * N], Y = par[(size_t)pY * N];
+      int er = P.P_r_element[n], eu = P.P_u_element[n], ev = P.P_v_element[n];
+      int4 nd;
+      bool ok = find_element<true>(P.rnode, P.RE, P.rAdj, X, Y, er, nd);
+      ok = find_element<false>(P.unode, P.UE, P.uAdj, X, Y, eu, nd) && ok;
+      ok = find_element<false>(P.vnode, P.VE, P.vAdj, X, Y, ev, nd) && ok;
+      c = ok ? 1u : 0u;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
+}
+
+}  // namespace ltd

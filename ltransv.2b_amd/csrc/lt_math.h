@@ -1,0 +1,547 @@
+// lt_math.h -- device-side numerics of the LTRANS hot path for gfx950.
+//
+// Register-resident restatements (one wavefront lane = one particle) of
+//   INT_MOD::polintd/linint            interpolation_module.f90:25-107
+//   TENSION_MOD (TSPACK, TOMS 716)     tension_module.f90:231-1354
+//   GRIDCELL_MOD::gridcell             gridcell_module.f90:26-257
+//   HYDRO_MOD interpolation weights    hydrodynamic_module.f90:1680-1740,2527-2563
+// The arithmetic order of every formula follows the Fortran so that results
+// agree with the CPU oracle to rounding of the transcendental functions only
+// (this file is compiled with -ffp-contract=off).  What is different from the
+// reference is the shape: fixed N=4 splines live in registers and are fitted
+// one interval at a time by a single loop body (keeps the instruction
+// footprint of the 36 fits per particle-step small), the interval search is a
+// comparison chain, and nothing is allocated.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ltd {
+
+#define LT_DEV __device__ __forceinline__
+#define LT_DEV_NOINLINE __device__ __noinline__
+
+// RTOL = 200*eps computed by the STORE loop, tension_module.f90:433-439:
+// the loop halves RTOL until 1+RTOL <= 1, i.e. RTOL = 2^-53, then *200.
+#define LT_SIGS_RTOL (200.0 * 1.1102230246251565e-16)
+#define LT_SBIG 85.0
+
+// Fortran MIN/MAX as compare-and-select (NaN falls through to the second
+// argument, like the oracle's dmin/dmax), not IEEE fmin/fmax.
+LT_DEV double dmin(double a, double b) { return (a < b) ? a : b; }
+LT_DEV double dmax(double a, double b) { return (a > b) ? a : b; }
+
+// ---------------------------------------------------------------- INT_MOD
+// polintd, interpolation_module.f90:70-107 (n = 3)
+LT_DEV double polintd3(double xa1, double xa2, double xa3, double ya1, double ya2, double ya3,
+                       double x) {
+  int ns = 1;
+  double dif = fabs(x - xa1);
+  double dift = fabs(x - xa2);
+  if (dift < dif) { ns = 2; dif = dift; }
+  dift = fabs(x - xa3);
+  if (dift < dif) { ns = 3; dif = dift; }
+  double c = (xa2 - x) * ((ya3 - ya2) / (xa2 - xa3));
+  c = c - (xa2 - x) * ((ya2 - ya1) / (xa1 - xa2));
+  c = c / (xa1 - xa3);
+  double a, b;
+  if (ns == 3) {
+    a = (ya3 - ya2) / (xa2 - xa3);
+    b = xa3 - x;
+  } else {
+    a = (ya2 - ya1) / (xa1 - xa2);
+    b = xa1 - x;
+  }
+  double yns = (ns == 1) ? ya1 : (ns == 2) ? ya2 : ya3;
+  double xns = (ns == 1) ? xa1 : (ns == 2) ? xa2 : xa3;
+  return yns + (xns - x) * a + b * c;
+}
+
+// linint for n = 4, interpolation_module.f90:25-59.  The bisection visits
+// k=2 then k=3 or stops: jlo/jhi end as (1,2), (2,3) or (3,4).
+LT_DEV double linint4(const double (&xa)[4], const double (&ya)[4], double x) {
+  // k = (4+1)/2 = 2
+  int jlo = 1, jhi = 4;
+  if (xa[1] > x) jhi = 2; else jlo = 2;
+  if (jhi - jlo != 1) {  // (2,4): k = 3
+    if (xa[2] > x) jhi = 3; else jlo = 3;
+  }
+  double xl = (jlo == 1) ? xa[0] : (jlo == 2) ? xa[1] : xa[2];
+  double yl = (jlo == 1) ? ya[0] : (jlo == 2) ? ya[1] : ya[2];
+  double xh = (jhi == 2) ? xa[1] : (jhi == 3) ? xa[2] : xa[3];
+  double yh = (jhi == 2) ? ya[1] : (jhi == 3) ? ya[2] : ya[3];
+  double m = (yl - yh) / (xl - xh);
+  double b = yl - m * xl;
+  return m * x + b;
+}
+
+// linint over an array in memory (VTurb fallback), returns y and slope m
+LT_DEV void linint_n(const double* xa, const double* ya, int n, int stride, double x, double& y,
+                     double& m) {
+  int jlo = 1, jhi = n;
+  for (;;) {
+    int k = (jhi + jlo) / 2;
+    if (xa[(size_t)(k - 1) * stride] > x) jhi = k; else jlo = k;
+    if (jhi - jlo == 1) break;
+  }
+  double xl = xa[(size_t)(jlo - 1) * stride], xh = xa[(size_t)(jhi - 1) * stride];
+  double yl = ya[(size_t)(jlo - 1) * stride], yh = ya[(size_t)(jhi - 1) * stride];
+  m = (yl - yh) / (xl - xh);
+  double b = yl - m * xl;
+  y = m * x + b;
+}
+
+// ------------------------------------------------------------ TENSION_MOD
+// SNHCSH, tension_module.f90:784-849
+LT_DEV void snhcsh(double X, double& SINHM, double& COSHM, double& COSHMM) {
+  const double P1 = -3.51754964808151394800e5, P2 = -1.15614435765005216044e4,
+               P3 = -1.63725857525983828727e2, P4 = -7.89474443963537015605e-1;
+  const double Q1 = -2.11052978884890840399e6, Q2 = 3.61578279834431989373e4,
+               Q3 = -2.77711081420602794433e2, Q4 = 1.0;
+  double AX = fabs(X), XS = AX * AX;
+  if (AX <= .5) {
+    double XC = X * XS;
+    double P = ((P4 * XS + P3) * XS + P2) * XS + P1;
+    double Q = ((Q4 * XS + Q3) * XS + Q2) * XS + Q1;
+    SINHM = XC * (P / Q);
+    double XSD4 = .25 * XS;
+    double XSD2 = XSD4 + XSD4;
+    P = ((P4 * XSD4 + P3) * XSD4 + P2) * XSD4 + P1;
+    Q = ((Q4 * XSD4 + Q3) * XSD4 + Q2) * XSD4 + Q1;
+    double F = XSD4 * (P / Q);
+    COSHMM = XSD2 * F * (F + 2.0);
+    COSHM = COSHMM + XSD2;
+  } else {
+    double EXPX = exp(AX);
+    SINHM = -(((1.0 / EXPX + AX) + AX) - EXPX) / 2.0;
+    if (X < 0.0) SINHM = -SINHM;
+    COSHM = ((1.0 / EXPX - 2.0) + EXPX) / 2.0;
+    COSHMM = COSHM - XS / 2.0;
+  }
+}
+
+LT_DEV double fsign1(double b) {  // SIGN(1.D0, b)
+  return copysign(1.0, b);
+}
+
+// One interval of SIGS (tension_module.f90:314-781 with SIGMA initialised to
+// zero as TSPSI's caller does): returns the tension factor of the interval
+// with knot spacing DX, end values Y1,Y2 and end slopes S1,S2.  sigerr is
+// incremented when the convexity Newton iteration exceeds 10000 steps (the
+// caller must then stop, as the reference RETURNs from SIGS).
+// The CONT flag is .TRUE. on the SIG<=.5 branch of the secant loop (original
+// TSPACK semantics; the F90 text leaves it unset there) -- same choice as the
+// oracle, checked against the flang build of the reference.
+LT_DEV double sigs_interval(double DX, double Y1, double Y2, double S1, double S2, int& sigerr) {
+  const double SBIG = LT_SBIG, RTOL = LT_SIGS_RTOL, FTOL = 0.0;
+  double S = (Y2 - Y1) / DX;
+  double D1 = S - S1;
+  double D2 = S2 - S;
+  double D1D2 = D1 * D2;
+  // infinite tension :470-485
+  if ((D1D2 == 0.0 && S1 != S2) || (S == 0.0 && S1 * S2 > 0.0)) return SBIG;
+  double SIG = 0.0;
+  if (D1D2 >= 0.0) {
+    if (D1D2 == 0.0) return 0.0;
+    double T = dmax(D1 / D2, D2 / D1);
+    if (T <= 2.0) return 0.0;
+    double TP1 = T + 1.0;
+    // convexity: Newton on F(SIG) = SIG*COSHM/SINHM - TP1  :531-580
+    SIG = sqrt(10.0 * T - 20.0);
+    int NIT = 0;
+    for (;;) {
+      double T1, FP;
+      if (SIG <= .5) {
+        double SINHM, COSHM, COSHMM;
+        snhcsh(SIG, SINHM, COSHM, COSHMM);
+        T1 = COSHM / SINHM;
+        FP = T1 + SIG * (SIG / SINHM - T1 * T1 + 1.0);
+      } else {
+        double EMS = exp(-SIG);
+        double SSM = 1.0 - EMS * (EMS + SIG + SIG);
+        T1 = (1.0 - EMS) * (1.0 - EMS) / SSM;
+        FP = T1 + SIG * (2.0 * SIG * EMS / SSM - T1 * T1 + 1.0);
+      }
+      double F = SIG * T1 - TP1;
+      NIT = NIT + 1;
+      if (NIT > 10000) {
+        sigerr = sigerr + 1;
+        return 0.0;
+      }
+      if (FP <= 0.0) break;
+      double DSIG = -F / FP;
+      if (fabs(DSIG) <= RTOL * SIG || (F >= 0.0 && F <= FTOL) || fabs(F) <= RTOL) break;
+      SIG = SIG + DSIG;
+    }
+    SIG = dmin(SIG, SBIG);
+    return (SIG > 0.0) ? SIG : 0.0;
+  }
+  // convexity cannot be satisfied :597-624
+  if (S1 * S < 0.0 || S2 * S < 0.0) return 0.0;
+  double T0 = 3.0 * S - S1 - S2;
+  double D0 = T0 * T0 - S1 * S2;
+  if (D0 <= 0.0 || S * T0 >= 0.0) return 0.0;
+  // monotonicity: secant iteration :638-760
+  double SGN = fsign1(S);
+  SIG = SBIG;
+  double FMAX = SGN * (SIG * S - S1 - S2) / (SIG - 2.0);
+  if (FMAX <= 0.0) return SBIG;
+  double STOL = RTOL * SIG;
+  double F = FMAX;
+  double F0 = SGN * D0 / (3.0 * (D1 - D2));
+  double FNEG = F0;
+  double DSIG = SIG;
+  double DMAX = SIG;
+  double D1PD2 = D1 + D2;
+  double A = 0.0, E = 0.0, C1, C2;
+  for (;;) {
+    DSIG = -F * DSIG / (F - F0);
+    if (fabs(DSIG) > fabs(DMAX) || DSIG * DMAX > 0.) {
+      DSIG = DMAX;
+      F0 = FNEG;
+      continue;
+    }
+    if (fabs(DSIG) < STOL / 2.0) DSIG = -copysign(STOL / 2.0, DMAX);
+    SIG = SIG + DSIG;
+    F0 = F;
+    bool CONT = true;
+    if (SIG <= .5) {
+      double SINHM, COSHM, COSHMM;
+      snhcsh(SIG, SINHM, COSHM, COSHMM);
+      C1 = SIG * COSHM * D2 - SINHM * D1PD2;
+      C2 = SIG * (SINHM + SIG) * D2 - COSHM * D1PD2;
+      A = C2 - C1;
+      E = SIG * SINHM - COSHMM - COSHMM;
+    } else {
+      double EMS = exp(-SIG);
+      double EMS2 = EMS + EMS;
+      double TM = 1.0 - EMS;
+      double SSINH = TM * (1.0 + EMS);
+      double SSM = SSINH - SIG * EMS2;
+      double SCM = TM * TM;
+      C1 = SIG * SCM * D2 - SSM * D1PD2;
+      C2 = SIG * SSINH * D2 - SCM * D1PD2;
+      F = FMAX;
+      if (C1 * (SIG * SCM * D1 - SSM * D1PD2) >= 0.0) CONT = false;
+      if (CONT) A = EMS2 * (SIG * TM * D2 + (TM - SIG) * D1PD2);
+      if (A * (C2 + C1) < 0.0) CONT = false;
+      if (CONT) E = SIG * SSINH - SCM - SCM;
+    }
+    if (CONT) F = (SGN * (E * S2 - C2) + sqrt(A * (C2 + C1))) / E;
+    STOL = RTOL * SIG;
+    if (fabs(DMAX) <= STOL || (F >= 0.0 && F <= FTOL) || fabs(F) <= RTOL) break;
+    DMAX = DMAX + DSIG;
+    if (F0 * F > 0.0 && fabs(F) >= fabs(F0)) {
+      DSIG = DMAX;
+      F0 = FNEG;
+      continue;
+    }
+    if (F0 * F <= 0.0) {
+      double T1 = DMAX, T2 = FNEG;
+      DMAX = DSIG;
+      FNEG = F0;
+      if (fabs(DSIG) > fabs(T1) && fabs(F) < fabs(T2)) {
+        DSIG = T1;
+        F0 = T2;
+      }
+    }
+  }
+  SIG = dmin(SIG, SBIG);
+  return (SIG > 0.0) ? SIG : 0.0;
+}
+
+// YPC1 end / interior formulas, tension_module.f90:852-977
+LT_DEV double ypc1_end(double SI, double T) {
+  return (SI >= 0.0) ? dmin(dmax(0.0, T), 3.0 * SI) : dmax(dmin(0.0, T), 3.0 * SI);
+}
+LT_DEV double ypc1_mid(double DXIM1, double DXI, double SIM1, double SI) {
+  double T = (DXIM1 * SI + DXI * SIM1) / (DXIM1 + DXI);
+  double ASIM1 = fabs(SIM1), ASI = fabs(SI);
+  double SGN = fsign1(SI);
+  if (ASIM1 > ASI) SGN = fsign1(SIM1);
+  return (SGN > 0.0) ? dmin(dmax(0.0, T), 3.0 * dmin(ASIM1, ASI))
+                     : dmax(dmin(0.0, T), -3.0 * dmin(ASIM1, ASI));
+}
+
+// YPC1 for N = 4.  ier != 0 when the abscissae are not strictly increasing.
+LT_DEV void ypc1_4(const double (&X)[4], const double (&Y)[4], double (&YP)[4], int& ier) {
+  double DX1 = X[1] - X[0], DX2 = X[2] - X[1], DX3 = X[3] - X[2];
+  ier = 0;
+  if (DX1 <= 0.0) { ier = 2; return; }
+  if (DX2 <= 0.0) { ier = 3; return; }
+  if (DX3 <= 0.0) { ier = 4; return; }
+  double SL1 = (Y[1] - Y[0]) / DX1;
+  double SL2 = (Y[2] - Y[1]) / DX2;
+  double SL3 = (Y[3] - Y[2]) / DX3;
+  YP[0] = ypc1_end(SL1, SL1 + DX1 * (SL1 - SL2) / (DX1 + DX2));
+  YP[1] = ypc1_mid(DX1, DX2, SL1, SL2);
+  YP[2] = ypc1_mid(DX2, DX3, SL2, SL3);
+  YP[3] = ypc1_end(SL3, SL3 + DX3 * (SL3 - SL2) / (DX2 + DX3));
+}
+
+// value of the Hermite tension spline on one interval, HVAL
+// tension_module.f90:1052-1117 (after the interval search)
+LT_DEV double hval_interval(double T, double X1, double X2, double Y1, double Y2, double YP1,
+                            double YP2, double SIGMA) {
+  double DX = X2 - X1;
+  double U = T - X1;
+  double B2 = U / DX;
+  double B1 = 1.0 - B2;
+  double S1 = YP1;
+  double S = (Y2 - Y1) / DX;
+  double D1 = S - S1;
+  double D2 = YP2 - S;
+  double SIG = fabs(SIGMA);
+  if (SIG < 1.e-9) {
+    return Y1 + U * (S1 + B2 * (D1 + B1 * (D1 - D2)));
+  } else if (SIG <= .5) {
+    double SB2 = SIG * B2, SM, CM, CMM, SM2, CM2, DUMMY;
+    snhcsh(SIG, SM, CM, CMM);
+    snhcsh(SB2, SM2, CM2, DUMMY);
+    double E = SIG * SM - CMM - CMM;
+    return Y1 + S1 * U +
+           DX * ((CM * SM2 - SM * CM2) * (D1 + D2) + SIG * (CM * CM2 - (SM + SIG) * SM2) * D1) /
+               (SIG * E);
+  } else {
+    double SB1 = SIG * B1;
+    double SB2 = SIG - SB1;
+    if (-SB1 > LT_SBIG || -SB2 > LT_SBIG) return Y1 + S * U;
+    double E1 = exp(-SB1), E2 = exp(-SB2);
+    double EMS = E1 * E2;
+    double TM = 1.0 - EMS;
+    double TS = TM * TM;
+    double TP = 1.0 + EMS;
+    double E = TM * (SIG * TP - TM - TM);
+    return Y1 + S * U +
+           DX * (TM * (TP - E1 - E2) * (D1 + D2) +
+                 SIG * ((E2 + EMS * (E1 - 2.0) - B1 * TS) * D1 +
+                        (E1 + EMS * (E2 - 2.0) - B2 * TS) * D2)) /
+               (SIG * E);
+  }
+}
+
+// derivative on one interval, HPVAL tension_module.f90:1196-1250
+LT_DEV double hpval_interval(double T, double X1, double X2, double Y1, double Y2, double YP1,
+                             double YP2, double SIGMA) {
+  double DX = X2 - X1;
+  double B1 = (X2 - T) / DX;
+  double B2 = 1.0 - B1;
+  double S1 = YP1;
+  double S = (Y2 - Y1) / DX;
+  double D1 = S - S1;
+  double D2 = YP2 - S;
+  double SIG = fabs(SIGMA);
+  if (SIG < 1.e-9) {
+    return S1 + B2 * (D1 + D2 - 3.0 * B1 * (D2 - D1));
+  } else if (SIG <= .5) {
+    double SB2 = SIG * B2, SM, CM, CMM, SM2, CM2, DUMMY;
+    snhcsh(SIG, SM, CM, CMM);
+    snhcsh(SB2, SM2, CM2, DUMMY);
+    double SINH2 = SM2 + SB2;
+    double E = SIG * SM - CMM - CMM;
+    return S1 + ((CM * CM2 - SM * SINH2) * (D1 + D2) + SIG * (CM * SINH2 - (SM + SIG) * CM2) * D1) / E;
+  } else {
+    double SB1 = SIG * B1;
+    double SB2 = SIG - SB1;
+    if (-SB1 > LT_SBIG || -SB2 > LT_SBIG) return S;
+    double E1 = exp(-SB1), E2 = exp(-SB2);
+    double EMS = E1 * E2;
+    double TM = 1.0 - EMS;
+    double E = TM * (SIG * (1.0 + EMS) - TM - TM);
+    return S + (TM * ((E2 - E1) * (D1 + D2) + TM * (D1 - D2)) +
+                SIG * ((E1 * EMS - E2) * D1 + (E1 - E2 * EMS) * D2)) /
+                   E;
+  }
+}
+
+// TSPSI(4) + HVAL at T, or the linint fallback when SIGS reports SigErr:
+// the body of one slot of WCTS_ITPI, hydrodynamic_module.f90:2619-2644.
+// sigerr_count (diagnostic) counts fits that fell back.
+LT_DEV double spline4_eval(const double (&X)[4], const double (&Y)[4], double T,
+                            int& sigerr_count) {
+  double YP[4];
+  int ier;
+  ypc1_4(X, Y, YP, ier);
+  // TSPSI: IER = -4 when YPC1 fails; SIGMA is then whatever the caller's array
+  // held.  s-levels are strictly increasing for any valid ROMS grid, so this
+  // only guards against h <= 0: treat as zero tension with zero slopes.
+  double sig0 = 0.0, sig1 = 0.0, sig2 = 0.0;
+  int sigerr = 0;
+  if (ier == 0) {
+    // SIGS interval loop (tension_module.f90:448-776): ONE copy of the
+    // interval body, fed through selects; stops at the first SigErr as the
+    // reference RETURNs.
+#pragma unroll 1
+    for (int iv = 0; iv < 3; iv++) {
+      double dx = (iv == 0) ? X[1] - X[0] : (iv == 1) ? X[2] - X[1] : X[3] - X[2];
+      double ya = (iv == 0) ? Y[0] : (iv == 1) ? Y[1] : Y[2];
+      double yb = (iv == 0) ? Y[1] : (iv == 1) ? Y[2] : Y[3];
+      double pa = (iv == 0) ? YP[0] : (iv == 1) ? YP[1] : YP[2];
+      double pb = (iv == 0) ? YP[1] : (iv == 1) ? YP[2] : YP[3];
+      double sg = sigs_interval(dx, ya, yb, pa, pb, sigerr);
+      if (sigerr != 0) break;
+      if (iv == 0) sig0 = sg; else if (iv == 1) sig1 = sg; else sig2 = sg;
+    }
+  } else {
+    // abscissae not strictly increasing (degenerate water column): slopes and
+    // tensions are defined as zero here and in the oracle; HVAL then returns 0
+    // on an interval of non-positive width (IER = -2, tension_module.f90:1060).
+    YP[0] = YP[1] = YP[2] = YP[3] = 0.0;
+  }
+  if (sigerr != 0) {
+    sigerr_count += 1;
+    return linint4(X, Y, T);
+  }
+  // interval search: extrapolate with the end intervals, else INTRVL
+  // (tension_module.f90:1044-1053,1287-1354) = comparison chain for N = 4
+  int I = (T < X[1]) ? 1 : (T < X[2]) ? 2 : 3;
+  if (T > X[3]) I = 3;
+  double x1 = (I == 1) ? X[0] : (I == 2) ? X[1] : X[2];
+  double x2 = (I == 1) ? X[1] : (I == 2) ? X[2] : X[3];
+  double y1 = (I == 1) ? Y[0] : (I == 2) ? Y[1] : Y[2];
+  double y2 = (I == 1) ? Y[1] : (I == 2) ? Y[2] : Y[3];
+  double p1 = (I == 1) ? YP[0] : (I == 2) ? YP[1] : YP[2];
+  double p2 = (I == 1) ? YP[1] : (I == 2) ? YP[2] : YP[3];
+  double sg = (I == 1) ? sig0 : (I == 2) ? sig1 : sig2;
+  if (x2 - x1 <= 0.0) return 0.0;
+  return hval_interval(T, x1, x2, y1, y2, p1, p2, sg);
+}
+
+// ------------------------------------------------------------ GRIDCELL_MOD
+// gridcell for ONE element (checkele form), gridcell_module.f90:26-257.
+// qx/qy: the four corners in element order.  Returns true when the reference
+// sets triangle = 1.
+LT_DEV bool gc_horiz(double ya, double yb, double xa, double xb, double Xpos, double Ypos,
+                     bool& hit) {
+  if (ya == yb && Ypos == ya) {
+    hit = (xa > xb && Xpos > xb && Xpos < xa) || (xb > xa && Xpos > xa && Xpos < xb);
+    return true;  // decided (hit, or "cycle")
+  }
+  return false;
+}
+
+LT_DEV bool gridcell_one(const double (&qx)[4], const double (&qy)[4], double Xpos, double Ypos) {
+  // 1, 2: bounding tests :49-59
+  if ((Ypos < qy[0] && Ypos < qy[1] && Ypos < qy[2] && Ypos < qy[3]) ||
+      (Ypos > qy[0] && Ypos > qy[1] && Ypos > qy[2] && Ypos > qy[3]))
+    return false;
+  if ((Xpos < qx[0] && Xpos < qx[1] && Xpos < qx[2] && Xpos < qx[3]) ||
+      (Xpos > qx[0] && Xpos > qx[1] && Xpos > qx[2] && Xpos > qx[3]))
+    return false;
+  // 3: on a node :61-69
+  if ((Xpos == qx[0] && Ypos == qy[0]) || (Xpos == qx[1] && Ypos == qy[1]) ||
+      (Xpos == qx[2] && Ypos == qy[2]) || (Xpos == qx[3] && Ypos == qy[3]))
+    return true;
+  // 4: horizontal segments :71-149 (pairs in the source order)
+  if (qy[0] == qy[1] || qy[0] == qy[2] || qy[0] == qy[3] || qy[1] == qy[2] || qy[1] == qy[3] ||
+      qy[2] == qy[3]) {
+    bool hit;
+    if (gc_horiz(qy[0], qy[1], qx[0], qx[1], Xpos, Ypos, hit)) return hit;
+    if (gc_horiz(qy[0], qy[2], qx[0], qx[2], Xpos, Ypos, hit)) return hit;
+    if (gc_horiz(qy[0], qy[3], qx[0], qx[3], Xpos, Ypos, hit)) return hit;
+    if (gc_horiz(qy[1], qy[2], qx[1], qx[2], Xpos, Ypos, hit)) return hit;
+    if (gc_horiz(qy[1], qy[3], qx[1], qx[3], Xpos, Ypos, hit)) return hit;
+    if (gc_horiz(qy[2], qy[3], qx[2], qx[3], Xpos, Ypos, hit)) return hit;
+  }
+  // 5: y equal to a corner y :151-183
+  if (Ypos == qy[0] || Ypos == qy[1] || Ypos == qy[2] || Ypos == qy[3]) {
+    double bhighy = fmax(fmax(qy[0], qy[1]), fmax(qy[2], qy[3]));
+    if (Ypos == bhighy) return false;
+    double blowy = fmin(fmin(qy[0], qy[1]), fmin(qy[2], qy[3]));
+    if (Ypos == blowy) return false;
+  }
+  // 6: crossing count :185-254.  An on-edge hit sets triangle=1 and leaves the
+  // edge loop; the parity test that follows cannot unset it.
+  int total = 0;
+  bool on_edge = false;
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    if (on_edge) break;
+    int q = (p + 1) & 3;
+    double bx1 = qx[p], by1 = qy[p], bx2 = qx[q], by2 = qy[q];
+    if (Xpos <= bx1 || Xpos <= bx2) {
+      if ((by1 > by2 && Ypos >= by2 && Ypos <= by1) || (by2 > by1 && Ypos >= by1 && Ypos <= by2)) {
+        if (bx1 == bx2) {
+          if (Xpos == bx1) {
+            on_edge = true;
+          } else if (Ypos != by2) {
+            total += 1;
+          }
+        } else {
+          double slope = ((by1 - by2) / (bx1 - bx2));
+          double xintersect = (Ypos - by1 + (slope * bx1)) / slope;
+          if (xintersect > Xpos && Ypos != by2) total += 1;
+          if (xintersect == Xpos) on_edge = true;
+        }
+      }
+    }
+  }
+  return on_edge || ((total & 1) != 0);
+}
+
+// ---------------------------------------------------- HYDRO_MOD weights
+// Interpolation weights inside a quadrilateral element with the reference's
+// three regimes (hydrodynamic_module.f90:1707-1738 = :2527-2563).  Expressed
+// as four node weights w1..w4 is NOT what the reference does (it evaluates
+// v1+(v2-v1)*t+(v3-v1)*u), so the regime and (t,u)/(W) are kept and applied by
+// apply() in the reference's own operation order.
+struct QuadWeights {
+  int regime;  // 1: first triangle, 2: second triangle, 3: inverse distance, 4: on a node
+  double t, u, W1, W2, W3, W4;
+  int node_hit;  // regime 4: last matching node (1..4), as :2543-2546 overwrite in order
+};
+
+LT_DEV QuadWeights quad_weights(double xp, double yp, const double (&x)[4], const double (&y)[4]) {
+  QuadWeights w;
+  w.W1 = w.W2 = w.W3 = w.W4 = 0.0;
+  w.node_hit = 0;
+  double x1 = x[0], x2 = x[1], x3 = x[2], x4 = x[3], y1 = y[0], y2 = y[1], y3 = y[2], y4 = y[3];
+  w.t = ((xp - x1) * (y3 - y1) + (y1 - yp) * (x3 - x1)) / ((x2 - x1) * (y3 - y1) - (y2 - y1) * (x3 - x1));
+  w.u = ((xp - x1) * (y2 - y1) + (y1 - yp) * (x2 - x1)) / ((x3 - x1) * (y2 - y1) - (y3 - y1) * (x2 - x1));
+  w.regime = 1;
+  if (w.t < 0. || w.u < 0. || (w.t + w.u) > 1.0) {
+    w.t = ((xp - x3) * (y1 - y3) + (y3 - yp) * (x1 - x3)) / ((x4 - x3) * (y1 - y3) - (y4 - y3) * (x1 - x3));
+    w.u = ((xp - x3) * (y4 - y3) + (y3 - yp) * (x4 - x3)) / ((x1 - x3) * (y4 - y3) - (y1 - y3) * (x4 - x3));
+    w.regime = 2;
+    if (w.t < 0. || w.u < 0. || (w.t + w.u) > 1.0) {
+      bool n1 = (xp == x1 && yp == y1), n2 = (xp == x2 && yp == y2), n3 = (xp == x3 && yp == y3),
+           n4 = (xp == x4 && yp == y4);
+      if (n1 || n2 || n3 || n4) {
+        w.regime = 4;
+        if (n1) { w.W1 = 1.0; w.node_hit = 1; }
+        if (n2) { w.W2 = 1.0; w.node_hit = 2; }
+        if (n3) { w.W3 = 1.0; w.node_hit = 3; }
+        if (n4) { w.W4 = 1.0; w.node_hit = 4; }
+      } else {
+        double Dis1 = 1. / (sqrt((x1 - xp) * (x1 - xp) + (y1 - yp) * (y1 - yp)));
+        double Dis2 = 1. / (sqrt((x2 - xp) * (x2 - xp) + (y2 - yp) * (y2 - yp)));
+        double Dis3 = 1. / (sqrt((x3 - xp) * (x3 - xp) + (y3 - yp) * (y3 - yp)));
+        double Dis4 = 1. / (sqrt((x4 - xp) * (x4 - xp) + (y4 - yp) * (y4 - yp)));
+        double TDis = Dis1 + Dis2 + Dis3 + Dis4;
+        w.W1 = Dis1 / TDis;
+        w.W2 = Dis2 / TDis;
+        w.W3 = Dis3 / TDis;
+        w.W4 = Dis4 / TDis;
+        w.regime = 3;
+      }
+    }
+  }
+  return w;
+}
+
+// interp() value formula, hydrodynamic_module.f90:2530-2561
+LT_DEV double apply_interp(const QuadWeights& w, double v1, double v2, double v3, double v4) {
+  if (w.regime == 1) return v1 + (v2 - v1) * w.t + (v3 - v1) * w.u;
+  if (w.regime == 2) return v3 + (v4 - v3) * w.t + (v1 - v3) * w.u;
+  if (w.regime == 3) return w.W1 * v1 + w.W2 * v2 + w.W3 * v3 + w.W4 * v4;
+  return (w.node_hit == 1) ? v1 : (w.node_hit == 2) ? v2 : (w.node_hit == 3) ? v3 : v4;
+}
+
+// getInterp() value formula, hydrodynamic_module.f90:1997-2003: the on-node
+// case keeps tOK = 2, i.e. the second-triangle formula (copied as is).
+LT_DEV double apply_getinterp(const QuadWeights& w, double v1, double v2, double v3, double v4) {
+  if (w.regime == 1) return v1 + (v2 - v1) * w.t + (v3 - v1) * w.u;
+  if (w.regime == 2 || w.regime == 4) return v3 + (v4 - v3) * w.t + (v1 - v3) * w.u;
+  return w.W1 * v1 + w.W2 * v2 + w.W3 * v3 + w.W4 * v4;
+}
+
+}  // namespace ltd
