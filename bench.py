@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-steps/s of the LTRANS hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of update_particles() (LTRANS.f90:707) over the shard of
+particles a rank holds: one internal time step of LTRANS.  Workload (N = 1):
+BASELINE.json configs[1] -- 1M particles on a synthetic 512x256x30 ROMS grid,
+RK4 advection only (HTurb / VTurb / behaviour off).  For N > 1 every rank holds
+its own 1M-particle shard of the same grid (fields replicated, weak scaling,
+SURVEY.md section 8e) and the ranks all-gather the new (x,y,z) over RCCL at the
+end of each step.  Inputs are resident in HBM when the timed region starts.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  "roofline":     algorithmic bytes / HIP-event kernel time vs the HBM peak
+  "cpu_baseline": the CPU oracle (a single-thread C port of the reference path)
+                  timed on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic bytes one particle-step must touch,
+# RK4 only, fp32 slab storage (coordinates / depth / angle stay fp64):
+#   state 96 + grid statics 256 + zeta 4x3x4 = 48 + u,v,w 3 x (4 x 4 x 3 x 4 = 192) = 576
+A_ADV_F32 = 96 + 256 + 48 + 576          # = 976 B
+A_ADV_F64 = 96 + 256 + 96 + 1152         # = 1600 B
+HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--numpar", type=int, default=1_000_000, help="particles per GPU")
+    ap.add_argument("--grid", type=str, default="512x256x30")
+    ap.add_argument("--slab", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=40000,
+                    help="particles of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-steps", type=int, default=30)
+    return ap.parse_args()
+
+
+def build_inputs(vi, uj, us, numpar, seed):
+    from ltrans_amd import roms_synth as rs
+    g = rs.make_grid(vi, uj, us)
+    geo = rs.build_geometry(g)
+    bounds = rs.create_bounds(g)
+    parts = rs.make_particles(g, geo, bounds, numpar, seed=seed)
+    return g, geo, bounds, parts
+
+
+def make_engine(ltrans_amd, cfg, g, geo, bounds, parts, records, **kw):
+    from ltrans_amd import roms_synth as rs
+    from ltrans_amd.driver import LtransRun
+    e = ltrans_amd.Engine(cfg, **kw)
+    e.set_grid(geo)
+    e.set_bounds(bounds)
+    e.set_particles(**parts, **rs.behaviour_state(cfg, cfg.numpar))
+    run = LtransRun(e, cfg.dt, cfg.idt, lambda r: records(r))
+    run.init_hydro()
+    return e, run
+
+
+def cpu_baseline(ltrans_amd, args, vi, uj, us, g, geo, bounds, records):
+    """Time the CPU oracle (kind "port": single-thread C restatement of the
+    reference path, oracle/ltrans_oracle.c) on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    from ltrans_amd import roms_synth as rs
+    n = args.cpu_sample
+    parts = rs.make_particles(g, geo, bounds, n, seed=777)
+    cfg = ltrans_amd.LtConfig(numpar=n, us=us, ws=us + 1, dt=3600, idt=120, Behavior=0,
+                              ErrorFlag=1)
+    e, run = make_engine(ltrans_amd, cfg, g, geo, bounds, parts, records,
+                         lib=oracle_lib.load_oracle(), prefix="lto_")
+    ex = run.external_times(2)
+    t0 = time.perf_counter()
+    for it in range(1, args.cpu_steps + 1):
+        e.update_particles(ex, run.internal_times(ex, it), 2, it)
+    dt = time.perf_counter() - t0
+    e.close()
+    return {"value": n * args.cpu_steps / dt, "unit": "particle-steps/s", "cores": 1,
+            "kind": "port",
+            "sample": f"{n} particles x {args.cpu_steps} internal steps on the same "
+                      f"{vi}x{uj}x{us} grid, {dt:.1f} s wall, {os.cpu_count()} host cores present"}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import ltrans_amd
+    from ltrans_amd import roms_synth as rs
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    vi, uj, us = (int(v) for v in args.grid.split("x"))
+    n = args.numpar
+    g, geo, bounds, parts = build_inputs(vi, uj, us, n, seed=12345 + rank)
+    rec_cache = {}
+
+    def records(r):
+        if r not in rec_cache:
+            rec_cache[r] = rs.make_record(g, geo, r, with_kh=False)
+        return rec_cache[r]
+
+    cfg = ltrans_amd.LtConfig(numpar=n, us=us, ws=us + 1, dt=3600, idt=120, Behavior=0,
+                              ErrorFlag=1, device=dev.index,
+                              slab_storage=(ltrans_amd.abi.LT_SLAB_F32 if args.slab == "f32"
+                                            else ltrans_amd.abi.LT_SLAB_F64))
+    e, run = make_engine(ltrans_amd, cfg, g, geo, bounds, parts, records)
+
+    send = recv = None
+    if world > 1:
+        send = torch.empty(3 * n, dtype=torch.float64, device=dev)
+        recv = torch.empty(3 * n * world, dtype=torch.float64, device=dev)
+
+    p = 2                      # second external step: plain (b,c,f) time interpolation
+    ex = run.external_times(p)
+    stepIT = cfg.dt // cfg.idt
+    state = {"it": 0, "p": p, "ex": ex}
+
+    def needs_rotation():
+        return state["it"] + 1 > stepIT
+
+    def rotate():
+        """next external step: updateHydro = rotate slots + upload ONE record.  Kept
+        outside the timed region (slab upload is reported separately)."""
+        state["p"] += 1
+        state["it"] = 0
+        run.p = state["p"]
+        run.update_hydro()
+        state["ex"] = run.external_times(state["p"])
+
+    def one_step():
+        state["it"] += 1
+        ix = run.internal_times(state["ex"], state["it"])
+        e.update_particles(state["ex"], ix, state["p"], state["it"])
+        if world > 1:
+            e.pack_positions(send.data_ptr())
+            e.sync()
+            dist.all_gather_into_tensor(recv, send)
+
+    def fence():
+        e.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        if needs_rotation():
+            rotate()
+        one_step()
+    fence()
+    e.profile_begin(args.steps)
+    wall = 0.0
+    upload_s = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if needs_rotation():
+            fence()
+            wall += time.perf_counter() - t0
+            tu = time.perf_counter()
+            rotate()
+            fence()
+            upload_s += time.perf_counter() - tu
+            t0 = time.perf_counter()
+        one_step()
+    fence()
+    wall += time.perf_counter() - t0
+    k_ms, k_n = e.profile_end()
+    stats = e.counters()
+
+    wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
+    wall = float(wall_t.item())
+
+    active = stats["active"]
+    total_particle_steps = float(n) * world * args.steps
+    value = total_particle_steps / wall
+    A = A_ADV_F32 if args.slab == "f32" else A_ADV_F64
+    k_avg_s = (k_ms / max(k_n, 1)) * 1e-3
+    achieved = (A * n / k_avg_s) / 1e9 if k_avg_s > 0 else 0.0
+
+    out = {
+        "metric": "particle-steps/s", "value": value, "unit": "particle-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{n} particles per GPU, synthetic {vi}x{uj}x{us} ROMS grid, RK4 "
+                               "advection only (HTurb/VTurb/behavior off), idt=120 s"
+                               + (", RCCL all-gather of (x,y,z) per step" if world > 1 else ""),
+                   "particles_per_gpu": n, "grid": args.grid, "slab_storage": args.slab,
+                   "active_last_step": active, "errors_last_step": stats["errors"],
+                   "sigerr_last_step": stats["sigerr"],
+                   "slab_rotation_s_excluded": upload_s},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "k_step", "kernel_ms_avg": k_avg_s * 1e3,
+                     "algorithmic_bytes_per_particle_step": A},
+    }
+    if rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(ltrans_amd, args, vi, uj, us, g, geo, bounds, records)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    e.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -27,9 +27,8 @@
  *     LOGICAL = int32_t (0 = .FALSE., non-zero = .TRUE.).
  *   - arrays are column-major with the extents written in the comments;
  *     node / element / segment ids are 1-based, 0 = empty adjacency slot.
- *   - every function returns an int status: LT_OK (0) or a negative LT_ERR_*;
- *     lt_step() returns >= 0 = number of particles that raised an error code
- *     in that step.  No host pointer is retained after a call returns.
+ *   - every function returns an int status: LT_OK (0) or a negative LT_ERR_*.
+ *     No host pointer is retained after a call returns.
  *   - an engine is single-caller (like the reference: one thread); it owns one
  *     HIP stream on one device.
  *   - plain pointers and sizes only: no torch / C++ types cross this ABI.
@@ -234,8 +233,9 @@ int lt_set_rng_window(lt_engine *e, int64_t active_before, int64_t active_total)
 
 /* the hot path ---------------------------------------------------------- */
 /* = update_particles() with main's ex(3), ix(3), p, it (LTRANS.f90:568-571,
- * 588-590).  Asynchronous on the engine's stream; returns the error count of
- * the PREVIOUS completed step only if sync = 0 is used by the host harness. */
+ * 588-590).  Enqueued on the engine's stream and returns LT_OK at once; the
+ * step's counters (tracked particles, per-particle error count) are read with
+ * lt_get_stats(), which synchronises. */
 int lt_step(lt_engine *e, const double *ex3, const double *ix3, int32_t p, int32_t it);
 int lt_sync(lt_engine *e);
 int lt_get_stats(lt_engine *e, lt_step_stats *out);
@@ -247,6 +247,15 @@ int lt_get_particles(lt_engine *e, lt_particles *out);
 int lt_pack_positions(lt_engine *e, void *dst_device);
 /* the engine's HIP stream (hipStream_t) for ordering external work */
 void *lt_stream(lt_engine *e);
+
+/* measurement aids (not part of the reference interface) ------------------- */
+/* HIP-event timing of the step kernel on the engine's stream: arm up to
+ * max_steps (start, stop) pairs, then synchronise and sum them. */
+int lt_profile_begin(lt_engine *e, int32_t max_steps);
+int lt_profile_end(lt_engine *e, double *total_ms, int32_t *launches);
+/* diagnostics of the last step: [0] active [1] errors [2] SigErr fallbacks
+ * [3] brute-force boundary scans [4] full point-in-polygon evaluations */
+int lt_get_counters(lt_engine *e, uint64_t *out8);
 
 #ifdef __cplusplus
 }

@@ -146,4 +146,5 @@ ENTRY_POINTS = [
     "set_slab", "set_time_slots", "set_rng", "get_rng", "count_active", "set_rng_window",
     "step", "sync", "get_stats", "get_particles",
 ]
-HIP_ONLY_ENTRY_POINTS = ["last_error", "abi_version", "pack_positions", "stream"]
+HIP_ONLY_ENTRY_POINTS = ["last_error", "abi_version", "pack_positions", "stream",
+                         "profile_begin", "profile_end", "get_counters"]

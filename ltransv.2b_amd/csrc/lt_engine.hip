@@ -67,7 +67,10 @@ struct lt_engine {
   unsigned long long* h_counters = nullptr;  // pinned
   lt_step_stats stats{};
   bool stats_valid = true;
-  std::vector<DevBuf*> all;
+  // optional HIP-event timing of the step kernel (lt_profile_*)
+  bool prof_on = false;
+  std::vector<hipEvent_t> prof_ev;  // pairs (start, stop)
+  size_t prof_used = 0;
 };
 
 namespace {
@@ -371,6 +374,7 @@ int lt_destroy(lt_engine* e) {
                     &e->P_deadage, &e->settletime, &e->counters};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
+  for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
   if (e->h_counters) (void)hipHostFree(e->h_counters);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -649,11 +653,17 @@ int lt_step(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32
   HIPCHK(e, hipMemsetAsync(e->counters.p, 0, CNT_COUNT * sizeof(unsigned long long), e->stream));
   unsigned blocks = (unsigned)((e->cfg.numpar + 255) / 256);
   if (blocks) {
+    const bool prof = e->prof_on && e->prof_used + 2 <= e->prof_ev.size();
+    if (prof) HIPCHK(e, hipEventRecord(e->prof_ev[e->prof_used], e->stream));
     if (e->cfg.slab_storage == LT_SLAB_F32)
       hipLaunchKernelGGL((k_step<float>), dim3(blocks), dim3(256), 0, e->stream, P);
     else
       hipLaunchKernelGGL((k_step<double>), dim3(blocks), dim3(256), 0, e->stream, P);
     HIPCHK(e, hipGetLastError());
+    if (prof) {
+      HIPCHK(e, hipEventRecord(e->prof_ev[e->prof_used + 1], e->stream));
+      e->prof_used += 2;
+    }
   }
   HIPCHK(e, hipMemcpyAsync(e->h_counters, e->counters.p, CNT_COUNT * sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, e->stream));
@@ -687,6 +697,39 @@ int lt_get_counters(lt_engine* e, uint64_t* out8) {
   if (!e || !out8) return LT_ERR_ARG;
   TRY(lt_sync(e));
   for (int i = 0; i < CNT_COUNT; i++) out8[i] = e->h_counters[i];
+  return LT_OK;
+}
+
+/* HIP-event timing of the step kernel on the engine's stream.
+ * lt_profile_begin(e, max_steps) arms up to max_steps (start, stop) event pairs;
+ * lt_profile_end(e, &total_ms, &launches) synchronises and sums them. */
+int lt_profile_begin(lt_engine* e, int32_t max_steps) {
+  if (!e || max_steps <= 0) return LT_ERR_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  while (e->prof_ev.size() < (size_t)max_steps * 2) {
+    hipEvent_t ev;
+    HIPCHK(e, hipEventCreate(&ev));
+    e->prof_ev.push_back(ev);
+  }
+  e->prof_used = 0;
+  e->prof_on = true;
+  return LT_OK;
+}
+
+int lt_profile_end(lt_engine* e, double* total_ms, int32_t* launches) {
+  if (!e || !total_ms || !launches) return LT_ERR_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  double sum = 0.0;
+  for (size_t i = 0; i + 1 < e->prof_used; i += 2) {
+    float ms = 0.f;
+    HIPCHK(e, hipEventElapsedTime(&ms, e->prof_ev[i], e->prof_ev[i + 1]));
+    sum += ms;
+  }
+  *total_ms = sum;
+  *launches = (int32_t)(e->prof_used / 2);
+  e->prof_on = false;
+  e->prof_used = 0;
   return LT_OK;
 }
 

@@ -281,6 +281,27 @@ class Engine:
         f.restype = C.c_int
         self._check(f(self._h, C.c_void_p(int(dst_device_ptr))), "pack_positions")
 
+    def profile_begin(self, max_steps):
+        f = self.lib.lt_profile_begin
+        f.restype = C.c_int
+        self._check(f(self._h, int(max_steps)), "profile_begin")
+
+    def profile_end(self):
+        """-> (total kernel milliseconds, launches) measured with HIP events."""
+        f = self.lib.lt_profile_end
+        f.restype = C.c_int
+        ms, n = C.c_double(), C.c_int32()
+        self._check(f(self._h, C.byref(ms), C.byref(n)), "profile_end")
+        return ms.value, n.value
+
+    def counters(self):
+        f = self.lib.lt_get_counters
+        f.restype = C.c_int
+        a = np.zeros(8, dtype=np.uint64)
+        self._check(f(self._h, a.ctypes.data_as(C.c_void_p)), "get_counters")
+        return {"active": int(a[0]), "errors": int(a[1]), "sigerr": int(a[2]),
+                "brute_bounds": int(a[3]), "pip_full": int(a[4])}
+
     def stream(self):
         f = self.lib.lt_stream
         f.restype = C.c_void_p
