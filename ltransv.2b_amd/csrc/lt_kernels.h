@@ -465,32 +465,119 @@ struct Column {
   double z1[3];     // Pwc_z{b,c,f}(1)
 };
 
-// find_currents, LTRANS.f90:1422-1614
+// s-level depth split into its zeta-independent part (one division per level
+// instead of one per level and slot): the operations and their order are those
+// of getSlevel/getWlevel (hydrodynamic_module.f90:2691-2777).
+struct LevCoef { double a, b, c; };
+LT_DEV LevCoef level_coef(const double* tab, int k, double h, double hc, int Vtransform) {
+  LevCoef r;
+  double A = tab[k - 1];
+  double B = tab[LT_LEV_STRIDE + k - 1];
+  if (Vtransform == 1) {
+    double S = A + (h - hc) * B;
+    r.a = S; r.b = 1.0 + S / h; r.c = 0.0;
+  } else if (Vtransform == 2) {
+    r.a = (A + h * B) / (hc + h); r.b = 0.0; r.c = 0.0;
+  } else {
+    r.a = A; r.b = 1.0 + tab[2 * LT_LEV_STRIDE + k - 1]; r.c = (h - hc) * B;
+  }
+  return r;
+}
+LT_DEV double level_at(const LevCoef& q, double zeta, double h, int Vtransform) {
+  if (Vtransform == 1) return q.a + zeta * q.b;
+  if (Vtransform == 2) return zeta + (zeta + h) * q.a;
+  return zeta * q.b + q.a + q.c;
+}
+
+LT_DEV int level_window2(const double* tab, int n, double Z, const Column& C, double hc,
+                         int Vtransform) {
+  int lo = 3, hi = n - 1;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    LevCoef q = level_coef(tab, mid, C.h, hc, Vtransform);
+    bool below = (Z < level_at(q, C.zeta[0], C.h, Vtransform)) ||
+                 (Z < level_at(q, C.zeta[1], C.h, Vtransform)) ||
+                 (Z < level_at(q, C.zeta[2], C.h, Vtransform));
+    if (below) hi = mid; else lo = mid + 1;
+  }
+  return lo - 2;
+}
+
+// per-wave LDS scratch of the batched convexity Newton pass
+#define LT_TASK_CAP 576  // 64 lanes x 3 slots x 3 intervals
+struct WaveScratch {
+  double task[LT_TASK_CAP];          // in: T ; out: sigma
+  unsigned short owner[LT_TASK_CAP]; // lane | slot << 6
+  unsigned int errmask[64];          // bit s: slot s of this lane hit SigErr
+};
+
+// state of one slot between the classify pass and the evaluation pass
+struct SlotFit {
+  double x1, x2, y1, p1, p2, S, sig;
+  int pend;   // task index of the evaluation interval's sigma, or -1
+};
+
+// One slot of WCTS_ITPI by the reference's own straight-line code (YPC1 + SIGS
+// + HVAL or the linint fallback): used when the batched pass reports SigErr or
+// the level window is degenerate.  Out of line: rare.
 template <typename SlabT>
-LT_DEV void find_currents(const StepParams& P, const double* lev, const Column& C, int4 rn, int4 un,
-                          int4 vn, double Xs, double Ys, double Zs, int version, double& Uad,
-                          double& Vad, double& Wad, int& sigerr_count) {
+__device__ __noinline__ double slot_slow(const SlabT* F, int n1, int n2, int n3, int n4, int L,
+                                         int k0, int ps, int regime, int node_hit, double wt,
+                                         double wu, double W1, double W2, double W3, double W4,
+                                         double az0, double az1, double az2, double az3,
+                                         double Pzs) {
+  QuadWeights w;
+  w.regime = regime; w.node_hit = node_hit; w.t = wt; w.u = wu;
+  w.W1 = W1; w.W2 = W2; w.W3 = W3; w.W4 = W4;
+  double az[4] = {az0, az1, az2, az3}, av[4];
+#pragma unroll
+  for (int l = 0; l < 4; l++)
+    av[l] = apply_interp(w, fld(F, n1, L, k0 + l, ps), fld(F, n2, L, k0 + l, ps),
+                         fld(F, n3, L, k0 + l, ps), fld(F, n4, L, k0 + l, ps));
+  int dummy = 0;
+  return spline4_eval(az, av, Pzs, dummy);
+}
+
+// find_currents, LTRANS.f90:1422-1614, executed by the WHOLE wave: lanes whose
+// particle is not tracked (act = false) only take part in the cooperative
+// Newton pass.
+template <typename SlabT>
+LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& ws, bool act,
+                          const Column& C, int4 rn, int4 un, int4 vn, double Xs, double Ys,
+                          double Zs, int version, double& Uad, double& Vad, double& Wad,
+                          int& sigerr_count) {
   const double* rtab = lev;
   const double* wtab = lev + 3 * LT_LEV_STRIDE;
+  const int lane = threadIdx.x & 63;
   const double ixv = (version == 1) ? P.ix0 : (version == 2) ? P.ix1 : P.ix2;
+  Uad = 0.0; Vad = 0.0; Wad = 0.0;
   // regime tests :1481-1491
-  if ((Zs < C.wz1[0] + P.z0) || (Zs < C.wz1[1] + P.z0) || (Zs < C.wz1[2] + P.z0)) {
-    Uad = 0.0; Vad = 0.0; Wad = 0.0;
-    return;
+  bool zero = false, loglayer = false;
+  int ii = 1, iii = 1;
+  if (act) {
+    zero = (Zs < C.wz1[0] + P.z0) || (Zs < C.wz1[1] + P.z0) || (Zs < C.wz1[2] + P.z0);
+    loglayer = !zero && ((Zs < C.z1[0]) || (Zs < C.z1[1]) || (Zs < C.z1[2]));
+    if (!zero && !loglayer) {
+      ii = level_window2(rtab, P.us, Zs, C, P.hc, P.Vtransform);
+      iii = level_window2(wtab, P.ws, Zs, C, P.hc, P.Vtransform);
+    }
   }
-  const bool loglayer = (Zs < C.z1[0]) || (Zs < C.z1[1]) || (Zs < C.z1[2]);
-  const int ii = level_window(rtab, P.us, Zs, C.zeta[0], C.zeta[1], C.zeta[2], C.h, P.hc, P.Vtransform);
-  const int iii = level_window(wtab, P.ws, Zs, C.zeta[0], C.zeta[1], C.zeta[2], C.h, P.hc, P.Vtransform);
+  const bool spl = act && !zero && !loglayer;  // this lane fits splines
 #pragma unroll 1
   for (int var = 0; var < 3; var++) {
     const int4 nd = (var == 0) ? un : (var == 1) ? vn : rn;
-    Quad q = (var == 2) ? load_quad_rho(P.rnode, nd)
-                        : load_quad_xy((var == 0) ? P.unode : P.vnode, nd);
-    const QuadWeights w = quad_weights(Xs, Ys, q.x, q.y);
     const SlabT* F = (const SlabT*)((var == 0) ? P.U : (var == 1) ? P.V : P.W);
     const int L = (var == 2) ? P.ws : P.us;
     const double* tab = (var == 2) ? wtab : rtab;
-    double Pv[3];
+    const int k0 = (var == 2) ? iii : ii;
+    QuadWeights w;
+    w.regime = 1; w.node_hit = 0; w.t = w.u = w.W1 = w.W2 = w.W3 = w.W4 = 0.0;
+    double Pv0 = 0.0, Pv1 = 0.0, Pv2 = 0.0;
+    if (act && !zero) {
+      Quad q = (var == 2) ? load_quad_rho(P.rnode, nd)
+                          : load_quad_xy((var == 0) ? P.unode : P.vnode, nd);
+      w = quad_weights(Xs, Ys, q.x, q.y);
+    }
     if (loglayer) {
       // log layer :1493-1522: level 1 of u,v; level 2 of w
       const int k = (var == 2) ? 2 : 1;
@@ -499,32 +586,143 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, const Column& 
         const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
         double val = apply_interp(w, fld(F, nd.x, L, k, ps), fld(F, nd.y, L, k, ps),
                                   fld(F, nd.z, L, k, ps), fld(F, nd.w, L, k, ps));
-        // u(z) = u(z1) * log10((z-zb)/z0) / log10((z1-zb)/z0); zb = Pwc_wzb(1) for all slots
         double ztop = (var == 2) ? level_z(wtab, 2, C.zeta[s], C.h, P.hc, P.Vtransform) : C.z1[s];
-        Pv[s] = val * log10((Zs - C.wz1[0]) / P.z0) / log10((ztop - C.wz1[0]) / P.z0);
-      }
-    } else {
-      const int k0 = (var == 2) ? iii : ii;
-#pragma unroll 1
-      for (int s = 0; s < 3; s++) {
-        const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
-        const double zeta = (s == 0) ? C.zeta[0] : (s == 1) ? C.zeta[1] : C.zeta[2];
-        const double Pzs = (s == 0) ? C.Pz[0] : (s == 1) ? C.Pz[1] : C.Pz[2];
-        double az[4], av[4];
-#pragma unroll
-        for (int l = 0; l < 4; l++) {
-          az[l] = level_z(tab, k0 + l, zeta, C.h, P.hc, P.Vtransform);
-          av[l] = apply_interp(w, fld(F, nd.x, L, k0 + l, ps), fld(F, nd.y, L, k0 + l, ps),
-                               fld(F, nd.z, L, k0 + l, ps), fld(F, nd.w, L, k0 + l, ps));
-        }
-        double r = spline4_eval(az, av, Pzs, sigerr_count);
-        if (s == 0) Pv[0] = r; else if (s == 1) Pv[1] = r; else Pv[2] = r;
+        double r = val * log10((Zs - C.wz1[0]) / P.z0) / log10((ztop - C.wz1[0]) / P.z0);
+        if (s == 0) Pv0 = r; else if (s == 1) Pv1 = r; else Pv2 = r;
       }
     }
+    // ---------------- pass A: fit without iterating, queue Newton tasks
+    SlotFit fit[3];
+    LevCoef lc[4];
+    unsigned slowmask = 0;
+    int ntask = 0;  // wave-uniform
+    ws.errmask[lane] = 0;
+    if (spl) {
+#pragma unroll
+      for (int l = 0; l < 4; l++) lc[l] = level_coef(tab, k0 + l, C.h, P.hc, P.Vtransform);
+    }
+    // field window: 4 nodes x (4 levels x 3 slots) contiguous values per node
+    SlabT f[4][12];
+    if (spl) {
+      const SlabT* b0 = F + ((size_t)(nd.x - 1) * L + (k0 - 1)) * 3;
+      const SlabT* b1 = F + ((size_t)(nd.y - 1) * L + (k0 - 1)) * 3;
+      const SlabT* b2 = F + ((size_t)(nd.z - 1) * L + (k0 - 1)) * 3;
+      const SlabT* b3 = F + ((size_t)(nd.w - 1) * L + (k0 - 1)) * 3;
+#pragma unroll
+      for (int j = 0; j < 12; j++) { f[0][j] = b0[j]; f[1][j] = b1[j]; f[2][j] = b2[j]; f[3][j] = b3[j]; }
+    }
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+      const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
+      double X[4], Y[4], YP[4], SL[3];
+      int I = 1;
+      bool ok = spl;
+      if (spl) {
+        const double zeta = C.zeta[s], Pzs = C.Pz[s];
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+          X[l] = level_at(lc[l], zeta, C.h, P.Vtransform);
+          double v1 = (double)((ps == 0) ? f[0][3 * l] : (ps == 1) ? f[0][3 * l + 1] : f[0][3 * l + 2]);
+          double v2 = (double)((ps == 0) ? f[1][3 * l] : (ps == 1) ? f[1][3 * l + 1] : f[1][3 * l + 2]);
+          double v3 = (double)((ps == 0) ? f[2][3 * l] : (ps == 1) ? f[2][3 * l + 1] : f[2][3 * l + 2]);
+          double v4 = (double)((ps == 0) ? f[3][3 * l] : (ps == 1) ? f[3][3 * l + 1] : f[3][3 * l + 2]);
+          Y[l] = apply_interp(w, v1, v2, v3, v4);
+        }
+        const double DX1 = X[1] - X[0], DX2 = X[2] - X[1], DX3 = X[3] - X[2];
+        ok = (DX1 > 0.0) && (DX2 > 0.0) && (DX3 > 0.0);
+        if (!ok) slowmask |= (1u << s);
+        // YPC1 (tension_module.f90:852-977) with the chord slopes kept for SIGS/HVAL
+        SL[0] = (Y[1] - Y[0]) / DX1;
+        SL[1] = (Y[2] - Y[1]) / DX2;
+        SL[2] = (Y[3] - Y[2]) / DX3;
+        YP[0] = ypc1_end(SL[0], SL[0] + DX1 * (SL[0] - SL[1]) / (DX1 + DX2));
+        YP[1] = ypc1_mid(DX1, DX2, SL[0], SL[1]);
+        YP[2] = ypc1_mid(DX2, DX3, SL[1], SL[2]);
+        YP[3] = ypc1_end(SL[2], SL[2] + DX3 * (SL[2] - SL[1]) / (DX2 + DX3));
+        I = (Pzs < X[1]) ? 1 : (Pzs < X[2]) ? 2 : 3;
+        if (Pzs > X[3]) I = 3;
+        fit[s].x1 = (I == 1) ? X[0] : (I == 2) ? X[1] : X[2];
+        fit[s].x2 = (I == 1) ? X[1] : (I == 2) ? X[2] : X[3];
+        fit[s].y1 = (I == 1) ? Y[0] : (I == 2) ? Y[1] : Y[2];
+        fit[s].p1 = (I == 1) ? YP[0] : (I == 2) ? YP[1] : YP[2];
+        fit[s].p2 = (I == 1) ? YP[1] : (I == 2) ? YP[2] : YP[3];
+        fit[s].S = (I == 1) ? SL[0] : (I == 2) ? SL[1] : SL[2];
+      }
+      fit[s].sig = 0.0;
+      fit[s].pend = -1;
+      // SIGS: classify the three intervals (tension_module.f90:448-776)
+#pragma unroll
+      for (int iv = 0; iv < 3; iv++) {
+        double sigma = 0.0, T = 0.0;
+        int kind = SIGK_DONE;
+        if (ok) {
+          kind = sigs_classify(SL[iv], YP[iv], YP[iv + 1], sigma, T);
+          if (kind == SIGK_SECANT) sigma = sigs_secant(SL[iv], YP[iv], YP[iv + 1]);
+        }
+        const bool need = ok && (kind == SIGK_NEWTON);
+        const unsigned long long m = __ballot(need);
+        const int idx = ntask + __popcll(m & ((1ull << lane) - 1ull));
+        if (need) {
+          ws.task[idx] = T;
+          ws.owner[idx] = (unsigned short)(lane | (s << 6));
+        }
+        ntask += __popcll(m);
+        if (ok && iv + 1 == I) {
+          fit[s].sig = sigma;
+          fit[s].pend = need ? idx : -1;
+        }
+      }
+    }
+    // ---------------- pass B: the queued Newton iterations, 64 at a time
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+    for (int t = lane; t < ntask; t += 64) {
+      bool failed;
+      double sg = sigs_newton(ws.task[t], failed);
+      ws.task[t] = sg;
+      if (failed) {
+        unsigned short o = ws.owner[t];
+        atomicOr(&ws.errmask[o & 63], 1u << (o >> 6));
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---------------- pass C: evaluate at P_z{b,c,f}
+    if (spl) {
+      const unsigned em = ws.errmask[lane];
+      slowmask |= em;
+      if (em) sigerr_count += __popc(em);
+#pragma unroll
+      for (int s = 0; s < 3; s++) {
+        double r;
+        if (slowmask & (1u << s)) {
+          const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
+          r = slot_slow<SlabT>(F, nd.x, nd.y, nd.z, nd.w, L, k0, ps, w.regime, w.node_hit, w.t,
+                               w.u, w.W1, w.W2, w.W3, w.W4,
+                               level_at(lc[0], C.zeta[s], C.h, P.Vtransform),
+                               level_at(lc[1], C.zeta[s], C.h, P.Vtransform),
+                               level_at(lc[2], C.zeta[s], C.h, P.Vtransform),
+                               level_at(lc[3], C.zeta[s], C.h, P.Vtransform), C.Pz[s]);
+        } else {
+          double sg = (fit[s].pend >= 0) ? ws.task[fit[s].pend] : fit[s].sig;
+          r = hval_interval_s(C.Pz[s], fit[s].x1, fit[s].x2, fit[s].y1, fit[s].p1, fit[s].p2,
+                              fit[s].S, sg);
+        }
+        if (s == 0) Pv0 = r; else if (s == 1) Pv1 = r; else Pv2 = r;
+      }
+    }
+    // the next variable reuses the scratch: all lanes must have read their results
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     // time interpolation :1534-1598 / hydrodynamic_module.f90:2653-2670
-    double e1 = Pv[0], e2 = (P.p == 1) ? Pv[0] : Pv[1], e3 = (P.p == 1) ? Pv[1] : Pv[2];
-    double val = polintd3(P.ex0, P.ex1, P.ex2, e1, e2, e3, ixv);
-    if (var == 0) Uad = val; else if (var == 1) Vad = val; else Wad = val;
+    if (act && !zero) {
+      double e1 = Pv0, e2 = (P.p == 1) ? Pv0 : Pv1, e3 = (P.p == 1) ? Pv1 : Pv2;
+      double val = polintd3(P.ex0, P.ex1, P.ex2, e1, e2, e3, ixv);
+      if (var == 0) Uad = val; else if (var == 1) Vad = val; else Wad = val;
+    }
   }
 }
 
@@ -532,31 +730,39 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, const Column& 
 template <typename SlabT>
 __global__ __launch_bounds__(256) void k_step(const StepParams P) {
   __shared__ double lev[6 * LT_LEV_STRIDE];
+  __shared__ WaveScratch wsc[4];
   for (int i = threadIdx.x; i < 6 * LT_LEV_STRIDE; i += blockDim.x) lev[i] = P.lev[i];
   __syncthreads();
 
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool inrange = n < P.numpar;
+  const size_t N = (size_t)P.numpar;
+  double* par = P.par + (inrange ? n : 0);
+#define PARV(k) par[(size_t)(k) * N]
   unsigned c_active = 0, c_err = 0, c_brute = 0, c_pipslow = 0;
   int sigerr_count = 0;
 
-  if (n < P.numpar) {
-    const size_t N = (size_t)P.numpar;
-    double* par = P.par + n;
-#define PARV(k) par[(size_t)(k) * N]
-    const double X = PARV(pX), Y = PARV(pY);
-    double Z = PARV(pZ);
-    double nX = X, nY = Y, nZ = Z;  // the new position to commit
-    bool keep_pn = false;           // true: pn stays what memory holds
-    int err = 0;
-    int er = P.P_r_element[n], eu = P.P_u_element[n], ev = P.P_v_element[n];
-    bool ele_dirty = false;
-    double lifespan = 0.0;
-    bool set_lifespan = false;
+  // per-particle state that lives across the sections
+  double X = 0.0, Y = 0.0, Z = 0.0, nX = 0.0, nY = 0.0, nZ = 0.0, age = 0.0, lifespan = 0.0;
+  double P_depth = 0.0, P_zetac = 0.0, cosA = 1.0, sinA = 0.0, Zpar = 0.0;
+  double maxpartdepth = 0.0, minpartdepth = 0.0;
+  bool keep_pn = false, ele_dirty = false, set_lifespan = false;
+  bool act = false;  // tracked this step and no error so far
+  int err = 0, er = 1, eu = 1, ev = 1;
+  int4 rn = make_int4(1, 1, 1, 1), un = rn, vn = rn;
+  Column C;
+  C.h = 1.0;
+#pragma unroll
+  for (int s = 0; s < 3; s++) { C.zeta[s] = 0.0; C.Pz[s] = 0.0; C.wz1[s] = 0.0; C.z1[s] = 0.0; }
 
+  // ---- section 1: gates, element search, water column (per lane)
+  if (inrange) {
+    X = PARV(pX); Y = PARV(pY); Z = PARV(pZ);
+    nX = X; nY = Y; nZ = Z;
+    er = P.P_r_element[n]; eu = P.P_u_element[n]; ev = P.P_v_element[n];
     // the gates of LTRANS.f90:790-816
     const bool released = !(P.ix2 <= PARV(pDOB));
     bool track = released;
-    double age = 0.0;
     if (released) {
       age = PARV(pAge) + (double)(float)P.idt;
       PARV(pAge) = age;
@@ -570,9 +776,7 @@ __global__ __launch_bounds__(256) void k_step(const StepParams P) {
       if (track && P.OpenOceanBoundary && P.oob[n] != 0) track = false;
       if (!track) keep_pn = true;
     }
-
     if (track) {
-      int4 rn, un, vn;
       // setEle :830 (all three grids are searched even after a miss)
       bool okr = find_element<true>(P.rnode, P.RE, P.rAdj, X, Y, er, rn);
       bool oku = find_element<false>(P.unode, P.UE, P.uAdj, X, Y, eu, un);
@@ -580,13 +784,14 @@ __global__ __launch_bounds__(256) void k_step(const StepParams P) {
       ele_dirty = true;
       if (!okv) err = 6; else if (!oku) err = 5; else if (!okr) err = 4;  // last assignment wins
       if (err == 0) {
+        act = true;
         c_active = 1;
         // setInterp + getInterp :882-896
         RhoNode r1 = P.rnode[rn.x - 1], r2 = P.rnode[rn.y - 1], r3 = P.rnode[rn.z - 1],
                 r4 = P.rnode[rn.w - 1];
         double qx[4] = {r1.x, r2.x, r3.x, r4.x}, qy[4] = {r1.y, r2.y, r3.y, r4.y};
         const QuadWeights w0 = quad_weights(X, Y, qx, qy);
-        const double P_depth = -1.0 * apply_getinterp(w0, r1.depth, r2.depth, r3.depth, r4.depth);
+        P_depth = -1.0 * apply_getinterp(w0, r1.depth, r2.depth, r3.depth, r4.depth);
         const double P_angle = apply_getinterp(w0, r1.angle, r2.angle, r3.angle, r4.angle);
         using Z4 = typename SlabTraits<SlabT>::zeta4;
         const Z4* zt = (const Z4*)P.zeta;
@@ -594,11 +799,10 @@ __global__ __launch_bounds__(256) void k_step(const StepParams P) {
         auto pick = [](const Z4& v, int s) -> double {
           return (double)((s == 0) ? v.x : (s == 1) ? v.y : v.z);
         };
-        Column C;
         C.zeta[0] = apply_getinterp(w0, pick(z1, P.tb), pick(z2, P.tb), pick(z3, P.tb), pick(z4, P.tb));
         C.zeta[1] = apply_getinterp(w0, pick(z1, P.tc), pick(z2, P.tc), pick(z3, P.tc), pick(z4, P.tc));
         C.zeta[2] = apply_getinterp(w0, pick(z1, P.tf), pick(z2, P.tf), pick(z3, P.tf), pick(z4, P.tf));
-        const double P_zetac = C.zeta[1];
+        P_zetac = C.zeta[1];
         // vertical clamps :900-922
         if (Z < P_depth) {
           Z = P_depth + (double)0.001f;
@@ -608,179 +812,192 @@ __global__ __launch_bounds__(256) void k_step(const StepParams P) {
         if (Z > C.zeta[0]) C.Pz[0] = C.zeta[0] - (double)0.001f;
         if (Z > C.zeta[1]) C.Pz[1] = C.zeta[1] - (double)0.001f;
         if (Z > C.zeta[2]) C.Pz[2] = C.zeta[2] - (double)0.001f;
-        const double Zpar = polintd3(P.ex0, P.ex1, P.ex2, C.Pz[0], C.Pz[1], C.Pz[2], P.ix1);
+        Zpar = polintd3(P.ex0, P.ex1, P.ex2, C.Pz[0], C.Pz[1], C.Pz[2], P.ix1);
         Z = Zpar;  // par(n,pZ) = Zpar :922
         C.h = -1.0 * P_depth;
         const double* rtab = lev;
         const double* wtab = lev + 3 * LT_LEV_STRIDE;
-        double maxpartdepth, minpartdepth;
-        {
+        const LevCoef w1 = level_coef(wtab, 1, C.h, P.hc, P.Vtransform);
+        const LevCoef r1c = level_coef(rtab, 1, C.h, P.hc, P.Vtransform);
+        const LevCoef wN = level_coef(wtab, P.ws, C.h, P.hc, P.Vtransform);
 #pragma unroll
-          for (int s = 0; s < 3; s++) {
-            C.wz1[s] = level_z(wtab, 1, C.zeta[s], C.h, P.hc, P.Vtransform);
-            C.z1[s] = level_z(rtab, 1, C.zeta[s], C.h, P.hc, P.Vtransform);
-          }
-          double t0 = level_z(wtab, P.ws, C.zeta[0], C.h, P.hc, P.Vtransform);
-          double t1 = level_z(wtab, P.ws, C.zeta[1], C.h, P.hc, P.Vtransform);
-          double t2 = level_z(wtab, P.ws, C.zeta[2], C.h, P.hc, P.Vtransform);
-          maxpartdepth = C.wz1[0];
-          if (C.wz1[1] > maxpartdepth) maxpartdepth = C.wz1[1];
-          if (C.wz1[2] > maxpartdepth) maxpartdepth = C.wz1[2];
-          minpartdepth = t0;
-          if (t1 < minpartdepth) minpartdepth = t1;
-          if (t2 < minpartdepth) minpartdepth = t2;
+        for (int s = 0; s < 3; s++) {
+          C.wz1[s] = level_at(w1, C.zeta[s], C.h, P.Vtransform);
+          C.z1[s] = level_at(r1c, C.zeta[s], C.h, P.Vtransform);
         }
-        // RK4 :990-1053
-        const double cosA = cos(P_angle), sinA = sin(P_angle);
-        double sumU = 0.0, sumV = 0.0, sumW = 0.0;
-        double Xs = X, Ys = Y, Zs = Zpar;
+        double t0 = level_at(wN, C.zeta[0], C.h, P.Vtransform);
+        double t1 = level_at(wN, C.zeta[1], C.h, P.Vtransform);
+        double t2 = level_at(wN, C.zeta[2], C.h, P.Vtransform);
+        maxpartdepth = C.wz1[0];
+        if (C.wz1[1] > maxpartdepth) maxpartdepth = C.wz1[1];
+        if (C.wz1[2] > maxpartdepth) maxpartdepth = C.wz1[2];
+        minpartdepth = t0;
+        if (t1 < minpartdepth) minpartdepth = t1;
+        if (t2 < minpartdepth) minpartdepth = t2;
+        cosA = cos(P_angle);
+        sinA = sin(P_angle);
+      }
+    }
+  }
+
+  // ---- section 2: RK4 :990-1053, executed by the whole wave
+  double sumU = 0.0, sumV = 0.0, sumW = 0.0;
+  {
+    WaveScratch& ws = wsc[threadIdx.x >> 6];
+    double Xs = X, Ys = Y, Zs = Zpar;
 #pragma unroll 1
-        for (int st = 0; st < 4; st++) {
-          const int version = (st == 0) ? 1 : (st == 3) ? 3 : 2;
-          double Uad, Vad, Wad;
-          find_currents<SlabT>(P, lev, C, rn, un, vn, Xs, Ys, Zs, version, Uad, Vad, Wad,
-                               sigerr_count);
-          if (st == 0) { sumU = Uad; sumV = Vad; sumW = Wad; }
-          else if (st == 3) { sumU = sumU + Uad; sumV = sumV + Vad; sumW = sumW + Wad; }
-          else { sumU = sumU + 2.0 * Uad; sumV = sumV + 2.0 * Vad; sumW = sumW + 2.0 * Wad; }
-          if (st < 3) {
-            const double dtf = (double)P.idt;
-            if (st < 2) {
-              Xs = X + (Uad * cosA - Vad * sinA) * dtf / 2.0;
-              Ys = Y + (Uad * sinA + Vad * cosA) * dtf / 2.0;
-              Zs = Zpar + Wad * dtf / 2.0;
-            } else {
-              Xs = X + (Uad * cosA - Vad * sinA) * dtf;
-              Ys = Y + (Uad * sinA + Vad * cosA) * dtf;
-              Zs = Zpar + Wad * dtf;
-            }
-            if (Zs > minpartdepth) Zs = minpartdepth - (double)0.000001f;
-            if (Zs < maxpartdepth) Zs = maxpartdepth + (double)0.000001f;
-          }
+    for (int st = 0; st < 4; st++) {
+      const int version = (st == 0) ? 1 : (st == 3) ? 3 : 2;
+      double Uad, Vad, Wad;
+      find_currents<SlabT>(P, lev, ws, act, C, rn, un, vn, Xs, Ys, Zs, version, Uad, Vad, Wad,
+                           sigerr_count);
+      if (st == 0) { sumU = Uad; sumV = Vad; sumW = Wad; }
+      else if (st == 3) { sumU = sumU + Uad; sumV = sumV + Vad; sumW = sumW + Wad; }
+      else { sumU = sumU + 2.0 * Uad; sumV = sumV + 2.0 * Vad; sumW = sumW + 2.0 * Wad; }
+      if (st < 3) {
+        const double dtf = (double)P.idt;
+        if (st < 2) {
+          Xs = X + (Uad * cosA - Vad * sinA) * dtf / 2.0;
+          Ys = Y + (Uad * sinA + Vad * cosA) * dtf / 2.0;
+          Zs = Zpar + Wad * dtf / 2.0;
+        } else {
+          Xs = X + (Uad * cosA - Vad * sinA) * dtf;
+          Ys = Y + (Uad * sinA + Vad * cosA) * dtf;
+          Zs = Zpar + Wad * dtf;
         }
-        const double P_U = sumU / 6.0, P_V = sumV / 6.0, P_W = sumW / 6.0;
-        const double AdvectX = P.idt * (P_U * cosA - P_V * sinA);
-        const double AdvectY = P.idt * (P_U * sinA + P_V * cosA);
-        const double AdvectZ = P.idt * P_W;
-        const double TurbHx = 0.0, TurbHy = 0.0, TurbV = 0.0;
-        // behave (types 0 and 6), behavior_module.f90:181-551
-        double ZBehav = 0.0;
-        if (P.Behavior != 0) {
-          const size_t np = (size_t)P.numpar;
-          double sw3 = P.P_swim[n + 2 * np];
-          bool sw_dirty = false;
-          if (age >= P.swimstart) { sw3 = P.P_swim[n] * age + P.P_swim[n + np]; sw_dirty = true; }
-          if (age >= P.P_pediage[n]) { sw3 = P.swimfast; sw_dirty = true; }
-          if (sw_dirty) P.P_swim[n + 2 * np] = sw3;
-          double parBehav = 0.0;
-          if (P.P_behave[n] == 6) parBehav = (age >= P.swimstart) ? P.sink : sw3;
-          ZBehav = parBehav * P.idt;
-        }
-        // new position, vertical reflection :1128-1176
-        double newXpos = X + AdvectX + TurbHx;
-        double newYpos = Y + AdvectY + TurbHy;
-        double newZpos = Z + AdvectZ + TurbV;
-        if (newZpos > P_zetac) {
-          double reflect = P_zetac - newZpos;
-          newZpos = P_zetac + reflect;
-        }
-        if (newZpos < P_depth) {
-          double reflect = P_depth - newZpos;
-          newZpos = P_depth + reflect;
-          if (P.TrackCollisions) P.hitBottom[n] += 1;
-        }
-        newZpos = newZpos + ZBehav;
-        if (newZpos > P_zetac) newZpos = P_zetac - (double)0.000001f;
-        if (newZpos < P_depth) {
-          newZpos = P_depth + (double)0.000001f;
-          if (P.TrackCollisions) P.hitBottom[n] += 1;
-        }
-        // horizontal boundaries :1180-1232
-        double Xpos = X, Ypos = Y, nXpos = newXpos, nYpos = newYpos;
-        int skipbound = -1, reflects = 0;
-        bool done = false;  // waterFlag
-        for (;;) {
-          Hit H;
-          intersect_reflect(P, Xpos, Ypos, nXpos, nYpos, skipbound, H, c_brute);
-          skipbound = H.seg;
-          if (!H.found) break;
-          if (P.TrackCollisions) P.hitLand[n] += 1;
-          if (P.OpenOceanBoundary && H.water) {
-            nX = H.fix; nY = H.fiy; nZ = newZpos;
-            P.oob[n] = 1;
-            done = true;
-            break;
-          }
-          reflects += 1;
-          if (reflects > 3) {
-            err = 24;
-            done = true;
-            break;
-          }
-          Xpos = H.fix; Ypos = H.fiy; nXpos = H.frx; nYpos = H.fry;
-        }
-        if (!done) {
-          newXpos = nXpos;
-          newYpos = nYpos;
-          // mbounds :1240, ibounds :1275
-          bool slow = false, inb;
-          if (P.use_pip_index) {
-            inb = mbounds_indexed(P, newXpos, newYpos, slow);
-          } else {
-            slow = true;
-            inb = false;
-          }
+        if (Zs > minpartdepth) Zs = minpartdepth - (double)0.000001f;
+        if (Zs < maxpartdepth) Zs = maxpartdepth + (double)0.000001f;
+      }
+    }
+  }
+
+  // ---- section 3: behaviour, reflection, boundaries, re-search, settlement
+  if (act) {
+    const double P_U = sumU / 6.0, P_V = sumV / 6.0, P_W = sumW / 6.0;
+    const double AdvectX = P.idt * (P_U * cosA - P_V * sinA);
+    const double AdvectY = P.idt * (P_U * sinA + P_V * cosA);
+    const double AdvectZ = P.idt * P_W;
+    const double TurbHx = 0.0, TurbHy = 0.0, TurbV = 0.0;
+    // behave (types 0 and 6), behavior_module.f90:181-551
+    double ZBehav = 0.0;
+    if (P.Behavior != 0) {
+      const size_t np = (size_t)P.numpar;
+      double sw3 = P.P_swim[n + 2 * np];
+      bool sw_dirty = false;
+      if (age >= P.swimstart) { sw3 = P.P_swim[n] * age + P.P_swim[n + np]; sw_dirty = true; }
+      if (age >= P.P_pediage[n]) { sw3 = P.swimfast; sw_dirty = true; }
+      if (sw_dirty) P.P_swim[n + 2 * np] = sw3;
+      double parBehav = 0.0;
+      if (P.P_behave[n] == 6) parBehav = (age >= P.swimstart) ? P.sink : sw3;
+      ZBehav = parBehav * P.idt;
+    }
+    // new position, vertical reflection :1128-1176
+    double newXpos = X + AdvectX + TurbHx;
+    double newYpos = Y + AdvectY + TurbHy;
+    double newZpos = Z + AdvectZ + TurbV;
+    if (newZpos > P_zetac) {
+      double reflect = P_zetac - newZpos;
+      newZpos = P_zetac + reflect;
+    }
+    if (newZpos < P_depth) {
+      double reflect = P_depth - newZpos;
+      newZpos = P_depth + reflect;
+      if (P.TrackCollisions) P.hitBottom[n] += 1;
+    }
+    newZpos = newZpos + ZBehav;
+    if (newZpos > P_zetac) newZpos = P_zetac - (double)0.000001f;
+    if (newZpos < P_depth) {
+      newZpos = P_depth + (double)0.000001f;
+      if (P.TrackCollisions) P.hitBottom[n] += 1;
+    }
+    // horizontal boundaries :1180-1232
+    double Xpos = X, Ypos = Y, nXpos = newXpos, nYpos = newYpos;
+    int skipbound = -1, reflects = 0;
+    bool done = false;  // waterFlag
+    for (;;) {
+      Hit H;
+      intersect_reflect(P, Xpos, Ypos, nXpos, nYpos, skipbound, H, c_brute);
+      skipbound = H.seg;
+      if (!H.found) break;
+      if (P.TrackCollisions) P.hitLand[n] += 1;
+      if (P.OpenOceanBoundary && H.water) {
+        nX = H.fix; nY = H.fiy; nZ = newZpos;
+        P.oob[n] = 1;
+        done = true;
+        break;
+      }
+      reflects += 1;
+      if (reflects > 3) {
+        err = 24;
+        done = true;
+        break;
+      }
+      Xpos = H.fix; Ypos = H.fiy; nXpos = H.frx; nYpos = H.fry;
+    }
+    if (!done) {
+      newXpos = nXpos;
+      newYpos = nYpos;
+      // mbounds :1240, ibounds :1275
+      bool slow = false, inb;
+      if (P.use_pip_index) {
+        inb = mbounds_indexed(P, newXpos, newYpos, slow);
+      } else {
+        slow = true;
+        inb = false;
+      }
+      if (slow) {
+        c_pipslow += 1;
+        inb = inpoly_full(newXpos, newYpos, P.maxbound, P.bx, P.by, false);
+      }
+      if (!inb) {
+        err = 25;
+      } else {
+        bool inisl = false;
+        if (P.numislands > 0) {
+          slow = false;
+          if (P.use_pip_index) inisl = ibounds_indexed(P, newXpos, newYpos, slow);
+          else slow = true;
           if (slow) {
             c_pipslow += 1;
-            inb = inpoly_full(newXpos, newYpos, P.maxbound, P.bx, P.by, false);
+            inisl = ibounds_full(P.hx, P.hy, P.hid, P.maxisland, P.numislands, newXpos, newYpos);
           }
-          if (!inb) {
-            err = 25;
-          } else {
-            bool inisl = false;
-            if (P.numislands > 0) {
-              slow = false;
-              if (P.use_pip_index) inisl = ibounds_indexed(P, newXpos, newYpos, slow);
-              else slow = true;
-              if (slow) {
-                c_pipslow += 1;
-                inisl = ibounds_full(P.hx, P.hy, P.hid, P.maxisland, P.numislands, newXpos, newYpos);
-              }
-            }
-            if (inisl) {
-              err = 26;
-            } else {
-              nX = newXpos; nY = newYpos; nZ = newZpos;  // :1312-1314
-              // setEle on the new position :1317
-              bool okr2 = find_element<true>(P.rnode, P.RE, P.rAdj, nXpos, nYpos, er, rn);
-              bool oku2 = find_element<false>(P.unode, P.UE, P.uAdj, nXpos, nYpos, eu, un);
-              bool okv2 = find_element<false>(P.vnode, P.VE, P.vAdj, nXpos, nYpos, ev, vn);
-              if (!okv2) err = 29; else if (!oku2) err = 28; else if (!okr2) err = 27;
-              if (err == 0 && P.settlementon) {
-                // testSettlement with the OLD position and the NEW element :1375
-                if (age >= P.settletime[n]) {
-                  int inpoly = test_settlement(P, X, Y, er);
-                  if (inpoly > 0) {
-                    P.settle[n] = 1;
-                    nZ = P_depth;
-                    P.endpoly[n] = inpoly;
-                    lifespan = age;
-                    set_lifespan = true;
-                  }
-                }
+        }
+        if (inisl) {
+          err = 26;
+        } else {
+          nX = newXpos; nY = newYpos; nZ = newZpos;  // :1312-1314
+          // setEle on the new position :1317
+          bool okr2 = find_element<true>(P.rnode, P.RE, P.rAdj, nXpos, nYpos, er, rn);
+          bool oku2 = find_element<false>(P.unode, P.UE, P.uAdj, nXpos, nYpos, eu, un);
+          bool okv2 = find_element<false>(P.vnode, P.VE, P.vAdj, nXpos, nYpos, ev, vn);
+          if (!okv2) err = 29; else if (!oku2) err = 28; else if (!okr2) err = 27;
+          if (err == 0 && P.settlementon) {
+            // testSettlement with the OLD position and the NEW element :1375
+            if (age >= P.settletime[n]) {
+              int inpoly = test_settlement(P, X, Y, er);
+              if (inpoly > 0) {
+                P.settle[n] = 1;
+                nZ = P_depth;
+                P.endpoly[n] = inpoly;
+                lifespan = age;
+                set_lifespan = true;
               }
             }
           }
         }
       }
-      // ErrorFlag handling :858-877 etc.  (ErrorFlag 0 = the host stops; the
-      // particle is returned to its previous location as under ErrorFlag 1)
-      if (err != 0) {
-        c_err = 1;
-        if (P.ErrorFlag == 2) { P.dead[n] = 1; keep_pn = true; }
-        else if (P.ErrorFlag == 3) { P.oob[n] = 1; keep_pn = true; }
-        else { nX = X; nY = Y; nZ = Z; keep_pn = false; }
-      }
+    }
+  }
+
+  // ---- section 4: ErrorFlag handling and the commit loop
+  if (inrange) {
+    // ErrorFlag handling :858-877 etc.  (ErrorFlag 0 = the host stops; the
+    // particle is returned to its previous location as under ErrorFlag 1)
+    if (err != 0) {
+      c_err = 1;
+      if (P.ErrorFlag == 2) { P.dead[n] = 1; keep_pn = true; }
+      else if (P.ErrorFlag == 3) { P.oob[n] = 1; keep_pn = true; }
+      else { nX = X; nY = Y; nZ = Z; keep_pn = false; }
     }
     P.err_code[n] = err;
     if (ele_dirty) {
@@ -797,8 +1014,8 @@ __global__ __launch_bounds__(256) void k_step(const StepParams P) {
     PARV(ppX) = X; PARV(ppY) = Y; PARV(ppZ) = Z;
     PARV(pX) = nX; PARV(pY) = nY; PARV(pZ) = nZ;
     if (set_lifespan) PARV(pLifespan) = lifespan;
-#undef PARV
   }
+#undef PARV
 
   // block-level counter reduction -> one atomic per counter per block
   __shared__ unsigned red[5];

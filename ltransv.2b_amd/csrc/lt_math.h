@@ -406,6 +406,197 @@ LT_DEV double spline4_eval(const double (&X)[4], const double (&Y)[4], double T,
   return hval_interval(T, x1, x2, y1, y2, p1, p2, sg);
 }
 
+// ---------------------------------------------- batched SIGS pieces
+// The fused kernel does not iterate inside the per-lane spline code: each
+// interval is first CLASSIFIED (no loops), the few that need the convexity
+// Newton iteration are handed to a wave-cooperative pass (lt_kernels.h), and
+// the monotonicity secant iteration (rare) runs out of line.  The arithmetic of
+// every piece is that of SIGS (tension_module.f90:314-781).
+enum { SIGK_DONE = 0, SIGK_NEWTON = 1, SIGK_SECANT = 2 };
+
+// Classify one interval: S = (Y2-Y1)/DX as computed by the caller (the same
+// expression SIGS evaluates), end slopes S1,S2.  Returns SIGK_DONE with sigma,
+// SIGK_NEWTON with T (= MAX(D1/D2,D2/D1) > 2), or SIGK_SECANT.
+// T <= 2 is decided without dividing when |big| <= 2|small| (then the rounded
+// quotient cannot exceed 2); otherwise the one quotient that is the maximum is
+// formed exactly as the reference forms it.
+LT_DEV int sigs_classify(double S, double S1, double S2, double& sigma, double& T) {
+  double D1 = S - S1;
+  double D2 = S2 - S;
+  double D1D2 = D1 * D2;
+  sigma = 0.0;
+  T = 0.0;
+  if ((D1D2 == 0.0 && S1 != S2) || (S == 0.0 && S1 * S2 > 0.0)) {
+    sigma = LT_SBIG;
+    return SIGK_DONE;
+  }
+  if (D1D2 >= 0.0) {
+    if (D1D2 == 0.0) return SIGK_DONE;
+    double a = fabs(D1), b = fabs(D2);
+    double big = (a > b) ? a : b, small = (a > b) ? b : a;
+    if (big <= 2.0 * small) return SIGK_DONE;
+    T = (a > b) ? D1 / D2 : D2 / D1;
+    if (T <= 2.0) return SIGK_DONE;
+    return SIGK_NEWTON;
+  }
+  if (S1 * S < 0.0 || S2 * S < 0.0) return SIGK_DONE;
+  double T0 = 3.0 * S - S1 - S2;
+  double D0 = T0 * T0 - S1 * S2;
+  if (D0 <= 0.0 || S * T0 >= 0.0) return SIGK_DONE;
+  return SIGK_SECANT;
+}
+
+// convexity Newton iteration, tension_module.f90:531-580.  Returns the tension
+// factor; failed = true when the iteration count exceeds 10000 (SigErr).
+LT_DEV double sigs_newton(double T, bool& failed) {
+  const double SBIG = LT_SBIG, RTOL = LT_SIGS_RTOL, FTOL = 0.0;
+  double TP1 = T + 1.0;
+  double SIG = sqrt(10.0 * T - 20.0);
+  int NIT = 0;
+  failed = false;
+  for (;;) {
+    double T1, FP;
+    if (SIG <= .5) {
+      double SINHM, COSHM, COSHMM;
+      snhcsh(SIG, SINHM, COSHM, COSHMM);
+      T1 = COSHM / SINHM;
+      FP = T1 + SIG * (SIG / SINHM - T1 * T1 + 1.0);
+    } else {
+      double EMS = exp(-SIG);
+      double SSM = 1.0 - EMS * (EMS + SIG + SIG);
+      T1 = (1.0 - EMS) * (1.0 - EMS) / SSM;
+      FP = T1 + SIG * (2.0 * SIG * EMS / SSM - T1 * T1 + 1.0);
+    }
+    double F = SIG * T1 - TP1;
+    NIT = NIT + 1;
+    if (NIT > 10000) {
+      failed = true;
+      return 0.0;
+    }
+    if (FP <= 0.0) break;
+    double DSIG = -F / FP;
+    if (fabs(DSIG) <= RTOL * SIG || (F >= 0.0 && F <= FTOL) || fabs(F) <= RTOL) break;
+    SIG = SIG + DSIG;
+  }
+  SIG = dmin(SIG, SBIG);
+  return (SIG > 0.0) ? SIG : 0.0;
+}
+
+// monotonicity secant iteration, tension_module.f90:638-760 (out of line: rare)
+__device__ __noinline__ double sigs_secant(double S, double S1, double S2) {
+  const double SBIG = LT_SBIG, RTOL = LT_SIGS_RTOL, FTOL = 0.0;
+  double D1 = S - S1;
+  double D2 = S2 - S;
+  double T0 = 3.0 * S - S1 - S2;
+  double D0 = T0 * T0 - S1 * S2;
+  double SGN = fsign1(S);
+  double SIG = SBIG;
+  double FMAX = SGN * (SIG * S - S1 - S2) / (SIG - 2.0);
+  if (FMAX <= 0.0) return SBIG;
+  double STOL = RTOL * SIG;
+  double F = FMAX;
+  double F0 = SGN * D0 / (3.0 * (D1 - D2));
+  double FNEG = F0;
+  double DSIG = SIG;
+  double DMAX = SIG;
+  double D1PD2 = D1 + D2;
+  double A = 0.0, E = 0.0, C1, C2;
+  for (;;) {
+    DSIG = -F * DSIG / (F - F0);
+    if (fabs(DSIG) > fabs(DMAX) || DSIG * DMAX > 0.) {
+      DSIG = DMAX;
+      F0 = FNEG;
+      continue;
+    }
+    if (fabs(DSIG) < STOL / 2.0) DSIG = -copysign(STOL / 2.0, DMAX);
+    SIG = SIG + DSIG;
+    F0 = F;
+    bool CONT = true;
+    if (SIG <= .5) {
+      double SINHM, COSHM, COSHMM;
+      snhcsh(SIG, SINHM, COSHM, COSHMM);
+      C1 = SIG * COSHM * D2 - SINHM * D1PD2;
+      C2 = SIG * (SINHM + SIG) * D2 - COSHM * D1PD2;
+      A = C2 - C1;
+      E = SIG * SINHM - COSHMM - COSHMM;
+    } else {
+      double EMS = exp(-SIG);
+      double EMS2 = EMS + EMS;
+      double TM = 1.0 - EMS;
+      double SSINH = TM * (1.0 + EMS);
+      double SSM = SSINH - SIG * EMS2;
+      double SCM = TM * TM;
+      C1 = SIG * SCM * D2 - SSM * D1PD2;
+      C2 = SIG * SSINH * D2 - SCM * D1PD2;
+      F = FMAX;
+      if (C1 * (SIG * SCM * D1 - SSM * D1PD2) >= 0.0) CONT = false;
+      if (CONT) A = EMS2 * (SIG * TM * D2 + (TM - SIG) * D1PD2);
+      if (A * (C2 + C1) < 0.0) CONT = false;
+      if (CONT) E = SIG * SSINH - SCM - SCM;
+    }
+    if (CONT) F = (SGN * (E * S2 - C2) + sqrt(A * (C2 + C1))) / E;
+    STOL = RTOL * SIG;
+    if (fabs(DMAX) <= STOL || (F >= 0.0 && F <= FTOL) || fabs(F) <= RTOL) break;
+    DMAX = DMAX + DSIG;
+    if (F0 * F > 0.0 && fabs(F) >= fabs(F0)) {
+      DSIG = DMAX;
+      F0 = FNEG;
+      continue;
+    }
+    if (F0 * F <= 0.0) {
+      double T1 = DMAX, T2 = FNEG;
+      DMAX = DSIG;
+      FNEG = F0;
+      if (fabs(DSIG) > fabs(T1) && fabs(F) < fabs(T2)) {
+        DSIG = T1;
+        F0 = T2;
+      }
+    }
+  }
+  SIG = dmin(SIG, SBIG);
+  return (SIG > 0.0) ? SIG : 0.0;
+}
+
+// HVAL on one interval with the chord slope S = (Y2-Y1)/DX supplied by the
+// caller (same expression as tension_module.f90:1074).
+LT_DEV double hval_interval_s(double T, double X1, double X2, double Y1, double YP1, double YP2,
+                              double S, double SIGMA) {
+  double DX = X2 - X1;
+  double U = T - X1;
+  double B2 = U / DX;
+  double B1 = 1.0 - B2;
+  double S1 = YP1;
+  double D1 = S - S1;
+  double D2 = YP2 - S;
+  double SIG = fabs(SIGMA);
+  if (SIG < 1.e-9) {
+    return Y1 + U * (S1 + B2 * (D1 + B1 * (D1 - D2)));
+  } else if (SIG <= .5) {
+    double SB2 = SIG * B2, SM, CM, CMM, SM2, CM2, DUMMY;
+    snhcsh(SIG, SM, CM, CMM);
+    snhcsh(SB2, SM2, CM2, DUMMY);
+    double E = SIG * SM - CMM - CMM;
+    return Y1 + S1 * U +
+           DX * ((CM * SM2 - SM * CM2) * (D1 + D2) + SIG * (CM * CM2 - (SM + SIG) * SM2) * D1) /
+               (SIG * E);
+  } else {
+    double SB1 = SIG * B1;
+    double SB2 = SIG - SB1;
+    if (-SB1 > LT_SBIG || -SB2 > LT_SBIG) return Y1 + S * U;
+    double E1 = exp(-SB1), E2 = exp(-SB2);
+    double EMS = E1 * E2;
+    double TM = 1.0 - EMS;
+    double TS = TM * TM;
+    double TP = 1.0 + EMS;
+    double E = TM * (SIG * TP - TM - TM);
+    return Y1 + S * U +
+           DX * (TM * (TP - E1 - E2) * (D1 + D2) +
+                 SIG * ((E2 + EMS * (E1 - 2.0) - B1 * TS) * D1 +
+                        (E1 + EMS * (E2 - 2.0) - B2 * TS) * D2)) /
+               (SIG * E);
+  }
+}
+
 // ------------------------------------------------------------ GRIDCELL_MOD
 // gridcell for ONE element (checkele form), gridcell_module.f90:26-257.
 // qx/qy: the four corners in element order.  Returns true when the reference
