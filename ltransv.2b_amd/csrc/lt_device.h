@@ -96,6 +96,9 @@ struct StepParams {
   const int* elepolys_ptr; const int* elepolys_ids;
   const int* polyholes_ptr; const int* polyholes_ids;
   int minpolyid, minholeid;
+  // ---- per-step workspace exchanged between k_pre / k_rk / k_post
+  double* ws_d;   // [WS_NDOUBLE][numpar]
+  int* ws_i;      // [numpar] flags | err << 8
   // ---- counters
   unsigned long long* counters;
 };

@@ -15,6 +15,9 @@
 #include <vector>
 
 #include "../../include/ltrans_hip.h"
+#ifndef LT_RK_WAVES
+#define LT_RK_WAVES 1
+#endif
 #include "lt_kernels.h"
 
 using namespace ltd;
@@ -56,6 +59,11 @@ struct lt_engine {
   lt_habitat hab{};
   int npoly = 0, nhole = 0;
   // particles
+  DevBuf ws_d, ws_i, orig;
+  // internal particle order: slot i of every device array holds the reference's
+  // particle perm[i] (0-based); sorted by rho element for memory locality
+  std::vector<int> perm;
+  bool sort_particles = true;
   DevBuf par, pr, pu, pv, P_behave, dead, oob, settle, endpoly, hitBottom, hitLand, err_code,
       P_swim, P_pediage, P_deadage, settletime;
   // rng (host copy of the state; turbulence kernels are not part of this build yet)
@@ -195,6 +203,8 @@ void fill_params(lt_engine* e, StepParams& P) {
   P.elepolys_ptr = (const int*)e->ep_ptr.p; P.elepolys_ids = (const int*)e->ep_ids.p;
   P.polyholes_ptr = (const int*)e->ph_ptr.p; P.polyholes_ids = (const int*)e->ph_ids.p;
   P.minpolyid = e->hab.minpolyid; P.minholeid = e->hab.minholeid;
+  P.ws_d = (double*)e->ws_d.p;
+  P.ws_i = (int*)e->ws_i.p;
   P.counters = (unsigned long long*)e->counters.p;
 }
 
@@ -302,6 +312,46 @@ int set_slab_t(lt_engine* e, int slot, const lt_slab* s) {
   return LT_OK;
 }
 
+// upload one per-particle array (cols columns, column-major) in the engine's
+// internal order: dst[c*n + i] = src[c*n + perm[i]]
+template <typename T>
+int put_field(lt_engine* e, DevBuf& buf, const T* src, int cols) {
+  const size_t n = (size_t)e->cfg.numpar;
+  const size_t bytes = n * cols * sizeof(T);
+  if (src) {
+    std::vector<T> tmp(n * cols);
+    const int* pm = e->perm.data();
+    for (int c = 0; c < cols; c++) {
+      const T* s = src + (size_t)c * n;
+      T* d = tmp.data() + (size_t)c * n;
+      for (size_t i = 0; i < n; i++) d[i] = s[pm[i]];
+    }
+    TRY(dev_alloc(e, buf, bytes));
+    if (bytes) HIPCHK(e, hipMemcpyAsync(buf.p, tmp.data(), bytes, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));  // tmp goes out of scope
+  } else if (!buf.p) {
+    TRY(dev_alloc(e, buf, bytes));
+    HIPCHK(e, hipMemsetAsync(buf.p, 0, buf.bytes, e->stream));
+  }
+  return LT_OK;
+}
+
+template <typename T>
+int get_field(lt_engine* e, const DevBuf& buf, T* dst, int cols) {
+  if (!dst || !buf.p) return LT_OK;
+  const size_t n = (size_t)e->cfg.numpar;
+  std::vector<T> tmp(n * cols);
+  HIPCHK(e, hipMemcpyAsync(tmp.data(), buf.p, n * cols * sizeof(T), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  const int* pm = e->perm.data();
+  for (int c = 0; c < cols; c++) {
+    const T* s = tmp.data() + (size_t)c * n;
+    T* d = dst + (size_t)c * n;
+    for (size_t i = 0; i < n; i++) d[pm[i]] = s[i];
+  }
+  return LT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -349,6 +399,8 @@ int lt_create(const lt_config* cfg, lt_engine** out) {
   e->counters.bytes = CNT_COUNT * sizeof(unsigned long long);
   e->flags.bytes = 16;
   (void)hipMemsetAsync(e->flags.p, 0, 16, e->stream);
+  const char* envs = getenv("LT_NO_SORT");
+  if (envs && atoi(envs) != 0) e->sort_particles = false;
   const char* env = getenv("LT_BRUTE_BOUNDS");
   if (env && atoi(env) != 0) { e->use_seg_index = 0; e->use_pip_index = 0; }
   // init_genrand(seed), random_module.f90:108-119 / LTRANS.f90:241
@@ -371,7 +423,7 @@ int lt_destroy(lt_engine* e) {
                     &e->ep_ptr, &e->ep_ids, &e->ph_ptr, &e->ph_ids, &e->par, &e->pr, &e->pu,
                     &e->pv, &e->P_behave, &e->dead, &e->oob, &e->settle, &e->endpoly,
                     &e->hitBottom, &e->hitLand, &e->err_code, &e->P_swim, &e->P_pediage,
-                    &e->P_deadage, &e->settletime, &e->counters};
+                    &e->P_deadage, &e->settletime, &e->counters, &e->ws_d, &e->ws_i, &e->orig};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
@@ -518,17 +570,6 @@ int lt_set_habitat(lt_engine* e, const lt_habitat* h) {
   return LT_OK;
 }
 
-#define PUP(buf, field, count, elem)                                                \
-  do {                                                                              \
-    size_t _bytes = (size_t)(count) * (elem);                                       \
-    if (p->field) {                                                                 \
-      TRY(upload(e, e->buf, p->field, _bytes));                                     \
-    } else if (!e->buf.p) {                                                         \
-      TRY(dev_alloc(e, e->buf, _bytes));                                            \
-      HIPCHK(e, hipMemsetAsync(e->buf.p, 0, e->buf.bytes, e->stream));              \
-    }                                                                               \
-  } while (0)
-
 int lt_set_particles(lt_engine* e, const lt_particles* p) {
   if (!e || !p) return LT_ERR_ARG;
   if (!e->have_grid) return fail(e, LT_ERR_STATE, "lt_set_particles before lt_set_grid");
@@ -540,36 +581,61 @@ int lt_set_particles(lt_engine* e, const lt_particles* p) {
   if (p->P_v_element) TRY(check_particle_elements(e, p->P_v_element, (int)n, e->v_elements, "P_v_element"));
   if (!e->pr.p && !(p->P_r_element && p->P_u_element && p->P_v_element))
     return fail(e, LT_ERR_ARG, "lt_set_particles: element ids are required on first upload");
-  PUP(par, par, 13 * n, 8);
-  PUP(pr, P_r_element, n, 4); PUP(pu, P_u_element, n, 4); PUP(pv, P_v_element, n, 4);
-  PUP(P_behave, P_behave, n, 4); PUP(dead, dead, n, 4); PUP(oob, oob, n, 4);
-  PUP(P_swim, P_swim, 3 * n, 8); PUP(P_pediage, P_pediage, n, 8); PUP(P_deadage, P_deadage, n, 8);
-  PUP(settle, settle, n, 4); PUP(settletime, settletime, n, 8); PUP(endpoly, endpoly, n, 4);
-  PUP(hitBottom, hitBottom, n, 4); PUP(hitLand, hitLand, n, 4); PUP(err_code, err_code, n, 4);
+  if (e->perm.size() != n) {
+    // first upload: choose the internal order.  Particles of one rho element are
+    // made neighbours (stable, so equal keys keep the reference order): the lanes
+    // of a wave then gather from the same few cache lines of the slabs.
+    e->perm.resize(n);
+    for (size_t i = 0; i < n; i++) e->perm[i] = (int)i;
+    if (e->sort_particles && p->P_r_element) {
+      const int32_t* key = p->P_r_element;
+      std::stable_sort(e->perm.begin(), e->perm.end(), [key](int a, int b) { return key[a] < key[b]; });
+    }
+    TRY(upload(e, e->orig, e->perm.data(), n * 4));
+    TRY(dev_alloc(e, e->ws_d, (size_t)WS_NDOUBLE * n * 8));
+    TRY(dev_alloc(e, e->ws_i, n * 4));
+  }
+  TRY(put_field<double>(e, e->par, p->par, 13));
+  TRY(put_field<int32_t>(e, e->pr, p->P_r_element, 1));
+  TRY(put_field<int32_t>(e, e->pu, p->P_u_element, 1));
+  TRY(put_field<int32_t>(e, e->pv, p->P_v_element, 1));
+  TRY(put_field<int32_t>(e, e->P_behave, p->P_behave, 1));
+  TRY(put_field<int32_t>(e, e->dead, p->dead, 1));
+  TRY(put_field<int32_t>(e, e->oob, p->oob, 1));
+  TRY(put_field<double>(e, e->P_swim, p->P_swim, 3));
+  TRY(put_field<double>(e, e->P_pediage, p->P_pediage, 1));
+  TRY(put_field<double>(e, e->P_deadage, p->P_deadage, 1));
+  TRY(put_field<int32_t>(e, e->settle, p->settle, 1));
+  TRY(put_field<double>(e, e->settletime, p->settletime, 1));
+  TRY(put_field<int32_t>(e, e->endpoly, p->endpoly, 1));
+  TRY(put_field<int32_t>(e, e->hitBottom, p->hitBottom, 1));
+  TRY(put_field<int32_t>(e, e->hitLand, p->hitLand, 1));
+  TRY(put_field<int32_t>(e, e->err_code, p->err_code, 1));
   HIPCHK(e, hipStreamSynchronize(e->stream));
   e->have_particles = true;
   return LT_OK;
 }
 
-#define PDOWN(buf, field, count, elem)                                                          \
-  do {                                                                                          \
-    if (out->field && e->buf.p)                                                                 \
-      HIPCHK(e, hipMemcpyAsync(out->field, e->buf.p, (size_t)(count) * (elem),                  \
-                               hipMemcpyDeviceToHost, e->stream));                              \
-  } while (0)
-
 int lt_get_particles(lt_engine* e, lt_particles* out) {
   if (!e || !out) return LT_ERR_ARG;
   if (!e->have_particles) return fail(e, LT_ERR_STATE, "no particles uploaded");
   HIPCHK(e, hipSetDevice(e->device));
-  const size_t n = (size_t)e->cfg.numpar;
-  PDOWN(par, par, 13 * n, 8);
-  PDOWN(pr, P_r_element, n, 4); PDOWN(pu, P_u_element, n, 4); PDOWN(pv, P_v_element, n, 4);
-  PDOWN(P_behave, P_behave, n, 4); PDOWN(dead, dead, n, 4); PDOWN(oob, oob, n, 4);
-  PDOWN(P_swim, P_swim, 3 * n, 8); PDOWN(P_pediage, P_pediage, n, 8); PDOWN(P_deadage, P_deadage, n, 8);
-  PDOWN(settle, settle, n, 4); PDOWN(settletime, settletime, n, 8); PDOWN(endpoly, endpoly, n, 4);
-  PDOWN(hitBottom, hitBottom, n, 4); PDOWN(hitLand, hitLand, n, 4); PDOWN(err_code, err_code, n, 4);
-  HIPCHK(e, hipStreamSynchronize(e->stream));
+  TRY(get_field<double>(e, e->par, out->par, 13));
+  TRY(get_field<int32_t>(e, e->pr, out->P_r_element, 1));
+  TRY(get_field<int32_t>(e, e->pu, out->P_u_element, 1));
+  TRY(get_field<int32_t>(e, e->pv, out->P_v_element, 1));
+  TRY(get_field<int32_t>(e, e->P_behave, out->P_behave, 1));
+  TRY(get_field<int32_t>(e, e->dead, out->dead, 1));
+  TRY(get_field<int32_t>(e, e->oob, out->oob, 1));
+  TRY(get_field<double>(e, e->P_swim, out->P_swim, 3));
+  TRY(get_field<double>(e, e->P_pediage, out->P_pediage, 1));
+  TRY(get_field<double>(e, e->P_deadage, out->P_deadage, 1));
+  TRY(get_field<int32_t>(e, e->settle, out->settle, 1));
+  TRY(get_field<double>(e, e->settletime, out->settletime, 1));
+  TRY(get_field<int32_t>(e, e->endpoly, out->endpoly, 1));
+  TRY(get_field<int32_t>(e, e->hitBottom, out->hitBottom, 1));
+  TRY(get_field<int32_t>(e, e->hitLand, out->hitLand, 1));
+  TRY(get_field<int32_t>(e, e->err_code, out->err_code, 1));
   return LT_OK;
 }
 
@@ -654,16 +720,18 @@ int lt_step(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32
   unsigned blocks = (unsigned)((e->cfg.numpar + 255) / 256);
   if (blocks) {
     const bool prof = e->prof_on && e->prof_used + 2 <= e->prof_ev.size();
+    const bool f32 = e->cfg.slab_storage == LT_SLAB_F32;
+    if (f32) hipLaunchKernelGGL((k_pre<float>), dim3(blocks), dim3(256), 0, e->stream, P);
+    else hipLaunchKernelGGL((k_pre<double>), dim3(blocks), dim3(256), 0, e->stream, P);
     if (prof) HIPCHK(e, hipEventRecord(e->prof_ev[e->prof_used], e->stream));
-    if (e->cfg.slab_storage == LT_SLAB_F32)
-      hipLaunchKernelGGL((k_step<float>), dim3(blocks), dim3(256), 0, e->stream, P);
-    else
-      hipLaunchKernelGGL((k_step<double>), dim3(blocks), dim3(256), 0, e->stream, P);
-    HIPCHK(e, hipGetLastError());
+    if (f32) hipLaunchKernelGGL((k_rk<float, LT_RK_WAVES>), dim3(blocks), dim3(256), 0, e->stream, P);
+    else hipLaunchKernelGGL((k_rk<double, LT_RK_WAVES>), dim3(blocks), dim3(256), 0, e->stream, P);
     if (prof) {
       HIPCHK(e, hipEventRecord(e->prof_ev[e->prof_used + 1], e->stream));
       e->prof_used += 2;
     }
+    hipLaunchKernelGGL(k_post, dim3(blocks), dim3(256), 0, e->stream, P);
+    HIPCHK(e, hipGetLastError());
   }
   HIPCHK(e, hipMemcpyAsync(e->h_counters, e->counters.p, CNT_COUNT * sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, e->stream));
@@ -737,9 +805,12 @@ int lt_pack_positions(lt_engine* e, void* dst_device) {
   if (!e || !dst_device) return LT_ERR_ARG;
   if (!e->have_particles) return fail(e, LT_ERR_STATE, "no particles uploaded");
   HIPCHK(e, hipSetDevice(e->device));
-  // par(:,1:3) is contiguous in the column-major array
-  HIPCHK(e, hipMemcpyAsync(dst_device, e->par.p, (size_t)e->cfg.numpar * 3 * 8,
-                           hipMemcpyDeviceToDevice, e->stream));
+  unsigned blocks = (unsigned)(((size_t)e->cfg.numpar + 255) / 256);
+  if (blocks)
+    hipLaunchKernelGGL(k_pack_positions, dim3(blocks), dim3(256), 0, e->stream,
+                       (const double*)e->par.p, (const int*)e->orig.p, (double*)dst_device,
+                       e->cfg.numpar);
+  HIPCHK(e, hipGetLastError());
   return LT_OK;
 }
 

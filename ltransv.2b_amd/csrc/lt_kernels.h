@@ -592,7 +592,9 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
       }
     }
     // ---------------- pass A: fit without iterating, queue Newton tasks
-    SlotFit fit[3];
+    SlotFit fit0, fit1, fit2;
+    fit0.x1 = fit0.x2 = fit0.y1 = fit0.p1 = fit0.p2 = fit0.S = fit0.sig = 0.0; fit0.pend = -1;
+    fit1 = fit0; fit2 = fit0;
     LevCoef lc[4];
     unsigned slowmask = 0;
     int ntask = 0;  // wave-uniform
@@ -611,14 +613,18 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
 #pragma unroll
       for (int j = 0; j < 12; j++) { f[0][j] = b0[j]; f[1][j] = b1[j]; f[2][j] = b2[j]; f[3][j] = b3[j]; }
     }
-#pragma unroll
+#pragma unroll 1
     for (int s = 0; s < 3; s++) {
       const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
       double X[4], Y[4], YP[4], SL[3];
       int I = 1;
       bool ok = spl;
+      SlotFit cur;
+      cur.x1 = cur.x2 = cur.y1 = cur.p1 = cur.p2 = cur.S = cur.sig = 0.0;
+      cur.pend = -1;
       if (spl) {
-        const double zeta = C.zeta[s], Pzs = C.Pz[s];
+        const double zeta = (s == 0) ? C.zeta[0] : (s == 1) ? C.zeta[1] : C.zeta[2];
+        const double Pzs = (s == 0) ? C.Pz[0] : (s == 1) ? C.Pz[1] : C.Pz[2];
 #pragma unroll
         for (int l = 0; l < 4; l++) {
           X[l] = level_at(lc[l], zeta, C.h, P.Vtransform);
@@ -641,15 +647,13 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
         YP[3] = ypc1_end(SL[2], SL[2] + DX3 * (SL[2] - SL[1]) / (DX2 + DX3));
         I = (Pzs < X[1]) ? 1 : (Pzs < X[2]) ? 2 : 3;
         if (Pzs > X[3]) I = 3;
-        fit[s].x1 = (I == 1) ? X[0] : (I == 2) ? X[1] : X[2];
-        fit[s].x2 = (I == 1) ? X[1] : (I == 2) ? X[2] : X[3];
-        fit[s].y1 = (I == 1) ? Y[0] : (I == 2) ? Y[1] : Y[2];
-        fit[s].p1 = (I == 1) ? YP[0] : (I == 2) ? YP[1] : YP[2];
-        fit[s].p2 = (I == 1) ? YP[1] : (I == 2) ? YP[2] : YP[3];
-        fit[s].S = (I == 1) ? SL[0] : (I == 2) ? SL[1] : SL[2];
+        cur.x1 = (I == 1) ? X[0] : (I == 2) ? X[1] : X[2];
+        cur.x2 = (I == 1) ? X[1] : (I == 2) ? X[2] : X[3];
+        cur.y1 = (I == 1) ? Y[0] : (I == 2) ? Y[1] : Y[2];
+        cur.p1 = (I == 1) ? YP[0] : (I == 2) ? YP[1] : YP[2];
+        cur.p2 = (I == 1) ? YP[1] : (I == 2) ? YP[2] : YP[3];
+        cur.S = (I == 1) ? SL[0] : (I == 2) ? SL[1] : SL[2];
       }
-      fit[s].sig = 0.0;
-      fit[s].pend = -1;
       // SIGS: classify the three intervals (tension_module.f90:448-776)
 #pragma unroll
       for (int iv = 0; iv < 3; iv++) {
@@ -668,10 +672,11 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
         }
         ntask += __popcll(m);
         if (ok && iv + 1 == I) {
-          fit[s].sig = sigma;
-          fit[s].pend = need ? idx : -1;
+          cur.sig = sigma;
+          cur.pend = need ? idx : -1;
         }
       }
+      if (s == 0) fit0 = cur; else if (s == 1) fit1 = cur; else fit2 = cur;
     }
     // ---------------- pass B: the queued Newton iterations, 64 at a time
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -695,21 +700,23 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
       const unsigned em = ws.errmask[lane];
       slowmask |= em;
       if (em) sigerr_count += __popc(em);
-#pragma unroll
+#pragma unroll 1
       for (int s = 0; s < 3; s++) {
         double r;
+        const double zeta = (s == 0) ? C.zeta[0] : (s == 1) ? C.zeta[1] : C.zeta[2];
+        const double Pzs = (s == 0) ? C.Pz[0] : (s == 1) ? C.Pz[1] : C.Pz[2];
         if (slowmask & (1u << s)) {
           const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
           r = slot_slow<SlabT>(F, nd.x, nd.y, nd.z, nd.w, L, k0, ps, w.regime, w.node_hit, w.t,
                                w.u, w.W1, w.W2, w.W3, w.W4,
-                               level_at(lc[0], C.zeta[s], C.h, P.Vtransform),
-                               level_at(lc[1], C.zeta[s], C.h, P.Vtransform),
-                               level_at(lc[2], C.zeta[s], C.h, P.Vtransform),
-                               level_at(lc[3], C.zeta[s], C.h, P.Vtransform), C.Pz[s]);
+                               level_at(lc[0], zeta, C.h, P.Vtransform),
+                               level_at(lc[1], zeta, C.h, P.Vtransform),
+                               level_at(lc[2], zeta, C.h, P.Vtransform),
+                               level_at(lc[3], zeta, C.h, P.Vtransform), Pzs);
         } else {
-          double sg = (fit[s].pend >= 0) ? ws.task[fit[s].pend] : fit[s].sig;
-          r = hval_interval_s(C.Pz[s], fit[s].x1, fit[s].x2, fit[s].y1, fit[s].p1, fit[s].p2,
-                              fit[s].S, sg);
+          const SlotFit ft = (s == 0) ? fit0 : (s == 1) ? fit1 : fit2;
+          double sg = (ft.pend >= 0) ? ws.task[ft.pend] : ft.sig;
+          r = hval_interval_s(Pzs, ft.x1, ft.x2, ft.y1, ft.p1, ft.p2, ft.S, sg);
         }
         if (s == 0) Pv0 = r; else if (s == 1) Pv1 = r; else Pv2 = r;
       }
@@ -727,44 +734,37 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
 }
 
 // ------------------------------------------------------------ the step
+// update_particles() is run as three kernels over the same particle index so
+// that the register-hungry RK4 part does not carry the state of the element
+// search and boundary code (occupancy), exchanging 13 doubles + one flag word
+// per particle through a workspace in HBM (SoA, stride numpar):
+//   k_pre   gates, setEle, setInterp/getInterp, vertical clamps   (per lane)
+//   k_rk    RK4 over find_currents/WCTS_ITPI                      (wave-cooperative)
+//   k_post  behaviour, reflection, boundaries, setEle, settlement, commit
+enum { WS_PDEPTH = 0, WS_COSA, WS_SINA, WS_ZETA0, WS_ZETA1, WS_ZETA2, WS_PZ0, WS_PZ1, WS_PZ2,
+       WS_ZPAR, WS_SUMU, WS_SUMV, WS_SUMW, WS_NDOUBLE };
+enum { FL_ACT = 1, FL_KEEP_PN = 2, FL_ERR_SHIFT = 8 };
+
 template <typename SlabT>
-__global__ __launch_bounds__(256) void k_step(const StepParams P) {
+__global__ __launch_bounds__(256) void k_pre(const StepParams P) {
   __shared__ double lev[6 * LT_LEV_STRIDE];
-  __shared__ WaveScratch wsc[4];
   for (int i = threadIdx.x; i < 6 * LT_LEV_STRIDE; i += blockDim.x) lev[i] = P.lev[i];
   __syncthreads();
-
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool inrange = n < P.numpar;
-  const size_t N = (size_t)P.numpar;
-  double* par = P.par + (inrange ? n : 0);
+  unsigned c_active = 0;
+  if (n < P.numpar) {
+    const size_t N = (size_t)P.numpar;
+    double* par = P.par + n;
+    double* wsd = P.ws_d + n;
 #define PARV(k) par[(size_t)(k) * N]
-  unsigned c_active = 0, c_err = 0, c_brute = 0, c_pipslow = 0;
-  int sigerr_count = 0;
-
-  // per-particle state that lives across the sections
-  double X = 0.0, Y = 0.0, Z = 0.0, nX = 0.0, nY = 0.0, nZ = 0.0, age = 0.0, lifespan = 0.0;
-  double P_depth = 0.0, P_zetac = 0.0, cosA = 1.0, sinA = 0.0, Zpar = 0.0;
-  double maxpartdepth = 0.0, minpartdepth = 0.0;
-  bool keep_pn = false, ele_dirty = false, set_lifespan = false;
-  bool act = false;  // tracked this step and no error so far
-  int err = 0, er = 1, eu = 1, ev = 1;
-  int4 rn = make_int4(1, 1, 1, 1), un = rn, vn = rn;
-  Column C;
-  C.h = 1.0;
-#pragma unroll
-  for (int s = 0; s < 3; s++) { C.zeta[s] = 0.0; C.Pz[s] = 0.0; C.wz1[s] = 0.0; C.z1[s] = 0.0; }
-
-  // ---- section 1: gates, element search, water column (per lane)
-  if (inrange) {
-    X = PARV(pX); Y = PARV(pY); Z = PARV(pZ);
-    nX = X; nY = Y; nZ = Z;
-    er = P.P_r_element[n]; eu = P.P_u_element[n]; ev = P.P_v_element[n];
+    const double X = PARV(pX), Y = PARV(pY);
+    double Z = PARV(pZ);
+    int flags = 0, err = 0;
     // the gates of LTRANS.f90:790-816
     const bool released = !(P.ix2 <= PARV(pDOB));
     bool track = released;
     if (released) {
-      age = PARV(pAge) + (double)(float)P.idt;
+      double age = PARV(pAge) + (double)(float)P.idt;
       PARV(pAge) = age;
       // updateStatus, behavior_module.f90:162-179
       bool settled = P.settlementon ? (P.settle[n] != 0) : false;
@@ -774,24 +774,26 @@ __global__ __launch_bounds__(256) void k_step(const StepParams P) {
       if (P.settlementon && settled) track = false;
       if (track && P.mortality && P.dead[n] != 0) track = false;
       if (track && P.OpenOceanBoundary && P.oob[n] != 0) track = false;
-      if (!track) keep_pn = true;
+      if (!track) flags |= FL_KEEP_PN;
     }
     if (track) {
+      int er = P.P_r_element[n], eu = P.P_u_element[n], ev = P.P_v_element[n];
+      int4 rn, un, vn;
       // setEle :830 (all three grids are searched even after a miss)
       bool okr = find_element<true>(P.rnode, P.RE, P.rAdj, X, Y, er, rn);
       bool oku = find_element<false>(P.unode, P.UE, P.uAdj, X, Y, eu, un);
       bool okv = find_element<false>(P.vnode, P.VE, P.vAdj, X, Y, ev, vn);
-      ele_dirty = true;
+      P.P_r_element[n] = er; P.P_u_element[n] = eu; P.P_v_element[n] = ev;
       if (!okv) err = 6; else if (!oku) err = 5; else if (!okr) err = 4;  // last assignment wins
       if (err == 0) {
-        act = true;
+        flags |= FL_ACT;
         c_active = 1;
         // setInterp + getInterp :882-896
         RhoNode r1 = P.rnode[rn.x - 1], r2 = P.rnode[rn.y - 1], r3 = P.rnode[rn.z - 1],
                 r4 = P.rnode[rn.w - 1];
         double qx[4] = {r1.x, r2.x, r3.x, r4.x}, qy[4] = {r1.y, r2.y, r3.y, r4.y};
         const QuadWeights w0 = quad_weights(X, Y, qx, qy);
-        P_depth = -1.0 * apply_getinterp(w0, r1.depth, r2.depth, r3.depth, r4.depth);
+        const double P_depth = -1.0 * apply_getinterp(w0, r1.depth, r2.depth, r3.depth, r4.depth);
         const double P_angle = apply_getinterp(w0, r1.angle, r2.angle, r3.angle, r4.angle);
         using Z4 = typename SlabTraits<SlabT>::zeta4;
         const Z4* zt = (const Z4*)P.zeta;
@@ -799,198 +801,267 @@ __global__ __launch_bounds__(256) void k_step(const StepParams P) {
         auto pick = [](const Z4& v, int s) -> double {
           return (double)((s == 0) ? v.x : (s == 1) ? v.y : v.z);
         };
-        C.zeta[0] = apply_getinterp(w0, pick(z1, P.tb), pick(z2, P.tb), pick(z3, P.tb), pick(z4, P.tb));
-        C.zeta[1] = apply_getinterp(w0, pick(z1, P.tc), pick(z2, P.tc), pick(z3, P.tc), pick(z4, P.tc));
-        C.zeta[2] = apply_getinterp(w0, pick(z1, P.tf), pick(z2, P.tf), pick(z3, P.tf), pick(z4, P.tf));
-        P_zetac = C.zeta[1];
+        double zeta[3], Pz[3];
+        zeta[0] = apply_getinterp(w0, pick(z1, P.tb), pick(z2, P.tb), pick(z3, P.tb), pick(z4, P.tb));
+        zeta[1] = apply_getinterp(w0, pick(z1, P.tc), pick(z2, P.tc), pick(z3, P.tc), pick(z4, P.tc));
+        zeta[2] = apply_getinterp(w0, pick(z1, P.tf), pick(z2, P.tf), pick(z3, P.tf), pick(z4, P.tf));
         // vertical clamps :900-922
         if (Z < P_depth) {
           Z = P_depth + (double)0.001f;
           if (P.TrackCollisions) P.hitBottom[n] += 1;
         }
-        C.Pz[0] = C.Pz[1] = C.Pz[2] = Z;
-        if (Z > C.zeta[0]) C.Pz[0] = C.zeta[0] - (double)0.001f;
-        if (Z > C.zeta[1]) C.Pz[1] = C.zeta[1] - (double)0.001f;
-        if (Z > C.zeta[2]) C.Pz[2] = C.zeta[2] - (double)0.001f;
-        Zpar = polintd3(P.ex0, P.ex1, P.ex2, C.Pz[0], C.Pz[1], C.Pz[2], P.ix1);
-        Z = Zpar;  // par(n,pZ) = Zpar :922
-        C.h = -1.0 * P_depth;
-        const double* rtab = lev;
-        const double* wtab = lev + 3 * LT_LEV_STRIDE;
-        const LevCoef w1 = level_coef(wtab, 1, C.h, P.hc, P.Vtransform);
-        const LevCoef r1c = level_coef(rtab, 1, C.h, P.hc, P.Vtransform);
-        const LevCoef wN = level_coef(wtab, P.ws, C.h, P.hc, P.Vtransform);
+        Pz[0] = Pz[1] = Pz[2] = Z;
+        if (Z > zeta[0]) Pz[0] = zeta[0] - (double)0.001f;
+        if (Z > zeta[1]) Pz[1] = zeta[1] - (double)0.001f;
+        if (Z > zeta[2]) Pz[2] = zeta[2] - (double)0.001f;
+        const double Zpar = polintd3(P.ex0, P.ex1, P.ex2, Pz[0], Pz[1], Pz[2], P.ix1);
+        wsd[(size_t)WS_PDEPTH * N] = P_depth;
+        wsd[(size_t)WS_COSA * N] = cos(P_angle);
+        wsd[(size_t)WS_SINA * N] = sin(P_angle);
+        wsd[(size_t)WS_ZETA0 * N] = zeta[0];
+        wsd[(size_t)WS_ZETA1 * N] = zeta[1];
+        wsd[(size_t)WS_ZETA2 * N] = zeta[2];
+        wsd[(size_t)WS_PZ0 * N] = Pz[0];
+        wsd[(size_t)WS_PZ1 * N] = Pz[1];
+        wsd[(size_t)WS_PZ2 * N] = Pz[2];
+        wsd[(size_t)WS_ZPAR * N] = Zpar;  // = par(n,pZ) after :922
+      }
+    }
+    P.ws_i[n] = flags | (err << FL_ERR_SHIFT);
+#undef PARV
+  }
+  unsigned v = c_active;
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(&P.counters[CNT_ACTIVE], (unsigned long long)v);
+}
+
+template <typename SlabT, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_rk(const StepParams P) {
+  __shared__ double lev[6 * LT_LEV_STRIDE];
+  __shared__ WaveScratch wsc[4];
+  for (int i = threadIdx.x; i < 6 * LT_LEV_STRIDE; i += blockDim.x) lev[i] = P.lev[i];
+  __syncthreads();
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t N = (size_t)P.numpar;
+  const bool act = (n < P.numpar) && ((P.ws_i[n] & FL_ACT) != 0);
+  double X = 0.0, Y = 0.0, Zpar = 0.0, cosA = 1.0, sinA = 0.0, maxpartdepth = 0.0, minpartdepth = 0.0;
+  int4 rn = make_int4(1, 1, 1, 1), un = rn, vn = rn;
+  Column C;
+  C.h = 1.0;
 #pragma unroll
-        for (int s = 0; s < 3; s++) {
-          C.wz1[s] = level_at(w1, C.zeta[s], C.h, P.Vtransform);
-          C.z1[s] = level_at(r1c, C.zeta[s], C.h, P.Vtransform);
-        }
-        double t0 = level_at(wN, C.zeta[0], C.h, P.Vtransform);
-        double t1 = level_at(wN, C.zeta[1], C.h, P.Vtransform);
-        double t2 = level_at(wN, C.zeta[2], C.h, P.Vtransform);
-        maxpartdepth = C.wz1[0];
-        if (C.wz1[1] > maxpartdepth) maxpartdepth = C.wz1[1];
-        if (C.wz1[2] > maxpartdepth) maxpartdepth = C.wz1[2];
-        minpartdepth = t0;
-        if (t1 < minpartdepth) minpartdepth = t1;
-        if (t2 < minpartdepth) minpartdepth = t2;
-        cosA = cos(P_angle);
-        sinA = sin(P_angle);
-      }
-    }
-  }
-
-  // ---- section 2: RK4 :990-1053, executed by the whole wave
-  double sumU = 0.0, sumV = 0.0, sumW = 0.0;
-  {
-    WaveScratch& ws = wsc[threadIdx.x >> 6];
-    double Xs = X, Ys = Y, Zs = Zpar;
-#pragma unroll 1
-    for (int st = 0; st < 4; st++) {
-      const int version = (st == 0) ? 1 : (st == 3) ? 3 : 2;
-      double Uad, Vad, Wad;
-      find_currents<SlabT>(P, lev, ws, act, C, rn, un, vn, Xs, Ys, Zs, version, Uad, Vad, Wad,
-                           sigerr_count);
-      if (st == 0) { sumU = Uad; sumV = Vad; sumW = Wad; }
-      else if (st == 3) { sumU = sumU + Uad; sumV = sumV + Vad; sumW = sumW + Wad; }
-      else { sumU = sumU + 2.0 * Uad; sumV = sumV + 2.0 * Vad; sumW = sumW + 2.0 * Wad; }
-      if (st < 3) {
-        const double dtf = (double)P.idt;
-        if (st < 2) {
-          Xs = X + (Uad * cosA - Vad * sinA) * dtf / 2.0;
-          Ys = Y + (Uad * sinA + Vad * cosA) * dtf / 2.0;
-          Zs = Zpar + Wad * dtf / 2.0;
-        } else {
-          Xs = X + (Uad * cosA - Vad * sinA) * dtf;
-          Ys = Y + (Uad * sinA + Vad * cosA) * dtf;
-          Zs = Zpar + Wad * dtf;
-        }
-        if (Zs > minpartdepth) Zs = minpartdepth - (double)0.000001f;
-        if (Zs < maxpartdepth) Zs = maxpartdepth + (double)0.000001f;
-      }
-    }
-  }
-
-  // ---- section 3: behaviour, reflection, boundaries, re-search, settlement
+  for (int s = 0; s < 3; s++) { C.zeta[s] = 0.0; C.Pz[s] = 0.0; C.wz1[s] = 0.0; C.z1[s] = 0.0; }
   if (act) {
-    const double P_U = sumU / 6.0, P_V = sumV / 6.0, P_W = sumW / 6.0;
-    const double AdvectX = P.idt * (P_U * cosA - P_V * sinA);
-    const double AdvectY = P.idt * (P_U * sinA + P_V * cosA);
-    const double AdvectZ = P.idt * P_W;
-    const double TurbHx = 0.0, TurbHy = 0.0, TurbV = 0.0;
-    // behave (types 0 and 6), behavior_module.f90:181-551
-    double ZBehav = 0.0;
-    if (P.Behavior != 0) {
-      const size_t np = (size_t)P.numpar;
-      double sw3 = P.P_swim[n + 2 * np];
-      bool sw_dirty = false;
-      if (age >= P.swimstart) { sw3 = P.P_swim[n] * age + P.P_swim[n + np]; sw_dirty = true; }
-      if (age >= P.P_pediage[n]) { sw3 = P.swimfast; sw_dirty = true; }
-      if (sw_dirty) P.P_swim[n + 2 * np] = sw3;
-      double parBehav = 0.0;
-      if (P.P_behave[n] == 6) parBehav = (age >= P.swimstart) ? P.sink : sw3;
-      ZBehav = parBehav * P.idt;
+    const double* wsd = P.ws_d + n;
+    X = P.par[(size_t)pX * N + n];
+    Y = P.par[(size_t)pY * N + n];
+    rn = P.RE[P.P_r_element[n] - 1];
+    un = P.UE[P.P_u_element[n] - 1];
+    vn = P.VE[P.P_v_element[n] - 1];
+    C.h = -1.0 * wsd[(size_t)WS_PDEPTH * N];
+    cosA = wsd[(size_t)WS_COSA * N];
+    sinA = wsd[(size_t)WS_SINA * N];
+    C.zeta[0] = wsd[(size_t)WS_ZETA0 * N]; C.zeta[1] = wsd[(size_t)WS_ZETA1 * N]; C.zeta[2] = wsd[(size_t)WS_ZETA2 * N];
+    C.Pz[0] = wsd[(size_t)WS_PZ0 * N]; C.Pz[1] = wsd[(size_t)WS_PZ1 * N]; C.Pz[2] = wsd[(size_t)WS_PZ2 * N];
+    Zpar = wsd[(size_t)WS_ZPAR * N];
+    const double* rtab = lev;
+    const double* wtab = lev + 3 * LT_LEV_STRIDE;
+    const LevCoef w1 = level_coef(wtab, 1, C.h, P.hc, P.Vtransform);
+    const LevCoef r1c = level_coef(rtab, 1, C.h, P.hc, P.Vtransform);
+    const LevCoef wN = level_coef(wtab, P.ws, C.h, P.hc, P.Vtransform);
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+      C.wz1[s] = level_at(w1, C.zeta[s], C.h, P.Vtransform);
+      C.z1[s] = level_at(r1c, C.zeta[s], C.h, P.Vtransform);
     }
-    // new position, vertical reflection :1128-1176
-    double newXpos = X + AdvectX + TurbHx;
-    double newYpos = Y + AdvectY + TurbHy;
-    double newZpos = Z + AdvectZ + TurbV;
-    if (newZpos > P_zetac) {
-      double reflect = P_zetac - newZpos;
-      newZpos = P_zetac + reflect;
-    }
-    if (newZpos < P_depth) {
-      double reflect = P_depth - newZpos;
-      newZpos = P_depth + reflect;
-      if (P.TrackCollisions) P.hitBottom[n] += 1;
-    }
-    newZpos = newZpos + ZBehav;
-    if (newZpos > P_zetac) newZpos = P_zetac - (double)0.000001f;
-    if (newZpos < P_depth) {
-      newZpos = P_depth + (double)0.000001f;
-      if (P.TrackCollisions) P.hitBottom[n] += 1;
-    }
-    // horizontal boundaries :1180-1232
-    double Xpos = X, Ypos = Y, nXpos = newXpos, nYpos = newYpos;
-    int skipbound = -1, reflects = 0;
-    bool done = false;  // waterFlag
-    for (;;) {
-      Hit H;
-      intersect_reflect(P, Xpos, Ypos, nXpos, nYpos, skipbound, H, c_brute);
-      skipbound = H.seg;
-      if (!H.found) break;
-      if (P.TrackCollisions) P.hitLand[n] += 1;
-      if (P.OpenOceanBoundary && H.water) {
-        nX = H.fix; nY = H.fiy; nZ = newZpos;
-        P.oob[n] = 1;
-        done = true;
-        break;
-      }
-      reflects += 1;
-      if (reflects > 3) {
-        err = 24;
-        done = true;
-        break;
-      }
-      Xpos = H.fix; Ypos = H.fiy; nXpos = H.frx; nYpos = H.fry;
-    }
-    if (!done) {
-      newXpos = nXpos;
-      newYpos = nYpos;
-      // mbounds :1240, ibounds :1275
-      bool slow = false, inb;
-      if (P.use_pip_index) {
-        inb = mbounds_indexed(P, newXpos, newYpos, slow);
+    double t0 = level_at(wN, C.zeta[0], C.h, P.Vtransform);
+    double t1 = level_at(wN, C.zeta[1], C.h, P.Vtransform);
+    double t2 = level_at(wN, C.zeta[2], C.h, P.Vtransform);
+    maxpartdepth = C.wz1[0];
+    if (C.wz1[1] > maxpartdepth) maxpartdepth = C.wz1[1];
+    if (C.wz1[2] > maxpartdepth) maxpartdepth = C.wz1[2];
+    minpartdepth = t0;
+    if (t1 < minpartdepth) minpartdepth = t1;
+    if (t2 < minpartdepth) minpartdepth = t2;
+  }
+  // RK4 :990-1053, executed by the whole wave
+  double sumU = 0.0, sumV = 0.0, sumW = 0.0;
+  int sigerr_count = 0;
+  WaveScratch& ws = wsc[threadIdx.x >> 6];
+  double Xs = X, Ys = Y, Zs = Zpar;
+#pragma unroll 1
+  for (int st = 0; st < 4; st++) {
+    const int version = (st == 0) ? 1 : (st == 3) ? 3 : 2;
+    double Uad, Vad, Wad;
+    find_currents<SlabT>(P, lev, ws, act, C, rn, un, vn, Xs, Ys, Zs, version, Uad, Vad, Wad,
+                         sigerr_count);
+    if (st == 0) { sumU = Uad; sumV = Vad; sumW = Wad; }
+    else if (st == 3) { sumU = sumU + Uad; sumV = sumV + Vad; sumW = sumW + Wad; }
+    else { sumU = sumU + 2.0 * Uad; sumV = sumV + 2.0 * Vad; sumW = sumW + 2.0 * Wad; }
+    if (st < 3) {
+      const double dtf = (double)P.idt;
+      if (st < 2) {
+        Xs = X + (Uad * cosA - Vad * sinA) * dtf / 2.0;
+        Ys = Y + (Uad * sinA + Vad * cosA) * dtf / 2.0;
+        Zs = Zpar + Wad * dtf / 2.0;
       } else {
-        slow = true;
-        inb = false;
+        Xs = X + (Uad * cosA - Vad * sinA) * dtf;
+        Ys = Y + (Uad * sinA + Vad * cosA) * dtf;
+        Zs = Zpar + Wad * dtf;
       }
-      if (slow) {
-        c_pipslow += 1;
-        inb = inpoly_full(newXpos, newYpos, P.maxbound, P.bx, P.by, false);
+      if (Zs > minpartdepth) Zs = minpartdepth - (double)0.000001f;
+      if (Zs < maxpartdepth) Zs = maxpartdepth + (double)0.000001f;
+    }
+  }
+  if (act) {
+    double* wsd = P.ws_d + n;
+    wsd[(size_t)WS_SUMU * N] = sumU;
+    wsd[(size_t)WS_SUMV * N] = sumV;
+    wsd[(size_t)WS_SUMW * N] = sumW;
+  }
+  unsigned v = (unsigned)sigerr_count;
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(&P.counters[CNT_SIGERR], (unsigned long long)v);
+}
+
+__global__ __launch_bounds__(256) void k_post(const StepParams P) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned c_err = 0, c_brute = 0, c_pipslow = 0;
+  if (n < P.numpar) {
+    const size_t N = (size_t)P.numpar;
+    double* par = P.par + n;
+    const double* wsd = P.ws_d + n;
+#define PARV(k) par[(size_t)(k) * N]
+    const int fl = P.ws_i[n];
+    const bool act = (fl & FL_ACT) != 0;
+    bool keep_pn = (fl & FL_KEEP_PN) != 0;
+    int err = fl >> FL_ERR_SHIFT;
+    const double X = PARV(pX), Y = PARV(pY);
+    double Z = act ? wsd[(size_t)WS_ZPAR * N] : PARV(pZ);
+    double nX = X, nY = Y, nZ = Z, lifespan = 0.0;
+    bool set_lifespan = false;
+    if (act) {
+      const double age = PARV(pAge);
+      const double P_depth = wsd[(size_t)WS_PDEPTH * N], P_zetac = wsd[(size_t)WS_ZETA1 * N];
+      const double cosA = wsd[(size_t)WS_COSA * N], sinA = wsd[(size_t)WS_SINA * N];
+      const double P_U = wsd[(size_t)WS_SUMU * N] / 6.0, P_V = wsd[(size_t)WS_SUMV * N] / 6.0,
+                   P_W = wsd[(size_t)WS_SUMW * N] / 6.0;
+      const double AdvectX = P.idt * (P_U * cosA - P_V * sinA);
+      const double AdvectY = P.idt * (P_U * sinA + P_V * cosA);
+      const double AdvectZ = P.idt * P_W;
+      const double TurbHx = 0.0, TurbHy = 0.0, TurbV = 0.0;
+      // behave (types 0 and 6), behavior_module.f90:181-551
+      double ZBehav = 0.0;
+      if (P.Behavior != 0) {
+        const size_t np = (size_t)P.numpar;
+        double sw3 = P.P_swim[n + 2 * np];
+        bool sw_dirty = false;
+        if (age >= P.swimstart) { sw3 = P.P_swim[n] * age + P.P_swim[n + np]; sw_dirty = true; }
+        if (age >= P.P_pediage[n]) { sw3 = P.swimfast; sw_dirty = true; }
+        if (sw_dirty) P.P_swim[n + 2 * np] = sw3;
+        double parBehav = 0.0;
+        if (P.P_behave[n] == 6) parBehav = (age >= P.swimstart) ? P.sink : sw3;
+        ZBehav = parBehav * P.idt;
       }
-      if (!inb) {
-        err = 25;
-      } else {
-        bool inisl = false;
-        if (P.numislands > 0) {
-          slow = false;
-          if (P.use_pip_index) inisl = ibounds_indexed(P, newXpos, newYpos, slow);
-          else slow = true;
-          if (slow) {
-            c_pipslow += 1;
-            inisl = ibounds_full(P.hx, P.hy, P.hid, P.maxisland, P.numislands, newXpos, newYpos);
-          }
+      // new position, vertical reflection :1128-1176
+      double newXpos = X + AdvectX + TurbHx;
+      double newYpos = Y + AdvectY + TurbHy;
+      double newZpos = Z + AdvectZ + TurbV;
+      if (newZpos > P_zetac) {
+        double reflect = P_zetac - newZpos;
+        newZpos = P_zetac + reflect;
+      }
+      if (newZpos < P_depth) {
+        double reflect = P_depth - newZpos;
+        newZpos = P_depth + reflect;
+        if (P.TrackCollisions) P.hitBottom[n] += 1;
+      }
+      newZpos = newZpos + ZBehav;
+      if (newZpos > P_zetac) newZpos = P_zetac - (double)0.000001f;
+      if (newZpos < P_depth) {
+        newZpos = P_depth + (double)0.000001f;
+        if (P.TrackCollisions) P.hitBottom[n] += 1;
+      }
+      // horizontal boundaries :1180-1232
+      double Xpos = X, Ypos = Y, nXpos = newXpos, nYpos = newYpos;
+      int skipbound = -1, reflects = 0;
+      bool done = false;  // waterFlag
+      for (;;) {
+        Hit H;
+        intersect_reflect(P, Xpos, Ypos, nXpos, nYpos, skipbound, H, c_brute);
+        skipbound = H.seg;
+        if (!H.found) break;
+        if (P.TrackCollisions) P.hitLand[n] += 1;
+        if (P.OpenOceanBoundary && H.water) {
+          nX = H.fix; nY = H.fiy; nZ = newZpos;
+          P.oob[n] = 1;
+          done = true;
+          break;
         }
-        if (inisl) {
-          err = 26;
+        reflects += 1;
+        if (reflects > 3) {
+          err = 24;
+          done = true;
+          break;
+        }
+        Xpos = H.fix; Ypos = H.fiy; nXpos = H.frx; nYpos = H.fry;
+      }
+      if (!done) {
+        newXpos = nXpos;
+        newYpos = nYpos;
+        // mbounds :1240, ibounds :1275
+        bool slow = false, inb;
+        if (P.use_pip_index) {
+          inb = mbounds_indexed(P, newXpos, newYpos, slow);
         } else {
-          nX = newXpos; nY = newYpos; nZ = newZpos;  // :1312-1314
-          // setEle on the new position :1317
-          bool okr2 = find_element<true>(P.rnode, P.RE, P.rAdj, nXpos, nYpos, er, rn);
-          bool oku2 = find_element<false>(P.unode, P.UE, P.uAdj, nXpos, nYpos, eu, un);
-          bool okv2 = find_element<false>(P.vnode, P.VE, P.vAdj, nXpos, nYpos, ev, vn);
-          if (!okv2) err = 29; else if (!oku2) err = 28; else if (!okr2) err = 27;
-          if (err == 0 && P.settlementon) {
-            // testSettlement with the OLD position and the NEW element :1375
-            if (age >= P.settletime[n]) {
-              int inpoly = test_settlement(P, X, Y, er);
-              if (inpoly > 0) {
-                P.settle[n] = 1;
-                nZ = P_depth;
-                P.endpoly[n] = inpoly;
-                lifespan = age;
-                set_lifespan = true;
+          slow = true;
+          inb = false;
+        }
+        if (slow) {
+          c_pipslow += 1;
+          inb = inpoly_full(newXpos, newYpos, P.maxbound, P.bx, P.by, false);
+        }
+        if (!inb) {
+          err = 25;
+        } else {
+          bool inisl = false;
+          if (P.numislands > 0) {
+            slow = false;
+            if (P.use_pip_index) inisl = ibounds_indexed(P, newXpos, newYpos, slow);
+            else slow = true;
+            if (slow) {
+              c_pipslow += 1;
+              inisl = ibounds_full(P.hx, P.hy, P.hid, P.maxisland, P.numislands, newXpos, newYpos);
+            }
+          }
+          if (inisl) {
+            err = 26;
+          } else {
+            nX = newXpos; nY = newYpos; nZ = newZpos;  // :1312-1314
+            // setEle on the new position :1317
+            int er = P.P_r_element[n], eu = P.P_u_element[n], ev = P.P_v_element[n];
+            int4 nd;
+            bool okr2 = find_element<true>(P.rnode, P.RE, P.rAdj, nXpos, nYpos, er, nd);
+            bool oku2 = find_element<false>(P.unode, P.UE, P.uAdj, nXpos, nYpos, eu, nd);
+            bool okv2 = find_element<false>(P.vnode, P.VE, P.vAdj, nXpos, nYpos, ev, nd);
+            P.P_r_element[n] = er; P.P_u_element[n] = eu; P.P_v_element[n] = ev;
+            if (!okv2) err = 29; else if (!oku2) err = 28; else if (!okr2) err = 27;
+            if (err == 0 && P.settlementon) {
+              // testSettlement with the OLD position and the NEW element :1375
+              if (age >= P.settletime[n]) {
+                int inpoly = test_settlement(P, X, Y, er);
+                if (inpoly > 0) {
+                  P.settle[n] = 1;
+                  nZ = P_depth;
+                  P.endpoly[n] = inpoly;
+                  lifespan = age;
+                  set_lifespan = true;
+                }
               }
             }
           }
         }
       }
     }
-  }
-
-  // ---- section 4: ErrorFlag handling and the commit loop
-  if (inrange) {
     // ErrorFlag handling :858-877 etc.  (ErrorFlag 0 = the host stops; the
     // particle is returned to its previous location as under ErrorFlag 1)
     if (err != 0) {
@@ -1000,11 +1071,6 @@ __global__ __launch_bounds__(256) void k_step(const StepParams P) {
       else { nX = X; nY = Y; nZ = Z; keep_pn = false; }
     }
     P.err_code[n] = err;
-    if (ele_dirty) {
-      P.P_r_element[n] = er;
-      P.P_u_element[n] = eu;
-      P.P_v_element[n] = ev;
-    }
     // commit loop :1407-1414 fused: pp <- p, p <- pn
     if (keep_pn) {
       nX = PARV(pnX); nY = PARV(pnY); nZ = PARV(pnZ);
@@ -1014,24 +1080,22 @@ __global__ __launch_bounds__(256) void k_step(const StepParams P) {
     PARV(ppX) = X; PARV(ppY) = Y; PARV(ppZ) = Z;
     PARV(pX) = nX; PARV(pY) = nY; PARV(pZ) = nZ;
     if (set_lifespan) PARV(pLifespan) = lifespan;
-  }
 #undef PARV
-
-  // block-level counter reduction -> one atomic per counter per block
-  __shared__ unsigned red[5];
-  if (threadIdx.x < 5) red[threadIdx.x] = 0;
+  }
+  __shared__ unsigned red[3];
+  if (threadIdx.x < 3) red[threadIdx.x] = 0;
   __syncthreads();
-  unsigned vals[5] = {c_active, c_err, (unsigned)sigerr_count, c_brute, c_pipslow};
+  unsigned vals[3] = {c_err, c_brute, c_pipslow};
 #pragma unroll
-  for (int k = 0; k < 5; k++) {
+  for (int k = 0; k < 3; k++) {
     unsigned v = vals[k];
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(&red[k], v);
   }
   __syncthreads();
-  if (threadIdx.x < 5 && red[threadIdx.x]) {
-    atomicAdd(&P.counters[threadIdx.x], (unsigned long long)red[threadIdx.x]);
-  }
+  const int slot[3] = {CNT_ERRORS, CNT_BRUTE, CNT_PIP_SLOW};
+  if (threadIdx.x < 3 && red[threadIdx.x])
+    atomicAdd(&P.counters[slot[threadIdx.x]], (unsigned long long)red[threadIdx.x]);
 }
 
 // ------------------------------------------------------ slab upload
@@ -1064,11 +1128,16 @@ __global__ void k_zeta_scatter(const double* __restrict__ src, SlabT* __restrict
   dst[idx * 4 + slot] = c;
 }
 
-// xyz(numpar,3) column-major <- par(:,1:3)
-__global__ void k_pack_positions(const double* __restrict__ par, double* __restrict__ dst, int numpar) {
-  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (size_t)numpar * 3) return;
-  dst[idx] = par[idx];  // columns 1..3 are the first 3*numpar values
+// xyz(numpar,3) column-major in the REFERENCE particle order <- par(:,1:3)
+__global__ void k_pack_positions(const double* __restrict__ par, const int* __restrict__ orig,
+                                 double* __restrict__ dst, int numpar) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= numpar) return;
+  const size_t N = (size_t)numpar;
+  const int o = orig[i];
+  dst[o] = par[i];
+  dst[N + o] = par[N + i];
+  dst[2 * N + o] = par[2 * N + i];
 }
 
 // number of particles that pass the gates and the first setEle (= draw RNG)

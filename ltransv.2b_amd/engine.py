@@ -26,7 +26,7 @@ def load_hip_library(path=None):
     global _hip_lib
     if path is None and _hip_lib is not None:
         return _hip_lib
-    p = path or HIP_LIBRARY
+    p = path or os.environ.get("LT_HIP_LIBRARY") or HIP_LIBRARY
     if not os.path.exists(p):
         raise RuntimeError(
             f"{p} not found: build the HIP extension first "
