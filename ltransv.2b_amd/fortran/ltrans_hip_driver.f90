@@ -1,0 +1,263 @@
+! ltrans_hip_driver.f90 -- Fortran host harness around the MI355X engine.
+!
+! Plays the part of LTRANS' PROGRAM main for the hot path only: it reads the
+! run's namelist file in the LTRANS.data syntax, owns par(numpar,13) and the
+! other arrays the reference's modules own, and runs the reference's loops
+!     run_LTRANS / run_External_Timestep / run_Internal_Timestep
+!     (Model/LTRANS.f90:141-161, 548-612)
+! calling lt_step() where the reference calls update_particles() (:596) and
+! lt_set_slab() where updateHydro scatters a new record (:559,
+! hydrodynamic_module.f90:1052-1410).  NetCDF is not available in this image,
+! so grid / boundary / particle / history arrays come from a flat binary "case"
+! file written by ltrans_amd.casefile (the arrays are exactly those initGrid,
+! createBounds, setEle_all and initHydro produce).
+!
+! usage: ltrans_hip_driver <LTRANS.data> <case.bin> <out.bin> [n_external] [max_internal]
+program ltrans_hip_driver
+  use iso_c_binding
+  use ltrans_hip
+  implicit none
+
+  ! ---- namelist variables (names are the LTRANS.data keys; types per the
+  !      reference's input schema: hc and days are REAL)
+  integer :: numpar
+  real :: days
+  integer :: iprint, dt, idt
+  integer :: us, ws, tdim, Vtransform
+  real :: hc
+  double precision :: z0, constZeta, constSalt, constTemp, constU, constV, constW, constAks, constDens
+  logical :: readZeta, readSalt, readTemp, readU, readV, readW, readAks, readDens
+  logical :: HTurbOn, VTurbOn
+  double precision :: ConstantHTurb
+  integer :: Behavior
+  logical :: OpenOceanBoundary, mortality
+  double precision :: deadage, pediage, swimstart, swimslow, swimfast, Sgradient, sink, Hswimspeed, Swimdepth
+  double precision :: twistart, twiend, daylength, Em, Kd, thresh
+  logical :: settlementon, holesExist
+  integer :: minpolyid, maxpolyid, minholeid, maxholeid, pedges, hedges
+  double precision :: PI, Earth_Radius, lonmin, latmin
+  logical :: SphericalProjection
+  integer :: seed, ErrorFlag, ijbuff
+  logical :: BoundaryBLNs, SaltTempOn, TrackCollisions, WriteHeaders, WriteModelTiming, FreeSlip
+
+  namelist/numparticles/ numpar
+  namelist/timeparam/ days, iprint, dt, idt
+  namelist/hydroparam/ us, ws, tdim, hc, z0, Vtransform, readZeta, constZeta, readSalt, constSalt, &
+                       readTemp, constTemp, readU, constU, readV, constV, readW, constW, readAks,   &
+                       constAks, readDens, constDens
+  namelist/turbparam/ HTurbOn, VTurbOn, ConstantHTurb
+  namelist/behavparam/ Behavior, OpenOceanBoundary, mortality, deadage, pediage, swimstart, swimslow, &
+                       swimfast, Sgradient, sink, Hswimspeed, Swimdepth
+  namelist/dvmparam/ twistart, twiend, daylength, Em, Kd, thresh
+  namelist/settleparam/ settlementon, holesExist, minpolyid, maxpolyid, minholeid, maxholeid, pedges, hedges
+  namelist/convparam/ PI, Earth_Radius, SphericalProjection, lonmin, latmin
+  namelist/other/ seed, ErrorFlag, BoundaryBLNs, SaltTempOn, TrackCollisions, WriteHeaders, &
+                  WriteModelTiming, ijbuff, FreeSlip
+
+  ! ---- case data
+  integer(c_int32_t) :: magic, vi, uj, c_us, c_ws, rho_nodes, u_nodes, v_nodes, rho_elements, &
+                        u_elements, v_elements, nbounds, maxbound, maxisland, numislands, c_numpar, nrec
+  real(c_double), allocatable, target :: rx(:), ry(:), ux(:), uy(:), vx(:), vy(:), depth(:), rho_angle(:)
+  integer(c_int32_t), allocatable, target :: RE(:,:), UE(:,:), VE(:,:), r_Adj(:,:), u_Adj(:,:), v_Adj(:,:)
+  real(c_double), allocatable, target :: SC(:), CS(:), SCW(:), CSW(:)
+  real(c_double), allocatable, target :: bnd_x(:,:), bnd_y(:,:), bx(:), by(:), hx(:), hy(:)
+  integer(c_int32_t), allocatable, target :: land(:), hid(:)
+  real(c_double), allocatable, target :: par(:,:)
+  integer(c_int32_t), allocatable, target :: P_r_element(:), P_u_element(:), P_v_element(:)
+  integer(c_int32_t), allocatable, target :: P_behave(:), dead(:), oob(:), settle(:), endpoly(:), &
+                                            hitBottom(:), hitLand(:), err_code(:)
+  real(c_double), allocatable, target :: P_swim(:,:), P_pediage(:), P_deadage(:), settletime(:)
+  real(c_double), allocatable, target :: zeta(:), Uvel(:,:), Vvel(:,:), Wvel(:,:), Kh(:,:)
+
+  type(c_ptr) :: eng
+  type(lt_config) :: cfg
+  type(lt_grid) :: g
+  type(lt_bounds) :: b
+  type(lt_particles) :: pp
+  type(lt_slab) :: slab
+  type(lt_step_stats) :: st
+  double precision :: ex(3), ix(3)
+  integer :: p, it, stepT, stepIT, t_b, t_c, t_f, stepf, n, nargs, n_external, max_internal, ios
+  integer(c_int64_t) :: total_errors
+  character(len=512) :: nmlfile, casefile, outfile, arg
+
+  nargs = command_argument_count()
+  if (nargs < 3) then
+    write(*,*) 'usage: ltrans_hip_driver <LTRANS.data> <case.bin> <out.bin> [n_external] [max_internal]'
+    stop 2
+  endif
+  call get_command_argument(1, nmlfile)
+  call get_command_argument(2, casefile)
+  call get_command_argument(3, outfile)
+  n_external = -1
+  max_internal = -1
+  if (nargs >= 4) then
+    call get_command_argument(4, arg); read(arg, *) n_external
+  endif
+  if (nargs >= 5) then
+    call get_command_argument(5, arg); read(arg, *) max_internal
+  endif
+
+  ! ---- getParams: same groups, same order as the reference's reader
+  !      (parameter_module.f90:29-86); groups this path does not use are skipped
+  HTurbOn = .false.; VTurbOn = .false.; settlementon = .false.; holesExist = .false.
+  OpenOceanBoundary = .false.; mortality = .false.; SaltTempOn = .false.; FreeSlip = .false.
+  TrackCollisions = .false.; Behavior = 0; seed = 9; ErrorFlag = 1; PI = 3.14159265358979d0
+  open(1, file=trim(nmlfile), status='old', action='read', iostat=ios)
+  if (ios /= 0) then
+    write(*,*) 'cannot open ', trim(nmlfile); stop 2
+  endif
+  read(1, nml=numparticles)
+  read(1, nml=timeparam)
+  read(1, nml=hydroparam)
+  read(1, nml=turbparam)
+  read(1, nml=behavparam)
+  read(1, nml=dvmparam, iostat=ios)
+  if (ios /= 0) rewind(1)
+  read(1, nml=settleparam)
+  read(1, nml=convparam)
+  rewind(1)
+  read(1, nml=other)
+  close(1)
+
+  ! ---- the arrays of initGrid / createBounds / setEle_all / initHydro
+  open(2, file=trim(casefile), access='stream', form='unformatted', status='old', action='read')
+  read(2) magic, vi, uj, c_us, c_ws, rho_nodes, u_nodes, v_nodes, rho_elements, u_elements, &
+          v_elements, nbounds, maxbound, maxisland, numislands, c_numpar, nrec
+  if (magic /= 1280590641) stop 'not an LTC1 case file'
+  if (c_us /= us .or. c_ws /= ws .or. c_numpar /= numpar) then
+    write(*,*) 'case file does not match the namelists: us,ws,numpar =', c_us, c_ws, c_numpar
+    stop 2
+  endif
+  allocate(rx(rho_nodes), ry(rho_nodes), ux(u_nodes), uy(u_nodes), vx(v_nodes), vy(v_nodes))
+  allocate(depth(rho_nodes), rho_angle(rho_nodes))
+  allocate(RE(4,rho_elements), UE(4,u_elements), VE(4,v_elements))
+  allocate(r_Adj(rho_elements,10), u_Adj(u_elements,10), v_Adj(v_elements,10))
+  allocate(SC(us), CS(us), SCW(ws), CSW(ws))
+  allocate(bnd_x(2,nbounds), bnd_y(2,nbounds), land(nbounds), bx(maxbound), by(maxbound))
+  allocate(hx(max(maxisland,1)), hy(max(maxisland,1)), hid(max(maxisland,1)))
+  allocate(par(numpar,13), P_r_element(numpar), P_u_element(numpar), P_v_element(numpar))
+  read(2) rx, ry, ux, uy, vx, vy, depth, rho_angle
+  read(2) RE, UE, VE, r_Adj, u_Adj, v_Adj
+  read(2) SC, CS, SCW, CSW
+  read(2) bnd_x, bnd_y, land, bx, by
+  if (maxisland > 0) read(2) hx(1:maxisland), hy(1:maxisland), hid(1:maxisland)
+  read(2) par, P_r_element, P_u_element, P_v_element
+  allocate(zeta(rho_nodes), Uvel(u_nodes,us), Vvel(v_nodes,us), Wvel(rho_nodes,ws), Kh(rho_nodes,ws))
+
+  ! ---- initBehave (behavior_module.f90:94-160) / initSettlement state
+  allocate(P_behave(numpar), dead(numpar), oob(numpar), settle(numpar), endpoly(numpar))
+  allocate(hitBottom(numpar), hitLand(numpar), err_code(numpar))
+  allocate(P_swim(numpar,3), P_pediage(numpar), P_deadage(numpar), settletime(numpar))
+  do n = 1, numpar
+    P_behave(n) = Behavior
+    P_pediage(n) = pediage
+    P_deadage(n) = deadage
+    P_swim(n,1) = (swimfast - swimslow)/(P_pediage(n) - swimstart)
+    P_swim(n,2) = swimfast - P_swim(n,1)*P_pediage(n)
+    P_swim(n,3) = 0.0
+    settletime(n) = P_pediage(n)
+  enddo
+  dead = 0; oob = 0; settle = 0; endpoly = 0; hitBottom = 0; hitLand = 0; err_code = 0
+
+  ! ---- hand everything to the device
+  cfg = lt_config_init()
+  cfg%numpar = numpar; cfg%dt = dt; cfg%idt = idt; cfg%us = us; cfg%ws = ws
+  cfg%hc = hc; cfg%Vtransform = Vtransform; cfg%z0 = z0
+  cfg%HTurbOn = merge(1, 0, HTurbOn); cfg%VTurbOn = merge(1, 0, VTurbOn)
+  cfg%ConstantHTurb = ConstantHTurb
+  cfg%Behavior = Behavior
+  cfg%OpenOceanBoundary = merge(1, 0, OpenOceanBoundary); cfg%mortality = merge(1, 0, mortality)
+  cfg%deadage = deadage; cfg%pediage = pediage; cfg%swimstart = swimstart
+  cfg%swimslow = swimslow; cfg%swimfast = swimfast; cfg%sink = sink; cfg%Swimdepth = Swimdepth
+  cfg%settlementon = merge(1, 0, settlementon); cfg%holesExist = merge(1, 0, holesExist)
+  cfg%PI = PI; cfg%seed = seed; cfg%ErrorFlag = ErrorFlag
+  cfg%SaltTempOn = merge(1, 0, SaltTempOn); cfg%TrackCollisions = merge(1, 0, TrackCollisions)
+  cfg%FreeSlip = merge(1, 0, FreeSlip)
+  eng = c_null_ptr
+  call lt_check(lt_create(cfg, eng), eng, 'lt_create')
+
+  g%rho_nodes = rho_nodes; g%u_nodes = u_nodes; g%v_nodes = v_nodes
+  g%rho_elements = rho_elements; g%u_elements = u_elements; g%v_elements = v_elements
+  g%rx = c_loc(rx); g%ry = c_loc(ry); g%ux = c_loc(ux); g%uy = c_loc(uy)
+  g%vx = c_loc(vx); g%vy = c_loc(vy); g%depth = c_loc(depth); g%rho_angle = c_loc(rho_angle)
+  g%rho_mask = c_null_ptr; g%u_mask = c_null_ptr; g%v_mask = c_null_ptr
+  g%RE = c_loc(RE); g%UE = c_loc(UE); g%VE = c_loc(VE)
+  g%r_Adjacent = c_loc(r_Adj); g%u_Adjacent = c_loc(u_Adj); g%v_Adjacent = c_loc(v_Adj)
+  g%SC = c_loc(SC); g%CS = c_loc(CS); g%SCW = c_loc(SCW); g%CSW = c_loc(CSW)
+  call lt_check(lt_set_grid(eng, g), eng, 'lt_set_grid')
+
+  b%nbounds = nbounds; b%maxbound = maxbound; b%maxisland = maxisland; b%numislands = numislands
+  b%bnd_x = c_loc(bnd_x); b%bnd_y = c_loc(bnd_y); b%land = c_loc(land)
+  b%bx = c_loc(bx); b%by = c_loc(by); b%hx = c_loc(hx); b%hy = c_loc(hy); b%hid = c_loc(hid)
+  call lt_check(lt_set_bounds(eng, b), eng, 'lt_set_bounds')
+
+  pp%par = c_loc(par)
+  pp%P_r_element = c_loc(P_r_element); pp%P_u_element = c_loc(P_u_element); pp%P_v_element = c_loc(P_v_element)
+  pp%P_behave = c_loc(P_behave); pp%dead = c_loc(dead); pp%oob = c_loc(oob)
+  pp%P_swim = c_loc(P_swim); pp%P_pediage = c_loc(P_pediage); pp%P_deadage = c_loc(P_deadage)
+  pp%settle = c_loc(settle); pp%settletime = c_loc(settletime)
+  pp%endpoly = c_loc(endpoly); pp%hitBottom = c_loc(hitBottom); pp%hitLand = c_loc(hitLand)
+  pp%err_code = c_loc(err_code)
+  call lt_check(lt_set_particles(eng, pp), eng, 'lt_set_particles')
+
+  ! ---- initHydro: first three records into slots 1,2,3 (hydrodynamic_module.f90:741-743)
+  slab%zeta = c_loc(zeta); slab%Uvel = c_loc(Uvel); slab%Vvel = c_loc(Vvel)
+  slab%Wvel = c_loc(Wvel); slab%Kh = c_loc(Kh)
+  do n = 1, 3
+    read(2) zeta, Uvel, Vvel, Wvel, Kh
+    call lt_check(lt_set_slab(eng, n, slab), eng, 'lt_set_slab')
+  enddo
+  t_b = 1; t_c = 2; t_f = 3; stepf = 3
+  call lt_check(lt_set_time_slots(eng, t_b, t_c, t_f), eng, 'lt_set_time_slots')
+
+  ! ---- run_LTRANS (LTRANS.f90:141-161)
+  stepT = int(days*86400.0)/dt
+  if (n_external > 0) stepT = min(stepT, n_external)
+  stepIT = int(dt/idt)
+  if (max_internal > 0) stepIT = min(stepIT, max_internal)
+  total_errors = 0
+  do p = 1, stepT
+    ! run_External_Timestep (:548-579)
+    if (p > 2) then
+      ! updateHydro: rotate indices (hydrodynamic_module.f90:1080-1082), one new record into t_f
+      t_b = mod(t_b,3)+1
+      t_c = mod(t_c,3)+1
+      t_f = mod(t_f,3)+1
+      stepf = stepf + 1
+      if (stepf > nrec) stop 'case file holds too few history records'
+      read(2) zeta, Uvel, Vvel, Wvel, Kh
+      call lt_check(lt_set_slab(eng, t_f, slab), eng, 'lt_set_slab')
+      call lt_check(lt_set_time_slots(eng, t_b, t_c, t_f), eng, 'lt_set_time_slots')
+    endif
+    ex = 0.0
+    ex(1) = (p-2)*dt
+    ex(2) = (p-1)*dt
+    ex(3) = p*dt
+    do it = 1, stepIT
+      ! run_Internal_Timestep (:583-612)
+      ix(1) = ex(2) + DBLE((it-2)*idt)
+      ix(2) = ex(2) + DBLE((it-1)*idt)
+      ix(3) = ex(2) + DBLE(it*idt)
+      call lt_check(lt_step(eng, ex, ix, p, it), eng, 'lt_step')   ! = call update_particles()
+      call lt_check(lt_get_stats(eng, st), eng, 'lt_get_stats')
+      total_errors = total_errors + st%errors
+      if (st%errors > 0 .and. (ErrorFlag < 1 .or. ErrorFlag > 3)) then
+        write(*,*) st%errors, ' particle error(s) at model time ', ix(3)
+        write(*,*) 'The Program Cannot Continue and Will Terminate'
+        stop 1
+      endif
+    enddo
+  enddo
+  close(2)
+
+  ! ---- fin: bring the state back and write it out
+  call lt_check(lt_get_particles(eng, pp), eng, 'lt_get_particles')
+  open(3, file=trim(outfile), access='stream', form='unformatted', status='replace', action='write')
+  write(3) int(numpar, c_int32_t), int(stepT*stepIT, c_int32_t)
+  write(3) par, P_r_element, P_u_element, P_v_element, err_code, hitBottom, hitLand, dead, oob, settle
+  close(3)
+  write(*,'(A,I0,A,I0,A,I0)') 'ltrans_hip_driver: ', numpar, ' particles, ', stepT*stepIT, &
+        ' internal steps, particle errors: ', total_errors
+  call lt_check(lt_destroy(eng), c_null_ptr, 'lt_destroy')
+end program ltrans_hip_driver

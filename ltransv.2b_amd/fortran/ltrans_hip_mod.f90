@@ -1,0 +1,245 @@
+! ltrans_hip_mod.f90 -- ISO_C_BINDING interface to the MI355X engine
+! (include/ltrans_hip.h, ABI version 1).
+!
+! This is the Fortran side of the drop-in boundary for LTRANS v.2b's
+! update_particles() (Model/LTRANS.f90:707-1419): the host program stays
+! Fortran; it hands the arrays the reference already owns to the device once
+! (after initGrid / createBounds / initBehave / setEle_all / initHydro) and then
+! calls lt_step(...) where the reference calls update_particles() (:596).
+! Every TYPE below mirrors the C struct of the same name field for field;
+! arrays are passed with C_LOC of the reference's own (column-major) arrays.
+module ltrans_hip
+  use iso_c_binding
+  implicit none
+  public
+
+  integer(c_int), parameter :: LT_ABI_EXPECTED = 1
+  integer(c_int), parameter :: LT_OK = 0
+  integer(c_int), parameter :: LT_SLAB_F32 = 0, LT_SLAB_F64 = 1
+
+  type, bind(C) :: lt_config
+    integer(c_int32_t) :: struct_size, abi_version
+    integer(c_int32_t) :: numpar
+    integer(c_int32_t) :: dt, idt
+    integer(c_int32_t) :: us, ws
+    real(c_float)      :: hc
+    integer(c_int32_t) :: Vtransform
+    real(c_double)     :: z0
+    integer(c_int32_t) :: HTurbOn, VTurbOn
+    real(c_double)     :: ConstantHTurb
+    integer(c_int32_t) :: Behavior, OpenOceanBoundary, mortality
+    real(c_double)     :: deadage, pediage, swimstart, swimslow, swimfast, sink, Swimdepth
+    integer(c_int32_t) :: settlementon, holesExist
+    real(c_double)     :: PI
+    integer(c_int32_t) :: seed, ErrorFlag, SaltTempOn, TrackCollisions, FreeSlip
+    integer(c_int32_t) :: slab_storage, device, reserved0
+  end type lt_config
+
+  type, bind(C) :: lt_grid
+    integer(c_int32_t) :: rho_nodes, u_nodes, v_nodes
+    integer(c_int32_t) :: rho_elements, u_elements, v_elements
+    type(c_ptr) :: rx, ry, ux, uy, vx, vy, depth, rho_angle
+    type(c_ptr) :: rho_mask, u_mask, v_mask
+    type(c_ptr) :: RE, UE, VE
+    type(c_ptr) :: r_Adjacent, u_Adjacent, v_Adjacent
+    type(c_ptr) :: SC, CS, SCW, CSW
+  end type lt_grid
+
+  type, bind(C) :: lt_bounds
+    integer(c_int32_t) :: nbounds, maxbound, maxisland, numislands
+    type(c_ptr) :: bnd_x, bnd_y, land, bx, by, hx, hy, hid
+  end type lt_bounds
+
+  type, bind(C) :: lt_habitat
+    integer(c_int32_t) :: pedges, hedges, minpolyid, maxpolyid, minholeid, maxholeid
+    type(c_ptr) :: polys, holes, polyspecs, holespecs, maxbdis, maxhdis
+    type(c_ptr) :: elepolys_ptr, elepolys_ids, polyholes_ptr, polyholes_ids
+  end type lt_habitat
+
+  type, bind(C) :: lt_particles
+    type(c_ptr) :: par
+    type(c_ptr) :: P_r_element, P_u_element, P_v_element
+    type(c_ptr) :: P_behave, dead, oob
+    type(c_ptr) :: P_swim, P_pediage, P_deadage
+    type(c_ptr) :: settle, settletime
+    type(c_ptr) :: endpoly, hitBottom, hitLand, err_code
+  end type lt_particles
+
+  type, bind(C) :: lt_slab
+    type(c_ptr) :: zeta, Uvel, Vvel, Wvel, Kh
+  end type lt_slab
+
+  type, bind(C) :: lt_step_stats
+    integer(c_int64_t) :: active, errors, rng_draws
+  end type lt_step_stats
+
+  interface
+    function lt_abi_version() bind(C, name="lt_abi_version") result(v)
+      import :: c_int
+      integer(c_int) :: v
+    end function
+    function lt_create(cfg, engine) bind(C, name="lt_create") result(rc)
+      import :: c_int, c_ptr, lt_config
+      type(lt_config), intent(in) :: cfg
+      type(c_ptr), intent(out) :: engine
+      integer(c_int) :: rc
+    end function
+    function lt_destroy(engine) bind(C, name="lt_destroy") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: engine
+      integer(c_int) :: rc
+    end function
+    function lt_last_error(engine) bind(C, name="lt_last_error") result(msg)
+      import :: c_ptr
+      type(c_ptr), value :: engine
+      type(c_ptr) :: msg
+    end function
+    function lt_set_grid(engine, g) bind(C, name="lt_set_grid") result(rc)
+      import :: c_int, c_ptr, lt_grid
+      type(c_ptr), value :: engine
+      type(lt_grid), intent(in) :: g
+      integer(c_int) :: rc
+    end function
+    function lt_set_bounds(engine, b) bind(C, name="lt_set_bounds") result(rc)
+      import :: c_int, c_ptr, lt_bounds
+      type(c_ptr), value :: engine
+      type(lt_bounds), intent(in) :: b
+      integer(c_int) :: rc
+    end function
+    function lt_set_habitat(engine, h) bind(C, name="lt_set_habitat") result(rc)
+      import :: c_int, c_ptr, lt_habitat
+      type(c_ptr), value :: engine
+      type(lt_habitat), intent(in) :: h
+      integer(c_int) :: rc
+    end function
+    function lt_set_particles(engine, p) bind(C, name="lt_set_particles") result(rc)
+      import :: c_int, c_ptr, lt_particles
+      type(c_ptr), value :: engine
+      type(lt_particles), intent(in) :: p
+      integer(c_int) :: rc
+    end function
+    function lt_get_particles(engine, p) bind(C, name="lt_get_particles") result(rc)
+      import :: c_int, c_ptr, lt_particles
+      type(c_ptr), value :: engine
+      type(lt_particles), intent(in) :: p     ! pointers to the caller's arrays: filled in place
+      integer(c_int) :: rc
+    end function
+    function lt_set_slab(engine, slot, s) bind(C, name="lt_set_slab") result(rc)
+      import :: c_int, c_int32_t, c_ptr, lt_slab
+      type(c_ptr), value :: engine
+      integer(c_int32_t), value :: slot
+      type(lt_slab), intent(in) :: s
+      integer(c_int) :: rc
+    end function
+    function lt_set_time_slots(engine, t_b, t_c, t_f) bind(C, name="lt_set_time_slots") result(rc)
+      import :: c_int, c_int32_t, c_ptr
+      type(c_ptr), value :: engine
+      integer(c_int32_t), value :: t_b, t_c, t_f
+      integer(c_int) :: rc
+    end function
+    function lt_set_rng(engine, mt, mti) bind(C, name="lt_set_rng") result(rc)
+      import :: c_int, c_int32_t, c_ptr
+      type(c_ptr), value :: engine
+      integer(c_int32_t), intent(in) :: mt(0:623)
+      integer(c_int32_t), value :: mti
+      integer(c_int) :: rc
+    end function
+    function lt_get_rng(engine, mt, mti) bind(C, name="lt_get_rng") result(rc)
+      import :: c_int, c_int32_t, c_ptr
+      type(c_ptr), value :: engine
+      integer(c_int32_t), intent(out) :: mt(0:623)
+      integer(c_int32_t), intent(out) :: mti
+      integer(c_int) :: rc
+    end function
+    function lt_count_active(engine, ix, n_active) bind(C, name="lt_count_active") result(rc)
+      import :: c_int, c_int64_t, c_double, c_ptr
+      type(c_ptr), value :: engine
+      real(c_double), intent(in) :: ix(3)
+      integer(c_int64_t), intent(out) :: n_active
+      integer(c_int) :: rc
+    end function
+    function lt_set_rng_window(engine, active_before, active_total) &
+        bind(C, name="lt_set_rng_window") result(rc)
+      import :: c_int, c_int64_t, c_ptr
+      type(c_ptr), value :: engine
+      integer(c_int64_t), value :: active_before, active_total
+      integer(c_int) :: rc
+    end function
+    ! = update_particles() with main's ex, ix, p, it (LTRANS.f90:568-571,588-590)
+    function lt_step(engine, ex, ix, p, it) bind(C, name="lt_step") result(rc)
+      import :: c_int, c_int32_t, c_double, c_ptr
+      type(c_ptr), value :: engine
+      real(c_double), intent(in) :: ex(3), ix(3)
+      integer(c_int32_t), value :: p, it
+      integer(c_int) :: rc
+    end function
+    function lt_sync(engine) bind(C, name="lt_sync") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: engine
+      integer(c_int) :: rc
+    end function
+    function lt_get_stats(engine, stats) bind(C, name="lt_get_stats") result(rc)
+      import :: c_int, c_ptr, lt_step_stats
+      type(c_ptr), value :: engine
+      type(lt_step_stats), intent(out) :: stats
+      integer(c_int) :: rc
+    end function
+    function lt_pack_positions(engine, dst_device) bind(C, name="lt_pack_positions") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: engine, dst_device
+      integer(c_int) :: rc
+    end function
+  end interface
+
+contains
+
+  ! lt_config with the sizes filled in and LTRANS.data defaults for the rest
+  function lt_config_init() result(cfg)
+    type(lt_config) :: cfg
+    cfg%struct_size = int(c_sizeof(cfg), c_int32_t)
+    cfg%abi_version = LT_ABI_EXPECTED
+    cfg%numpar = 0; cfg%dt = 3600; cfg%idt = 120; cfg%us = 0; cfg%ws = 0
+    cfg%hc = 0.2; cfg%Vtransform = 1; cfg%z0 = 0.0005d0
+    cfg%HTurbOn = 0; cfg%VTurbOn = 0; cfg%ConstantHTurb = 1.0d0
+    cfg%Behavior = 0; cfg%OpenOceanBoundary = 0; cfg%mortality = 0
+    cfg%deadage = 367200.d0; cfg%pediage = 302400.d0; cfg%swimstart = 0.d0
+    cfg%swimslow = 0.005d0; cfg%swimfast = 0.005d0; cfg%sink = -0.0003d0; cfg%Swimdepth = 2.d0
+    cfg%settlementon = 0; cfg%holesExist = 0
+    cfg%PI = 3.14159265358979d0
+    cfg%seed = 9; cfg%ErrorFlag = 1; cfg%SaltTempOn = 0; cfg%TrackCollisions = 0; cfg%FreeSlip = 0
+    cfg%slab_storage = LT_SLAB_F32; cfg%device = -1; cfg%reserved0 = 0
+  end function
+
+  ! engine-owned message of the last failure as a Fortran string
+  function lt_error_string(engine) result(s)
+    type(c_ptr), intent(in) :: engine
+    character(len=:), allocatable :: s
+    character(kind=c_char), pointer :: p(:)
+    type(c_ptr) :: cp
+    integer :: n
+    cp = lt_last_error(engine)
+    s = ''
+    if (.not. c_associated(cp)) return
+    call c_f_pointer(cp, p, [512])
+    n = 0
+    do while (n < 512)
+      if (p(n + 1) == c_null_char) exit
+      n = n + 1
+    enddo
+    allocate(character(len=n) :: s)
+    if (n > 0) s = transfer(p(1:n), s)
+  end function
+
+  subroutine lt_check(rc, engine, what)
+    integer(c_int), intent(in) :: rc
+    type(c_ptr), intent(in) :: engine
+    character(len=*), intent(in) :: what
+    if (rc < 0) then
+      write(*,*) 'ltrans_hip: ', what, ' failed with status ', rc
+      if (c_associated(engine)) write(*,*) '  ', lt_error_string(engine)
+      write(*,*) 'The Program Cannot Continue and Will Terminate'
+      stop 1
+    endif
+  end subroutine
+
+end module ltrans_hip
