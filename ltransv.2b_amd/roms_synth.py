@@ -246,9 +246,10 @@ def create_bounds(g):
 # --------------------------------------------------------------------------
 # fields
 # --------------------------------------------------------------------------
-def make_record(g, geo, r, dt=3600.0, with_kh=True):
+def make_record(g, geo, r, dt=3600.0, with_kh=True, drift=(0.0, 0.0)):
     """History record r (time r*dt) as ROMS stores it (float32), then masked and
     node-numbered as updateHydro does (hydrodynamic_module.f90:1371-1403).
+    ``drift`` adds a uniform (u, v) to push particles into the coast (reflection tests).
     Returns dict zeta (rho_nodes), Uvel (u_nodes,us), Vvel (v_nodes,us),
     Wvel/Kh (rho_nodes,ws), all float64 holding float32-representable values."""
     vi, uj, us, ws = g["vi"], g["uj"], g["us"], g["ws"]
@@ -271,8 +272,8 @@ def make_record(g, geo, r, dt=3600.0, with_kh=True):
     u2 = -0.5 * tide * np.sin(2 * np.pi * xu) * np.cos(np.pi * yu) + 0.05 * math.sin(2 * math.pi * t / 44714.0)
     v2 = 0.5 * tide * np.cos(2 * np.pi * xv) * np.sin(np.pi * yv) * (Ly / Lx) * 2.0
     v2 = np.clip(v2, -0.5, 0.5)
-    U = u2[:, :, None] * shear
-    V = v2[:, :, None] * shear
+    U = (u2[:, :, None] + drift[0]) * shear
+    V = (v2[:, :, None] + drift[1]) * shear
     W = 1.0e-3 * np.sin(np.pi * sw) * (np.sin(2 * np.pi * xr) * np.cos(np.pi * yr))[:, :, None] * tide
     out = dict(
         zeta=F(f32(zeta) * geo["m_r"]),

@@ -16,6 +16,19 @@ CASES = {
                       numpar=608, near_land=0.2, cfg=dict(Behavior=0)),
     "mid_adv": dict(grid=(128, 64, 30), islands=[], numpar=20000, near_land=0.1,
                     cfg=dict(Behavior=0)),
+    # uniform drift into the west/south coast and the island: many reflections
+    "tiny_reflect": dict(grid=(24, 16, 8), islands=[(10, 12, 6, 8)], numpar=768, near_land=0.6,
+                         drift=(-0.35, -0.25), cfg=dict(Behavior=0)),
+    # open eastern boundary, drift towards it: particles leave through open ocean
+    "tiny_open": dict(grid=(24, 16, 8), islands=[], numpar=512, near_land=0.0, open_east=True,
+                      drift=(0.45, 0.05), cfg=dict(Behavior=0, OpenOceanBoundary=1)),
+    # sinking + settlement on habitat polygons (one with a hole), mortality on
+    "tiny_settle": dict(grid=(24, 16, 8), islands=[(10, 12, 6, 8)], numpar=768, near_land=0.2,
+                        polygons=[(6000.0, 5000.0, 2500.0, 12), (16000.0, 9000.0, 3000.0, 9),
+                                  (18000.0, 4000.0, 1500.0, 7)],
+                        holes=[(0, 6200.0, 5200.0, 900.0, 8)],
+                        cfg=dict(Behavior=6, sink=-0.002, swimstart=0.0, settlementon=1,
+                                 holesExist=1, pediage=1800.0, mortality=1, deadage=5400.0)),
 }
 
 
@@ -41,7 +54,7 @@ def build_case(name, numpar=None, slab_storage=None, **cfg_extra):
 
     def record(r):
         if r not in recs:
-            recs[r] = rs.make_record(g, geo, r, with_kh=bool(cfg.VTurbOn) or True)
+            recs[r] = rs.make_record(g, geo, r, with_kh=True, drift=spec.get("drift", (0.0, 0.0)))
         return recs[r]
 
     return dict(name=name, g=g, geo=geo, bounds=bounds, cfg=cfg, parts=parts, record=record,

@@ -42,6 +42,30 @@ def test_parity_two_external_steps(name):
     print(f"{name}: max rel err {err:.3e}; land hits {int(ora['hitLand'].sum())}")
 
 
+@pytest.mark.parametrize("errflag", [1, 2, 3])
+def test_parity_reflection(errflag):
+    """drift into coast and island: intersect_reflect, up to 3 reflections, error paths."""
+    case = cases.build_case("tiny_reflect", ErrorFlag=errflag)
+    hip, ora = _both(case, n_external=2)
+    _check(hip, ora)
+    assert int(ora["hitLand"].sum()) > 50, "case must exercise reflections"
+
+
+def test_parity_open_ocean_boundary():
+    case = cases.build_case("tiny_open")
+    hip, ora = _both(case, n_external=3)
+    _check(hip, ora)
+    assert int(ora["oob"].sum()) > 10, "case must let particles leave through the open boundary"
+
+
+def test_parity_settlement_and_mortality():
+    case = cases.build_case("tiny_settle")
+    hip, ora = _both(case, n_external=3)
+    _check(hip, ora)
+    assert int(ora["settle"].sum()) > 5 and int(ora["dead"].sum()) > 5
+    assert np.array_equal(hip["par"][:, 12], ora["par"][:, 12])      # lifespan
+
+
 def test_parity_slab_rotation():
     """p = 1 special case, p = 2, and two updateHydro rotations (p = 3, 4)."""
     case = cases.build_case("tiny_adv")
