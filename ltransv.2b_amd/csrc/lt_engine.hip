@@ -730,6 +730,8 @@ int lt_step(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32
       HIPCHK(e, hipEventRecord(e->prof_ev[e->prof_used + 1], e->stream));
       e->prof_used += 2;
     }
+    if (f32) hipLaunchKernelGGL((k_rk_slow<float>), dim3(blocks), dim3(256), 0, e->stream, P);
+    else hipLaunchKernelGGL((k_rk_slow<double>), dim3(blocks), dim3(256), 0, e->stream, P);
     hipLaunchKernelGGL(k_post, dim3(blocks), dim3(256), 0, e->stream, P);
     HIPCHK(e, hipGetLastError());
   }

@@ -33,6 +33,11 @@ enum { pX = 0, pY, pZ, pnX, pnY, pnZ, ppX, ppY, ppZ, pStatus, pDOB, pAge, pLifes
 
 #define LT_LEV_STRIDE 64
 
+// per-step workspace columns (doubles, SoA stride numpar) and the flag word
+enum { WS_PDEPTH = 0, WS_COSA, WS_SINA, WS_ZETA0, WS_ZETA1, WS_ZETA2, WS_PZ0, WS_PZ1, WS_PZ2,
+       WS_ZPAR, WS_SUMU, WS_SUMV, WS_SUMW, WS_NDOUBLE };
+enum { FL_ACT = 1, FL_KEEP_PN = 2, FL_SLOW = 4, FL_ERR_SHIFT = 8 };
+
 template <typename SlabT> struct SlabTraits;
 template <> struct SlabTraits<float> { using zeta4 = float4; };
 template <> struct SlabTraits<double> { using zeta4 = double4; };
@@ -503,136 +508,176 @@ LT_DEV int level_window2(const double* tab, int n, double Z, const Column& C, do
   return lo - 2;
 }
 
-// per-wave LDS scratch of the batched convexity Newton pass
-#define LT_TASK_CAP 576  // 64 lanes x 3 slots x 3 intervals
+// per-wave LDS scratch of the batched passes.  Two task kinds:
+//   check: a non-evaluation interval that needs the convexity Newton iteration;
+//          only its convergence matters (SigErr), so the task is just T;
+//   eval:  the evaluation interval needs Newton: the task carries the interval
+//          so that the lane that iterates also evaluates HVAL.
+#define LT_CHK_CAP 256
+#define LT_EV_CAP 128
 struct WaveScratch {
-  double task[LT_TASK_CAP];          // in: T ; out: sigma
-  unsigned short owner[LT_TASK_CAP]; // lane | slot << 6
+  double chk[LT_CHK_CAP];            // T
+  unsigned short chk_owner[LT_CHK_CAP];
+  double ev[LT_EV_CAP][8];           // T,x1,x2,y1,p1,p2,S,Pz ; out: [0] = H(Pz)
+  unsigned short ev_owner[LT_EV_CAP];
   unsigned int errmask[64];          // bit s: slot s of this lane hit SigErr
 };
 
-// state of one slot between the classify pass and the evaluation pass
-struct SlotFit {
-  double x1, x2, y1, p1, p2, S, sig;
-  int pend;   // task index of the evaluation interval's sigma, or -1
-};
-
-// One slot of WCTS_ITPI by the reference's own straight-line code (YPC1 + SIGS
-// + HVAL or the linint fallback): used when the batched pass reports SigErr or
-// the level window is degenerate.  Out of line: rare.
-template <typename SlabT>
-__device__ __noinline__ double slot_slow(const SlabT* F, int n1, int n2, int n3, int n4, int L,
-                                         int k0, int ps, int regime, int node_hit, double wt,
-                                         double wu, double W1, double W2, double W3, double W4,
-                                         double az0, double az1, double az2, double az3,
-                                         double Pzs) {
-  QuadWeights w;
-  w.regime = regime; w.node_hit = node_hit; w.t = wt; w.u = wu;
-  w.W1 = W1; w.W2 = W2; w.W3 = W3; w.W4 = W4;
-  double az[4] = {az0, az1, az2, az3}, av[4];
-#pragma unroll
-  for (int l = 0; l < 4; l++)
-    av[l] = apply_interp(w, fld(F, n1, L, k0 + l, ps), fld(F, n2, L, k0 + l, ps),
-                         fld(F, n3, L, k0 + l, ps), fld(F, n4, L, k0 + l, ps));
-  int dummy = 0;
-  return spline4_eval(az, av, Pzs, dummy);
+// pass B: the queued Newton iterations, 64 at a time, all lanes of the wave
+LT_DEV void run_tasks(WaveScratch& ws, int nchk, int nev, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+  for (int t = lane; t < nchk; t += 64) {
+    bool failed;
+    (void)sigs_newton(ws.chk[t], failed);
+    if (failed) {
+      unsigned short o = ws.chk_owner[t];
+      atomicOr(&ws.errmask[o & 63], 1u << (o >> 6));
+    }
+  }
+#pragma unroll 1
+  for (int t = lane; t < nev; t += 64) {
+    bool failed = false;
+    const double* e = ws.ev[t];
+    const unsigned short o = ws.ev_owner[t];
+    double sg;
+    if (o & 0x100) sg = sigs_secant(e[6], e[4], e[5]);  // monotonicity secant (rare)
+    else sg = sigs_newton(e[0], failed);
+    double r = hval_interval_s(e[7], e[1], e[2], e[3], e[4], e[5], e[6], sg);
+    ws.ev[t][0] = r;
+    if (failed) atomicOr(&ws.errmask[o & 63], 1u << ((o >> 6) & 3));
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // find_currents, LTRANS.f90:1422-1614, executed by the WHOLE wave: lanes whose
-// particle is not tracked (act = false) only take part in the cooperative
-// Newton pass.
+// particle is not tracked (act = false) only take part in the cooperative pass.
+// Per-particle constants of the water column are read from the step workspace
+// (coalesced, L2-resident) where needed instead of living in registers.
 template <typename SlabT>
-LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& ws, bool act,
-                          const Column& C, int4 rn, int4 un, int4 vn, double Xs, double Ys,
-                          double Zs, int version, double& Uad, double& Vad, double& Wad,
-                          int& sigerr_count) {
+LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& ws, bool act, int n,
+                          double h, double Xs, double Ys, double Zs, int version, double& Uad,
+                          double& Vad, double& Wad, int& sigerr_count, bool& slow) {
   const double* rtab = lev;
   const double* wtab = lev + 3 * LT_LEV_STRIDE;
   const int lane = threadIdx.x & 63;
+  const size_t N = (size_t)P.numpar;
+  const double* wsd = P.ws_d + (act ? n : 0);
   const double ixv = (version == 1) ? P.ix0 : (version == 2) ? P.ix1 : P.ix2;
   Uad = 0.0; Vad = 0.0; Wad = 0.0;
   // regime tests :1481-1491
   bool zero = false, loglayer = false;
   int ii = 1, iii = 1;
+  double wzb1 = 0.0;
   if (act) {
-    zero = (Zs < C.wz1[0] + P.z0) || (Zs < C.wz1[1] + P.z0) || (Zs < C.wz1[2] + P.z0);
-    loglayer = !zero && ((Zs < C.z1[0]) || (Zs < C.z1[1]) || (Zs < C.z1[2]));
+    const double zb = wsd[(size_t)WS_ZETA0 * N], zc = wsd[(size_t)WS_ZETA1 * N], zf = wsd[(size_t)WS_ZETA2 * N];
+    const LevCoef w1 = level_coef(wtab, 1, h, P.hc, P.Vtransform);
+    const LevCoef r1 = level_coef(rtab, 1, h, P.hc, P.Vtransform);
+    wzb1 = level_at(w1, zb, h, P.Vtransform);
+    const double wzc1 = level_at(w1, zc, h, P.Vtransform), wzf1 = level_at(w1, zf, h, P.Vtransform);
+    zero = (Zs < wzb1 + P.z0) || (Zs < wzc1 + P.z0) || (Zs < wzf1 + P.z0);
+    loglayer = !zero && ((Zs < level_at(r1, zb, h, P.Vtransform)) || (Zs < level_at(r1, zc, h, P.Vtransform)) ||
+                         (Zs < level_at(r1, zf, h, P.Vtransform)));
     if (!zero && !loglayer) {
-      ii = level_window2(rtab, P.us, Zs, C, P.hc, P.Vtransform);
-      iii = level_window2(wtab, P.ws, Zs, C, P.hc, P.Vtransform);
+      // lowest 4-level windows :1451-1467 by bisection on the monotone level depths
+      int lo = 3, hi = P.us - 1;
+      while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        LevCoef q = level_coef(rtab, mid, h, P.hc, P.Vtransform);
+        bool below = (Zs < level_at(q, zb, h, P.Vtransform)) || (Zs < level_at(q, zc, h, P.Vtransform)) ||
+                     (Zs < level_at(q, zf, h, P.Vtransform));
+        if (below) hi = mid; else lo = mid + 1;
+      }
+      ii = lo - 2;
+      lo = 3; hi = P.ws - 1;
+      while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        LevCoef q = level_coef(wtab, mid, h, P.hc, P.Vtransform);
+        bool below = (Zs < level_at(q, zb, h, P.Vtransform)) || (Zs < level_at(q, zc, h, P.Vtransform)) ||
+                     (Zs < level_at(q, zf, h, P.Vtransform));
+        if (below) hi = mid; else lo = mid + 1;
+      }
+      iii = lo - 2;
     }
   }
   const bool spl = act && !zero && !loglayer;  // this lane fits splines
 #pragma unroll 1
   for (int var = 0; var < 3; var++) {
-    const int4 nd = (var == 0) ? un : (var == 1) ? vn : rn;
+    int4 nd = make_int4(1, 1, 1, 1);
     const SlabT* F = (const SlabT*)((var == 0) ? P.U : (var == 1) ? P.V : P.W);
     const int L = (var == 2) ? P.ws : P.us;
     const double* tab = (var == 2) ? wtab : rtab;
     const int k0 = (var == 2) ? iii : ii;
     QuadWeights w;
     w.regime = 1; w.node_hit = 0; w.t = w.u = w.W1 = w.W2 = w.W3 = w.W4 = 0.0;
+    // results per slot: value, or (pending) index of the eval task that will hold it
     double Pv0 = 0.0, Pv1 = 0.0, Pv2 = 0.0;
+    int pend0 = -1, pend1 = -1, pend2 = -1;
     if (act && !zero) {
-      Quad q = (var == 2) ? load_quad_rho(P.rnode, nd)
-                          : load_quad_xy((var == 0) ? P.unode : P.vnode, nd);
+      Quad q;
+      if (var == 2) { nd = P.RE[P.P_r_element[n] - 1]; q = load_quad_rho(P.rnode, nd); }
+      else if (var == 0) { nd = P.UE[P.P_u_element[n] - 1]; q = load_quad_xy(P.unode, nd); }
+      else { nd = P.VE[P.P_v_element[n] - 1]; q = load_quad_xy(P.vnode, nd); }
       w = quad_weights(Xs, Ys, q.x, q.y);
     }
     if (loglayer) {
       // log layer :1493-1522: level 1 of u,v; level 2 of w
       const int k = (var == 2) ? 2 : 1;
+      const LevCoef qt = level_coef((var == 2) ? wtab : rtab, k, h, P.hc, P.Vtransform);
 #pragma unroll
       for (int s = 0; s < 3; s++) {
         const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
+        const double zeta = wsd[(size_t)(WS_ZETA0 + s) * N];
         double val = apply_interp(w, fld(F, nd.x, L, k, ps), fld(F, nd.y, L, k, ps),
                                   fld(F, nd.z, L, k, ps), fld(F, nd.w, L, k, ps));
-        double ztop = (var == 2) ? level_z(wtab, 2, C.zeta[s], C.h, P.hc, P.Vtransform) : C.z1[s];
-        double r = val * log10((Zs - C.wz1[0]) / P.z0) / log10((ztop - C.wz1[0]) / P.z0);
+        double ztop = level_at(qt, zeta, h, P.Vtransform);
+        double r = val * log10((Zs - wzb1) / P.z0) / log10((ztop - wzb1) / P.z0);
         if (s == 0) Pv0 = r; else if (s == 1) Pv1 = r; else Pv2 = r;
       }
     }
     // ---------------- pass A: fit without iterating, queue Newton tasks
-    SlotFit fit0, fit1, fit2;
-    fit0.x1 = fit0.x2 = fit0.y1 = fit0.p1 = fit0.p2 = fit0.S = fit0.sig = 0.0; fit0.pend = -1;
-    fit1 = fit0; fit2 = fit0;
     LevCoef lc[4];
     unsigned slowmask = 0;
-    int ntask = 0;  // wave-uniform
+    int nchk = 0, nev = 0;  // wave-uniform
     ws.errmask[lane] = 0;
+    const SlabT *b0 = F, *b1 = F, *b2 = F, *b3 = F;
     if (spl) {
 #pragma unroll
-      for (int l = 0; l < 4; l++) lc[l] = level_coef(tab, k0 + l, C.h, P.hc, P.Vtransform);
-    }
-    // field window: 4 nodes x (4 levels x 3 slots) contiguous values per node
-    SlabT f[4][12];
-    if (spl) {
-      const SlabT* b0 = F + ((size_t)(nd.x - 1) * L + (k0 - 1)) * 3;
-      const SlabT* b1 = F + ((size_t)(nd.y - 1) * L + (k0 - 1)) * 3;
-      const SlabT* b2 = F + ((size_t)(nd.z - 1) * L + (k0 - 1)) * 3;
-      const SlabT* b3 = F + ((size_t)(nd.w - 1) * L + (k0 - 1)) * 3;
-#pragma unroll
-      for (int j = 0; j < 12; j++) { f[0][j] = b0[j]; f[1][j] = b1[j]; f[2][j] = b2[j]; f[3][j] = b3[j]; }
+      for (int l = 0; l < 4; l++) lc[l] = level_coef(tab, k0 + l, h, P.hc, P.Vtransform);
+      b0 = F + ((size_t)(nd.x - 1) * L + (k0 - 1)) * 3;
+      b1 = F + ((size_t)(nd.y - 1) * L + (k0 - 1)) * 3;
+      b2 = F + ((size_t)(nd.z - 1) * L + (k0 - 1)) * 3;
+      b3 = F + ((size_t)(nd.w - 1) * L + (k0 - 1)) * 3;
     }
 #pragma unroll 1
     for (int s = 0; s < 3; s++) {
+      if (nchk > LT_CHK_CAP - 128 || nev > LT_EV_CAP - 64) {
+        // scratch nearly full (rare): run what is queued and collect the results
+        run_tasks(ws, nchk, nev, lane);
+        if (pend0 >= 0) { Pv0 = ws.ev[pend0][0]; pend0 = -1; }
+        if (pend1 >= 0) { Pv1 = ws.ev[pend1][0]; pend1 = -1; }
+        if (pend2 >= 0) { Pv2 = ws.ev[pend2][0]; pend2 = -1; }
+        __builtin_amdgcn_wave_barrier();
+        nchk = 0; nev = 0;
+      }
       const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
-      double X[4], Y[4], YP[4], SL[3];
+      double YP[4], SL[3];
+      double x1 = 0.0, x2 = 0.0, y1 = 0.0, p1 = 0.0, p2 = 0.0, Sv = 0.0, Pzs = 0.0, r = 0.0;
       int I = 1;
       bool ok = spl;
-      SlotFit cur;
-      cur.x1 = cur.x2 = cur.y1 = cur.p1 = cur.p2 = cur.S = cur.sig = 0.0;
-      cur.pend = -1;
       if (spl) {
-        const double zeta = (s == 0) ? C.zeta[0] : (s == 1) ? C.zeta[1] : C.zeta[2];
-        const double Pzs = (s == 0) ? C.Pz[0] : (s == 1) ? C.Pz[1] : C.Pz[2];
+        const double zeta = wsd[(size_t)(WS_ZETA0 + s) * N];
+        Pzs = wsd[(size_t)(WS_PZ0 + s) * N];
+        double X[4], Y[4];
 #pragma unroll
         for (int l = 0; l < 4; l++) {
-          X[l] = level_at(lc[l], zeta, C.h, P.Vtransform);
-          double v1 = (double)((ps == 0) ? f[0][3 * l] : (ps == 1) ? f[0][3 * l + 1] : f[0][3 * l + 2]);
-          double v2 = (double)((ps == 0) ? f[1][3 * l] : (ps == 1) ? f[1][3 * l + 1] : f[1][3 * l + 2]);
-          double v3 = (double)((ps == 0) ? f[2][3 * l] : (ps == 1) ? f[2][3 * l + 1] : f[2][3 * l + 2]);
-          double v4 = (double)((ps == 0) ? f[3][3 * l] : (ps == 1) ? f[3][3 * l + 1] : f[3][3 * l + 2]);
-          Y[l] = apply_interp(w, v1, v2, v3, v4);
+          X[l] = level_at(lc[l], zeta, h, P.Vtransform);
+          Y[l] = apply_interp(w, (double)b0[3 * l + ps], (double)b1[3 * l + ps],
+                              (double)b2[3 * l + ps], (double)b3[3 * l + ps]);
         }
         const double DX1 = X[1] - X[0], DX2 = X[2] - X[1], DX3 = X[3] - X[2];
         ok = (DX1 > 0.0) && (DX2 > 0.0) && (DX3 > 0.0);
@@ -647,79 +692,60 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
         YP[3] = ypc1_end(SL[2], SL[2] + DX3 * (SL[2] - SL[1]) / (DX2 + DX3));
         I = (Pzs < X[1]) ? 1 : (Pzs < X[2]) ? 2 : 3;
         if (Pzs > X[3]) I = 3;
-        cur.x1 = (I == 1) ? X[0] : (I == 2) ? X[1] : X[2];
-        cur.x2 = (I == 1) ? X[1] : (I == 2) ? X[2] : X[3];
-        cur.y1 = (I == 1) ? Y[0] : (I == 2) ? Y[1] : Y[2];
-        cur.p1 = (I == 1) ? YP[0] : (I == 2) ? YP[1] : YP[2];
-        cur.p2 = (I == 1) ? YP[1] : (I == 2) ? YP[2] : YP[3];
-        cur.S = (I == 1) ? SL[0] : (I == 2) ? SL[1] : SL[2];
+        x1 = (I == 1) ? X[0] : (I == 2) ? X[1] : X[2];
+        x2 = (I == 1) ? X[1] : (I == 2) ? X[2] : X[3];
+        y1 = (I == 1) ? Y[0] : (I == 2) ? Y[1] : Y[2];
+        p1 = (I == 1) ? YP[0] : (I == 2) ? YP[1] : YP[2];
+        p2 = (I == 1) ? YP[1] : (I == 2) ? YP[2] : YP[3];
+        Sv = (I == 1) ? SL[0] : (I == 2) ? SL[1] : SL[2];
       }
-      // SIGS: classify the three intervals (tension_module.f90:448-776)
+      // SIGS: classify the three intervals (tension_module.f90:448-776).  Only the
+      // evaluation interval's tension is ever used by HVAL; the other two matter
+      // only through SigErr, which only the convexity Newton iteration can raise.
+      int pend = -1;
+      bool evdone = false;
+      double sigI = 0.0;
 #pragma unroll
       for (int iv = 0; iv < 3; iv++) {
         double sigma = 0.0, T = 0.0;
         int kind = SIGK_DONE;
-        if (ok) {
-          kind = sigs_classify(SL[iv], YP[iv], YP[iv + 1], sigma, T);
-          if (kind == SIGK_SECANT) sigma = sigs_secant(SL[iv], YP[iv], YP[iv + 1]);
+        if (ok) kind = sigs_classify(SL[iv], YP[iv], YP[iv + 1], sigma, T);
+        const bool isev = ok && (iv + 1 == I);
+        const bool needc = ok && (kind == SIGK_NEWTON) && !isev;
+        const bool neede = isev && (kind != SIGK_DONE);
+        const unsigned long long mc = __ballot(needc), me = __ballot(neede);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (needc) {
+          const int idx = nchk + __popcll(mc & below);
+          ws.chk[idx] = T;
+          ws.chk_owner[idx] = (unsigned short)(lane | (s << 6));
         }
-        const bool need = ok && (kind == SIGK_NEWTON);
-        const unsigned long long m = __ballot(need);
-        const int idx = ntask + __popcll(m & ((1ull << lane) - 1ull));
-        if (need) {
-          ws.task[idx] = T;
-          ws.owner[idx] = (unsigned short)(lane | (s << 6));
+        if (neede) {
+          const int idx = nev + __popcll(me & below);
+          double* e = ws.ev[idx];
+          e[0] = T; e[1] = x1; e[2] = x2; e[3] = y1; e[4] = p1; e[5] = p2; e[6] = Sv; e[7] = Pzs;
+          ws.ev_owner[idx] = (unsigned short)(lane | (s << 6) | ((kind == SIGK_SECANT) ? 0x100 : 0));
+          pend = idx;
         }
-        ntask += __popcll(m);
-        if (ok && iv + 1 == I) {
-          cur.sig = sigma;
-          cur.pend = need ? idx : -1;
-        }
+        nchk += __popcll(mc);
+        nev += __popcll(me);
+        if (isev && kind == SIGK_DONE) { evdone = true; sigI = sigma; }
       }
-      if (s == 0) fit0 = cur; else if (s == 1) fit1 = cur; else fit2 = cur;
+      // HVAL now when the evaluation interval's tension is already known
+      if (evdone) r = hval_interval_s(Pzs, x1, x2, y1, p1, p2, Sv, sigI);
+      if (s == 0) { Pv0 = spl ? r : Pv0; pend0 = pend; }
+      else if (s == 1) { Pv1 = spl ? r : Pv1; pend1 = pend; }
+      else { Pv2 = spl ? r : Pv2; pend2 = pend; }
     }
-    // ---------------- pass B: the queued Newton iterations, 64 at a time
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll 1
-    for (int t = lane; t < ntask; t += 64) {
-      bool failed;
-      double sg = sigs_newton(ws.task[t], failed);
-      ws.task[t] = sg;
-      if (failed) {
-        unsigned short o = ws.owner[t];
-        atomicOr(&ws.errmask[o & 63], 1u << (o >> 6));
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---------------- pass C: evaluate at P_z{b,c,f}
+    // ---------------- pass B + C
+    run_tasks(ws, nchk, nev, lane);
     if (spl) {
+      if (pend0 >= 0) Pv0 = ws.ev[pend0][0];
+      if (pend1 >= 0) Pv1 = ws.ev[pend1][0];
+      if (pend2 >= 0) Pv2 = ws.ev[pend2][0];
       const unsigned em = ws.errmask[lane];
-      slowmask |= em;
       if (em) sigerr_count += __popc(em);
-#pragma unroll 1
-      for (int s = 0; s < 3; s++) {
-        double r;
-        const double zeta = (s == 0) ? C.zeta[0] : (s == 1) ? C.zeta[1] : C.zeta[2];
-        const double Pzs = (s == 0) ? C.Pz[0] : (s == 1) ? C.Pz[1] : C.Pz[2];
-        if (slowmask & (1u << s)) {
-          const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
-          r = slot_slow<SlabT>(F, nd.x, nd.y, nd.z, nd.w, L, k0, ps, w.regime, w.node_hit, w.t,
-                               w.u, w.W1, w.W2, w.W3, w.W4,
-                               level_at(lc[0], zeta, C.h, P.Vtransform),
-                               level_at(lc[1], zeta, C.h, P.Vtransform),
-                               level_at(lc[2], zeta, C.h, P.Vtransform),
-                               level_at(lc[3], zeta, C.h, P.Vtransform), Pzs);
-        } else {
-          const SlotFit ft = (s == 0) ? fit0 : (s == 1) ? fit1 : fit2;
-          double sg = (ft.pend >= 0) ? ws.task[ft.pend] : ft.sig;
-          r = hval_interval_s(Pzs, ft.x1, ft.x2, ft.y1, ft.p1, ft.p2, ft.S, sg);
-        }
-        if (s == 0) Pv0 = r; else if (s == 1) Pv1 = r; else Pv2 = r;
-      }
+      if (slowmask | em) slow = true;  // this particle-step is redone by k_rk_slow
     }
     // the next variable reuses the scratch: all lanes must have read their results
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -741,9 +767,6 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
 //   k_pre   gates, setEle, setInterp/getInterp, vertical clamps   (per lane)
 //   k_rk    RK4 over find_currents/WCTS_ITPI                      (wave-cooperative)
 //   k_post  behaviour, reflection, boundaries, setEle, settlement, commit
-enum { WS_PDEPTH = 0, WS_COSA, WS_SINA, WS_ZETA0, WS_ZETA1, WS_ZETA2, WS_PZ0, WS_PZ1, WS_PZ2,
-       WS_ZPAR, WS_SUMU, WS_SUMV, WS_SUMW, WS_NDOUBLE };
-enum { FL_ACT = 1, FL_KEEP_PN = 2, FL_ERR_SHIFT = 8 };
 
 template <typename SlabT>
 __global__ __launch_bounds__(256) void k_pre(const StepParams P) {
@@ -844,56 +867,174 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_rk(const StepParams P) 
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   const size_t N = (size_t)P.numpar;
   const bool act = (n < P.numpar) && ((P.ws_i[n] & FL_ACT) != 0);
-  double X = 0.0, Y = 0.0, Zpar = 0.0, cosA = 1.0, sinA = 0.0, maxpartdepth = 0.0, minpartdepth = 0.0;
-  int4 rn = make_int4(1, 1, 1, 1), un = rn, vn = rn;
-  Column C;
-  C.h = 1.0;
-#pragma unroll
-  for (int s = 0; s < 3; s++) { C.zeta[s] = 0.0; C.Pz[s] = 0.0; C.wz1[s] = 0.0; C.z1[s] = 0.0; }
+  const double* wsd = P.ws_d + (act ? n : 0);
+  double h = 1.0, Xs = 0.0, Ys = 0.0, Zs = 0.0;
   if (act) {
-    const double* wsd = P.ws_d + n;
-    X = P.par[(size_t)pX * N + n];
-    Y = P.par[(size_t)pY * N + n];
-    rn = P.RE[P.P_r_element[n] - 1];
-    un = P.UE[P.P_u_element[n] - 1];
-    vn = P.VE[P.P_v_element[n] - 1];
-    C.h = -1.0 * wsd[(size_t)WS_PDEPTH * N];
-    cosA = wsd[(size_t)WS_COSA * N];
-    sinA = wsd[(size_t)WS_SINA * N];
-    C.zeta[0] = wsd[(size_t)WS_ZETA0 * N]; C.zeta[1] = wsd[(size_t)WS_ZETA1 * N]; C.zeta[2] = wsd[(size_t)WS_ZETA2 * N];
-    C.Pz[0] = wsd[(size_t)WS_PZ0 * N]; C.Pz[1] = wsd[(size_t)WS_PZ1 * N]; C.Pz[2] = wsd[(size_t)WS_PZ2 * N];
-    Zpar = wsd[(size_t)WS_ZPAR * N];
-    const double* rtab = lev;
-    const double* wtab = lev + 3 * LT_LEV_STRIDE;
-    const LevCoef w1 = level_coef(wtab, 1, C.h, P.hc, P.Vtransform);
-    const LevCoef r1c = level_coef(rtab, 1, C.h, P.hc, P.Vtransform);
-    const LevCoef wN = level_coef(wtab, P.ws, C.h, P.hc, P.Vtransform);
-#pragma unroll
-    for (int s = 0; s < 3; s++) {
-      C.wz1[s] = level_at(w1, C.zeta[s], C.h, P.Vtransform);
-      C.z1[s] = level_at(r1c, C.zeta[s], C.h, P.Vtransform);
-    }
-    double t0 = level_at(wN, C.zeta[0], C.h, P.Vtransform);
-    double t1 = level_at(wN, C.zeta[1], C.h, P.Vtransform);
-    double t2 = level_at(wN, C.zeta[2], C.h, P.Vtransform);
-    maxpartdepth = C.wz1[0];
-    if (C.wz1[1] > maxpartdepth) maxpartdepth = C.wz1[1];
-    if (C.wz1[2] > maxpartdepth) maxpartdepth = C.wz1[2];
-    minpartdepth = t0;
-    if (t1 < minpartdepth) minpartdepth = t1;
-    if (t2 < minpartdepth) minpartdepth = t2;
+    h = -1.0 * wsd[(size_t)WS_PDEPTH * N];
+    Xs = P.par[(size_t)pX * N + n];
+    Ys = P.par[(size_t)pY * N + n];
+    Zs = wsd[(size_t)WS_ZPAR * N];
   }
   // RK4 :990-1053, executed by the whole wave
   double sumU = 0.0, sumV = 0.0, sumW = 0.0;
   int sigerr_count = 0;
+  bool slow = false;
   WaveScratch& ws = wsc[threadIdx.x >> 6];
-  double Xs = X, Ys = Y, Zs = Zpar;
 #pragma unroll 1
   for (int st = 0; st < 4; st++) {
     const int version = (st == 0) ? 1 : (st == 3) ? 3 : 2;
     double Uad, Vad, Wad;
-    find_currents<SlabT>(P, lev, ws, act, C, rn, un, vn, Xs, Ys, Zs, version, Uad, Vad, Wad,
-                         sigerr_count);
+    find_currents<SlabT>(P, lev, ws, act, n, h, Xs, Ys, Zs, version, Uad, Vad, Wad, sigerr_count, slow);
+    if (st == 0) { sumU = Uad; sumV = Vad; sumW = Wad; }
+    else if (st == 3) { sumU = sumU + Uad; sumV = sumV + Vad; sumW = sumW + Wad; }
+    else { sumU = sumU + 2.0 * Uad; sumV = sumV + 2.0 * Vad; sumW = sumW + 2.0 * Wad; }
+    if (st < 3 && act) {
+      // next RK position :999-1035; the per-particle constants come back from
+      // the workspace / par (coalesced) instead of staying in registers
+      const double X = P.par[(size_t)pX * N + n], Y = P.par[(size_t)pY * N + n];
+      const double Zpar = wsd[(size_t)WS_ZPAR * N];
+      const double cosA = wsd[(size_t)WS_COSA * N], sinA = wsd[(size_t)WS_SINA * N];
+      const double dtf = (double)P.idt;
+      if (st < 2) {
+        Xs = X + (Uad * cosA - Vad * sinA) * dtf / 2.0;
+        Ys = Y + (Uad * sinA + Vad * cosA) * dtf / 2.0;
+        Zs = Zpar + Wad * dtf / 2.0;
+      } else {
+        Xs = X + (Uad * cosA - Vad * sinA) * dtf;
+        Ys = Y + (Uad * sinA + Vad * cosA) * dtf;
+        Zs = Zpar + Wad * dtf;
+      }
+      // maxpartdepth / minpartdepth :981-987
+      const double* wtab = lev + 3 * LT_LEV_STRIDE;
+      const LevCoef w1 = level_coef(wtab, 1, h, P.hc, P.Vtransform);
+      const LevCoef wN = level_coef(wtab, P.ws, h, P.hc, P.Vtransform);
+      const double zb = wsd[(size_t)WS_ZETA0 * N], zc = wsd[(size_t)WS_ZETA1 * N], zf = wsd[(size_t)WS_ZETA2 * N];
+      double maxpartdepth = level_at(w1, zb, h, P.Vtransform);
+      double t1 = level_at(w1, zc, h, P.Vtransform), t2 = level_at(w1, zf, h, P.Vtransform);
+      if (t1 > maxpartdepth) maxpartdepth = t1;
+      if (t2 > maxpartdepth) maxpartdepth = t2;
+      double minpartdepth = level_at(wN, zb, h, P.Vtransform);
+      t1 = level_at(wN, zc, h, P.Vtransform); t2 = level_at(wN, zf, h, P.Vtransform);
+      if (t1 < minpartdepth) minpartdepth = t1;
+      if (t2 < minpartdepth) minpartdepth = t2;
+      if (Zs > minpartdepth) Zs = minpartdepth - (double)0.000001f;
+      if (Zs < maxpartdepth) Zs = maxpartdepth + (double)0.000001f;
+    }
+  }
+  if (act) {
+    double* wso = P.ws_d + n;
+    wso[(size_t)WS_SUMU * N] = sumU;
+    wso[(size_t)WS_SUMV * N] = sumV;
+    wso[(size_t)WS_SUMW * N] = sumW;
+    if (slow) P.ws_i[n] |= FL_SLOW;
+  }
+  unsigned v = (unsigned)sigerr_count;
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(&P.counters[CNT_SIGERR], (unsigned long long)v);
+}
+
+// ---- k_rk_slow: the particle-steps k_rk could not finish on its fast path
+// (a SigErr in some spline fit, or a degenerate level window) are redone here
+// by a straight per-lane transcription of find_currents / WCTS_ITPI
+// (LTRANS.f90:1422-1614, hydrodynamic_module.f90:2577-2689): YPC1, the SIGS
+// interval loop with its early RETURN, HVAL or the linint fallback.
+template <typename SlabT>
+LT_DEV void find_currents_ref(const StepParams& P, const double* lev, const Column& C, int4 rn,
+                              int4 un, int4 vn, double Xs, double Ys, double Zs, int version,
+                              double& Uad, double& Vad, double& Wad) {
+  const double* rtab = lev;
+  const double* wtab = lev + 3 * LT_LEV_STRIDE;
+  const double ixv = (version == 1) ? P.ix0 : (version == 2) ? P.ix1 : P.ix2;
+  if ((Zs < C.wz1[0] + P.z0) || (Zs < C.wz1[1] + P.z0) || (Zs < C.wz1[2] + P.z0)) {
+    Uad = 0.0; Vad = 0.0; Wad = 0.0;
+    return;
+  }
+  const bool loglayer = (Zs < C.z1[0]) || (Zs < C.z1[1]) || (Zs < C.z1[2]);
+  const int ii = level_window(rtab, P.us, Zs, C.zeta[0], C.zeta[1], C.zeta[2], C.h, P.hc, P.Vtransform);
+  const int iii = level_window(wtab, P.ws, Zs, C.zeta[0], C.zeta[1], C.zeta[2], C.h, P.hc, P.Vtransform);
+#pragma unroll 1
+  for (int var = 0; var < 3; var++) {
+    const int4 nd = (var == 0) ? un : (var == 1) ? vn : rn;
+    Quad q = (var == 2) ? load_quad_rho(P.rnode, nd)
+                        : load_quad_xy((var == 0) ? P.unode : P.vnode, nd);
+    const QuadWeights w = quad_weights(Xs, Ys, q.x, q.y);
+    const SlabT* F = (const SlabT*)((var == 0) ? P.U : (var == 1) ? P.V : P.W);
+    const int L = (var == 2) ? P.ws : P.us;
+    const double* tab = (var == 2) ? wtab : rtab;
+    double Pv0 = 0.0, Pv1 = 0.0, Pv2 = 0.0;
+#pragma unroll 1
+    for (int s = 0; s < 3; s++) {
+      const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
+      const double zeta = (s == 0) ? C.zeta[0] : (s == 1) ? C.zeta[1] : C.zeta[2];
+      double r;
+      if (loglayer) {
+        const int k = (var == 2) ? 2 : 1;
+        double val = apply_interp(w, fld(F, nd.x, L, k, ps), fld(F, nd.y, L, k, ps),
+                                  fld(F, nd.z, L, k, ps), fld(F, nd.w, L, k, ps));
+        const double z1s = (s == 0) ? C.z1[0] : (s == 1) ? C.z1[1] : C.z1[2];
+        double ztop = (var == 2) ? level_z(wtab, 2, zeta, C.h, P.hc, P.Vtransform) : z1s;
+        r = val * log10((Zs - C.wz1[0]) / P.z0) / log10((ztop - C.wz1[0]) / P.z0);
+      } else {
+        const int k0 = (var == 2) ? iii : ii;
+        const double Pzs = (s == 0) ? C.Pz[0] : (s == 1) ? C.Pz[1] : C.Pz[2];
+        double az[4], av[4];
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+          az[l] = level_z(tab, k0 + l, zeta, C.h, P.hc, P.Vtransform);
+          av[l] = apply_interp(w, fld(F, nd.x, L, k0 + l, ps), fld(F, nd.y, L, k0 + l, ps),
+                               fld(F, nd.z, L, k0 + l, ps), fld(F, nd.w, L, k0 + l, ps));
+        }
+        int dummy = 0;
+        r = spline4_eval(az, av, Pzs, dummy);
+      }
+      if (s == 0) Pv0 = r; else if (s == 1) Pv1 = r; else Pv2 = r;
+    }
+    double e1 = Pv0, e2 = (P.p == 1) ? Pv0 : Pv1, e3 = (P.p == 1) ? Pv1 : Pv2;
+    double val = polintd3(P.ex0, P.ex1, P.ex2, e1, e2, e3, ixv);
+    if (var == 0) Uad = val; else if (var == 1) Vad = val; else Wad = val;
+  }
+}
+
+template <typename SlabT>
+__global__ __launch_bounds__(256) void k_rk_slow(const StepParams P) {
+  __shared__ double lev[6 * LT_LEV_STRIDE];
+  for (int i = threadIdx.x; i < 6 * LT_LEV_STRIDE; i += blockDim.x) lev[i] = P.lev[i];
+  __syncthreads();
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= P.numpar) return;
+  if (!(P.ws_i[n] & FL_SLOW)) return;
+  const size_t N = (size_t)P.numpar;
+  double* wsd = P.ws_d + n;
+  const double X = P.par[(size_t)pX * N + n], Y = P.par[(size_t)pY * N + n];
+  const double Zpar = wsd[(size_t)WS_ZPAR * N];
+  const double cosA = wsd[(size_t)WS_COSA * N], sinA = wsd[(size_t)WS_SINA * N];
+  const int4 rn = P.RE[P.P_r_element[n] - 1], un = P.UE[P.P_u_element[n] - 1],
+             vn = P.VE[P.P_v_element[n] - 1];
+  Column C;
+  C.h = -1.0 * wsd[(size_t)WS_PDEPTH * N];
+#pragma unroll
+  for (int s = 0; s < 3; s++) {
+    C.zeta[s] = wsd[(size_t)(WS_ZETA0 + s) * N];
+    C.Pz[s] = wsd[(size_t)(WS_PZ0 + s) * N];
+    C.wz1[s] = level_z(lev + 3 * LT_LEV_STRIDE, 1, C.zeta[s], C.h, P.hc, P.Vtransform);
+    C.z1[s] = level_z(lev, 1, C.zeta[s], C.h, P.hc, P.Vtransform);
+  }
+  double maxpartdepth = C.wz1[0];
+  if (C.wz1[1] > maxpartdepth) maxpartdepth = C.wz1[1];
+  if (C.wz1[2] > maxpartdepth) maxpartdepth = C.wz1[2];
+  double minpartdepth = level_z(lev + 3 * LT_LEV_STRIDE, P.ws, C.zeta[0], C.h, P.hc, P.Vtransform);
+  {
+    double t1 = level_z(lev + 3 * LT_LEV_STRIDE, P.ws, C.zeta[1], C.h, P.hc, P.Vtransform);
+    double t2 = level_z(lev + 3 * LT_LEV_STRIDE, P.ws, C.zeta[2], C.h, P.hc, P.Vtransform);
+    if (t1 < minpartdepth) minpartdepth = t1;
+    if (t2 < minpartdepth) minpartdepth = t2;
+  }
+  double sumU = 0.0, sumV = 0.0, sumW = 0.0, Xs = X, Ys = Y, Zs = Zpar;
+#pragma unroll 1
+  for (int st = 0; st < 4; st++) {
+    const int version = (st == 0) ? 1 : (st == 3) ? 3 : 2;
+    double Uad, Vad, Wad;
+    find_currents_ref<SlabT>(P, lev, C, rn, un, vn, Xs, Ys, Zs, version, Uad, Vad, Wad);
     if (st == 0) { sumU = Uad; sumV = Vad; sumW = Wad; }
     else if (st == 3) { sumU = sumU + Uad; sumV = sumV + Vad; sumW = sumW + Wad; }
     else { sumU = sumU + 2.0 * Uad; sumV = sumV + 2.0 * Vad; sumW = sumW + 2.0 * Wad; }
@@ -912,15 +1053,9 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_rk(const StepParams P) 
       if (Zs < maxpartdepth) Zs = maxpartdepth + (double)0.000001f;
     }
   }
-  if (act) {
-    double* wsd = P.ws_d + n;
-    wsd[(size_t)WS_SUMU * N] = sumU;
-    wsd[(size_t)WS_SUMV * N] = sumV;
-    wsd[(size_t)WS_SUMW * N] = sumW;
-  }
-  unsigned v = (unsigned)sigerr_count;
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  if ((threadIdx.x & 63) == 0 && v) atomicAdd(&P.counters[CNT_SIGERR], (unsigned long long)v);
+  wsd[(size_t)WS_SUMU * N] = sumU;
+  wsd[(size_t)WS_SUMV * N] = sumV;
+  wsd[(size_t)WS_SUMW * N] = sumW;
 }
 
 __global__ __launch_bounds__(256) void k_post(const StepParams P) {
