@@ -352,6 +352,21 @@ int get_field(lt_engine* e, const DevBuf& buf, T* dst, int cols) {
   return LT_OK;
 }
 
+// k_rk is instantiated per slab type and per Vtransform (the s-level formula is
+// then straight-line code in the hot loop)
+template <typename SlabT>
+void launch_rk_t(lt_engine* e, const StepParams& P, unsigned blocks) {
+  switch (e->cfg.Vtransform) {
+    case 1: hipLaunchKernelGGL((k_rk<SlabT, 1, LT_RK_WAVES>), dim3(blocks), dim3(256), 0, e->stream, P); break;
+    case 2: hipLaunchKernelGGL((k_rk<SlabT, 2, LT_RK_WAVES>), dim3(blocks), dim3(256), 0, e->stream, P); break;
+    default: hipLaunchKernelGGL((k_rk<SlabT, 3, LT_RK_WAVES>), dim3(blocks), dim3(256), 0, e->stream, P); break;
+  }
+}
+void launch_rk(lt_engine* e, const StepParams& P, unsigned blocks) {
+  if (e->cfg.slab_storage == LT_SLAB_F32) launch_rk_t<float>(e, P, blocks);
+  else launch_rk_t<double>(e, P, blocks);
+}
+
 }  // namespace
 
 extern "C" {
@@ -724,8 +739,7 @@ int lt_step(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32
     if (f32) hipLaunchKernelGGL((k_pre<float>), dim3(blocks), dim3(256), 0, e->stream, P);
     else hipLaunchKernelGGL((k_pre<double>), dim3(blocks), dim3(256), 0, e->stream, P);
     if (prof) HIPCHK(e, hipEventRecord(e->prof_ev[e->prof_used], e->stream));
-    if (f32) hipLaunchKernelGGL((k_rk<float, LT_RK_WAVES>), dim3(blocks), dim3(256), 0, e->stream, P);
-    else hipLaunchKernelGGL((k_rk<double, LT_RK_WAVES>), dim3(blocks), dim3(256), 0, e->stream, P);
+    launch_rk(e, P, blocks);
     if (prof) {
       HIPCHK(e, hipEventRecord(e->prof_ev[e->prof_used + 1], e->stream));
       e->prof_used += 2;

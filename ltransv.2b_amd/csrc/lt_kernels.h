@@ -558,7 +558,7 @@ LT_DEV void run_tasks(WaveScratch& ws, int nchk, int nev, int lane) {
 // particle is not tracked (act = false) only take part in the cooperative pass.
 // Per-particle constants of the water column are read from the step workspace
 // (coalesced, L2-resident) where needed instead of living in registers.
-template <typename SlabT>
+template <typename SlabT, int VT>
 LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& ws, bool act, int n,
                           double h, double Xs, double Ys, double Zs, int version, double& Uad,
                           double& Vad, double& Wad, int& sigerr_count, bool& slow) {
@@ -575,30 +575,30 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
   double wzb1 = 0.0;
   if (act) {
     const double zb = wsd[(size_t)WS_ZETA0 * N], zc = wsd[(size_t)WS_ZETA1 * N], zf = wsd[(size_t)WS_ZETA2 * N];
-    const LevCoef w1 = level_coef(wtab, 1, h, P.hc, P.Vtransform);
-    const LevCoef r1 = level_coef(rtab, 1, h, P.hc, P.Vtransform);
-    wzb1 = level_at(w1, zb, h, P.Vtransform);
-    const double wzc1 = level_at(w1, zc, h, P.Vtransform), wzf1 = level_at(w1, zf, h, P.Vtransform);
+    const LevCoef w1 = level_coef(wtab, 1, h, P.hc, VT);
+    const LevCoef r1 = level_coef(rtab, 1, h, P.hc, VT);
+    wzb1 = level_at(w1, zb, h, VT);
+    const double wzc1 = level_at(w1, zc, h, VT), wzf1 = level_at(w1, zf, h, VT);
     zero = (Zs < wzb1 + P.z0) || (Zs < wzc1 + P.z0) || (Zs < wzf1 + P.z0);
-    loglayer = !zero && ((Zs < level_at(r1, zb, h, P.Vtransform)) || (Zs < level_at(r1, zc, h, P.Vtransform)) ||
-                         (Zs < level_at(r1, zf, h, P.Vtransform)));
+    loglayer = !zero && ((Zs < level_at(r1, zb, h, VT)) || (Zs < level_at(r1, zc, h, VT)) ||
+                         (Zs < level_at(r1, zf, h, VT)));
     if (!zero && !loglayer) {
       // lowest 4-level windows :1451-1467 by bisection on the monotone level depths
       int lo = 3, hi = P.us - 1;
       while (lo < hi) {
         int mid = (lo + hi) >> 1;
-        LevCoef q = level_coef(rtab, mid, h, P.hc, P.Vtransform);
-        bool below = (Zs < level_at(q, zb, h, P.Vtransform)) || (Zs < level_at(q, zc, h, P.Vtransform)) ||
-                     (Zs < level_at(q, zf, h, P.Vtransform));
+        LevCoef q = level_coef(rtab, mid, h, P.hc, VT);
+        bool below = (Zs < level_at(q, zb, h, VT)) || (Zs < level_at(q, zc, h, VT)) ||
+                     (Zs < level_at(q, zf, h, VT));
         if (below) hi = mid; else lo = mid + 1;
       }
       ii = lo - 2;
       lo = 3; hi = P.ws - 1;
       while (lo < hi) {
         int mid = (lo + hi) >> 1;
-        LevCoef q = level_coef(wtab, mid, h, P.hc, P.Vtransform);
-        bool below = (Zs < level_at(q, zb, h, P.Vtransform)) || (Zs < level_at(q, zc, h, P.Vtransform)) ||
-                     (Zs < level_at(q, zf, h, P.Vtransform));
+        LevCoef q = level_coef(wtab, mid, h, P.hc, VT);
+        bool below = (Zs < level_at(q, zb, h, VT)) || (Zs < level_at(q, zc, h, VT)) ||
+                     (Zs < level_at(q, zf, h, VT));
         if (below) hi = mid; else lo = mid + 1;
       }
       iii = lo - 2;
@@ -627,14 +627,14 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
     if (loglayer) {
       // log layer :1493-1522: level 1 of u,v; level 2 of w
       const int k = (var == 2) ? 2 : 1;
-      const LevCoef qt = level_coef((var == 2) ? wtab : rtab, k, h, P.hc, P.Vtransform);
+      const LevCoef qt = level_coef((var == 2) ? wtab : rtab, k, h, P.hc, VT);
 #pragma unroll
       for (int s = 0; s < 3; s++) {
         const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
         const double zeta = wsd[(size_t)(WS_ZETA0 + s) * N];
         double val = apply_interp(w, fld(F, nd.x, L, k, ps), fld(F, nd.y, L, k, ps),
                                   fld(F, nd.z, L, k, ps), fld(F, nd.w, L, k, ps));
-        double ztop = level_at(qt, zeta, h, P.Vtransform);
+        double ztop = level_at(qt, zeta, h, VT);
         double r = val * log10((Zs - wzb1) / P.z0) / log10((ztop - wzb1) / P.z0);
         if (s == 0) Pv0 = r; else if (s == 1) Pv1 = r; else Pv2 = r;
       }
@@ -647,7 +647,7 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
     const SlabT *b0 = F, *b1 = F, *b2 = F, *b3 = F;
     if (spl) {
 #pragma unroll
-      for (int l = 0; l < 4; l++) lc[l] = level_coef(tab, k0 + l, h, P.hc, P.Vtransform);
+      for (int l = 0; l < 4; l++) lc[l] = level_coef(tab, k0 + l, h, P.hc, VT);
       b0 = F + ((size_t)(nd.x - 1) * L + (k0 - 1)) * 3;
       b1 = F + ((size_t)(nd.y - 1) * L + (k0 - 1)) * 3;
       b2 = F + ((size_t)(nd.z - 1) * L + (k0 - 1)) * 3;
@@ -675,7 +675,7 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
         double X[4], Y[4];
 #pragma unroll
         for (int l = 0; l < 4; l++) {
-          X[l] = level_at(lc[l], zeta, h, P.Vtransform);
+          X[l] = level_at(lc[l], zeta, h, VT);
           Y[l] = apply_interp(w, (double)b0[3 * l + ps], (double)b1[3 * l + ps],
                               (double)b2[3 * l + ps], (double)b3[3 * l + ps]);
         }
@@ -858,7 +858,7 @@ __global__ __launch_bounds__(256) void k_pre(const StepParams P) {
   if ((threadIdx.x & 63) == 0 && v) atomicAdd(&P.counters[CNT_ACTIVE], (unsigned long long)v);
 }
 
-template <typename SlabT, int WAVES_PER_SIMD>
+template <typename SlabT, int VT, int WAVES_PER_SIMD>
 __global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_rk(const StepParams P) {
   __shared__ double lev[6 * LT_LEV_STRIDE];
   __shared__ WaveScratch wsc[4];
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_rk(const StepParams P) 
   for (int st = 0; st < 4; st++) {
     const int version = (st == 0) ? 1 : (st == 3) ? 3 : 2;
     double Uad, Vad, Wad;
-    find_currents<SlabT>(P, lev, ws, act, n, h, Xs, Ys, Zs, version, Uad, Vad, Wad, sigerr_count, slow);
+    find_currents<SlabT, VT>(P, lev, ws, act, n, h, Xs, Ys, Zs, version, Uad, Vad, Wad, sigerr_count, slow);
     if (st == 0) { sumU = Uad; sumV = Vad; sumW = Wad; }
     else if (st == 3) { sumU = sumU + Uad; sumV = sumV + Vad; sumW = sumW + Wad; }
     else { sumU = sumU + 2.0 * Uad; sumV = sumV + 2.0 * Vad; sumW = sumW + 2.0 * Wad; }
@@ -906,15 +906,15 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_rk(const StepParams P) 
       }
       // maxpartdepth / minpartdepth :981-987
       const double* wtab = lev + 3 * LT_LEV_STRIDE;
-      const LevCoef w1 = level_coef(wtab, 1, h, P.hc, P.Vtransform);
-      const LevCoef wN = level_coef(wtab, P.ws, h, P.hc, P.Vtransform);
+      const LevCoef w1 = level_coef(wtab, 1, h, P.hc, VT);
+      const LevCoef wN = level_coef(wtab, P.ws, h, P.hc, VT);
       const double zb = wsd[(size_t)WS_ZETA0 * N], zc = wsd[(size_t)WS_ZETA1 * N], zf = wsd[(size_t)WS_ZETA2 * N];
-      double maxpartdepth = level_at(w1, zb, h, P.Vtransform);
-      double t1 = level_at(w1, zc, h, P.Vtransform), t2 = level_at(w1, zf, h, P.Vtransform);
+      double maxpartdepth = level_at(w1, zb, h, VT);
+      double t1 = level_at(w1, zc, h, VT), t2 = level_at(w1, zf, h, VT);
       if (t1 > maxpartdepth) maxpartdepth = t1;
       if (t2 > maxpartdepth) maxpartdepth = t2;
-      double minpartdepth = level_at(wN, zb, h, P.Vtransform);
-      t1 = level_at(wN, zc, h, P.Vtransform); t2 = level_at(wN, zf, h, P.Vtransform);
+      double minpartdepth = level_at(wN, zb, h, VT);
+      t1 = level_at(wN, zc, h, VT); t2 = level_at(wN, zf, h, VT);
       if (t1 < minpartdepth) minpartdepth = t1;
       if (t2 < minpartdepth) minpartdepth = t2;
       if (Zs > minpartdepth) Zs = minpartdepth - (double)0.000001f;
