@@ -509,45 +509,52 @@ LT_DEV int level_window2(const double* tab, int n, double Z, const Column& C, do
 }
 
 // per-wave LDS scratch of the batched passes.  Two task kinds:
-//   check: a non-evaluation interval that needs the convexity Newton iteration;
-//          only its convergence matters (SigErr), so the task is just T;
-//   eval:  the evaluation interval needs Newton: the task carries the interval
-//          so that the lane that iterates also evaluates HVAL.
+//   check: a non-evaluation interval that may need the convexity Newton
+//          iteration; only its convergence matters (SigErr): (num, den) of T;
+//   eval:  the evaluation interval's tension is not known without iterating:
+//          the task carries the interval, the lane that iterates evaluates HVAL.
+// Results of all 9 (variable, slot) fits of a stage are collected in res[][lane].
 #define LT_CHK_CAP 256
 #define LT_EV_CAP 128
 struct WaveScratch {
-  double chk[LT_CHK_CAP];            // T
-  unsigned short chk_owner[LT_CHK_CAP];
-  double ev[LT_EV_CAP][8];           // T,x1,x2,y1,p1,p2,S,Pz ; out: [0] = H(Pz)
+  double chk[LT_CHK_CAP][2];         // num, den of T = MAX(D1/D2, D2/D1)
+  unsigned short chk_owner[LT_CHK_CAP];  // lane | slot9 << 6
+  double ev[LT_EV_CAP][7];           // x1,x2,y1,p1,p2,S,Pz
   unsigned short ev_owner[LT_EV_CAP];
-  unsigned int errmask[64];          // bit s: slot s of this lane hit SigErr
+  double res[9][64];                 // H(P_z) per (variable*3+slot, lane)
+  unsigned int errmask[64];          // bit (variable*3+slot): SigErr / degenerate window
 };
 
-// pass B: the queued Newton iterations, 64 at a time, all lanes of the wave
+// pass B: the queued iterations, 64 at a time, all lanes of the wave
 LT_DEV void run_tasks(WaveScratch& ws, int nchk, int nev, int lane) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll 1
   for (int t = lane; t < nchk; t += 64) {
-    bool failed;
-    (void)sigs_newton(ws.chk[t], failed);
-    if (failed) {
-      unsigned short o = ws.chk_owner[t];
-      atomicOr(&ws.errmask[o & 63], 1u << (o >> 6));
+    // a non-evaluation interval: only the convergence of its Newton iteration matters
+    const double T = ws.chk[t][0] / ws.chk[t][1];
+    if (T > 2.0) {
+      bool failed;
+      (void)sigs_newton(T, failed);
+      if (failed) {
+        unsigned short o = ws.chk_owner[t];
+        atomicOr(&ws.errmask[o & 63], 1u << (o >> 6));
+      }
     }
   }
 #pragma unroll 1
   for (int t = lane; t < nev; t += 64) {
+    // the evaluation interval: full SIGS decision, then HVAL
     bool failed = false;
     const double* e = ws.ev[t];
     const unsigned short o = ws.ev_owner[t];
-    double sg;
-    if (o & 0x100) sg = sigs_secant(e[6], e[4], e[5]);  // monotonicity secant (rare)
-    else sg = sigs_newton(e[0], failed);
-    double r = hval_interval_s(e[7], e[1], e[2], e[3], e[4], e[5], e[6], sg);
-    ws.ev[t][0] = r;
-    if (failed) atomicOr(&ws.errmask[o & 63], 1u << ((o >> 6) & 3));
+    double sg, T;
+    const int kind = sigs_classify(e[5], e[3], e[4], sg, T);
+    if (kind == SIGK_NEWTON) sg = sigs_newton(T, failed);
+    else if (kind == SIGK_SECANT) sg = sigs_secant(e[5], e[3], e[4]);  // rare
+    ws.res[o >> 6][o & 63] = hval_interval_s(e[6], e[0], e[1], e[2], e[3], e[4], e[5], sg);
+    if (failed) atomicOr(&ws.errmask[o & 63], 1u << (o >> 6));
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -567,7 +574,6 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
   const int lane = threadIdx.x & 63;
   const size_t N = (size_t)P.numpar;
   const double* wsd = P.ws_d + (act ? n : 0);
-  const double ixv = (version == 1) ? P.ix0 : (version == 2) ? P.ix1 : P.ix2;
   Uad = 0.0; Vad = 0.0; Wad = 0.0;
   // regime tests :1481-1491
   bool zero = false, loglayer = false;
@@ -605,6 +611,10 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
     }
   }
   const bool spl = act && !zero && !loglayer;  // this lane fits splines
+  int nchk = 0, nev = 0;  // wave-uniform task counts of this stage
+  unsigned degenerate = 0;
+  ws.errmask[lane] = 0;
+  // ---------------- pass A: fit without iterating, queue what must iterate
 #pragma unroll 1
   for (int var = 0; var < 3; var++) {
     int4 nd = make_int4(1, 1, 1, 1);
@@ -614,9 +624,6 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
     const int k0 = (var == 2) ? iii : ii;
     QuadWeights w;
     w.regime = 1; w.node_hit = 0; w.t = w.u = w.W1 = w.W2 = w.W3 = w.W4 = 0.0;
-    // results per slot: value, or (pending) index of the eval task that will hold it
-    double Pv0 = 0.0, Pv1 = 0.0, Pv2 = 0.0;
-    int pend0 = -1, pend1 = -1, pend2 = -1;
     if (act && !zero) {
       Quad q;
       if (var == 2) { nd = P.RE[P.P_r_element[n] - 1]; q = load_quad_rho(P.rnode, nd); }
@@ -635,15 +642,10 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
         double val = apply_interp(w, fld(F, nd.x, L, k, ps), fld(F, nd.y, L, k, ps),
                                   fld(F, nd.z, L, k, ps), fld(F, nd.w, L, k, ps));
         double ztop = level_at(qt, zeta, h, VT);
-        double r = val * log10((Zs - wzb1) / P.z0) / log10((ztop - wzb1) / P.z0);
-        if (s == 0) Pv0 = r; else if (s == 1) Pv1 = r; else Pv2 = r;
+        ws.res[var * 3 + s][lane] = val * log10((Zs - wzb1) / P.z0) / log10((ztop - wzb1) / P.z0);
       }
     }
-    // ---------------- pass A: fit without iterating, queue Newton tasks
     LevCoef lc[4];
-    unsigned slowmask = 0;
-    int nchk = 0, nev = 0;  // wave-uniform
-    ws.errmask[lane] = 0;
     const SlabT *b0 = F, *b1 = F, *b2 = F, *b3 = F;
     if (spl) {
 #pragma unroll
@@ -656,17 +658,13 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
 #pragma unroll 1
     for (int s = 0; s < 3; s++) {
       if (nchk > LT_CHK_CAP - 128 || nev > LT_EV_CAP - 64) {
-        // scratch nearly full (rare): run what is queued and collect the results
-        run_tasks(ws, nchk, nev, lane);
-        if (pend0 >= 0) { Pv0 = ws.ev[pend0][0]; pend0 = -1; }
-        if (pend1 >= 0) { Pv1 = ws.ev[pend1][0]; pend1 = -1; }
-        if (pend2 >= 0) { Pv2 = ws.ev[pend2][0]; pend2 = -1; }
-        __builtin_amdgcn_wave_barrier();
+        run_tasks(ws, nchk, nev, lane);  // scratch nearly full (rare): run what is queued
         nchk = 0; nev = 0;
       }
+      const int slot9 = var * 3 + s;
       const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
       double YP[4], SL[3];
-      double x1 = 0.0, x2 = 0.0, y1 = 0.0, p1 = 0.0, p2 = 0.0, Sv = 0.0, Pzs = 0.0, r = 0.0;
+      double x1 = 0.0, x2 = 0.0, y1 = 0.0, p1 = 0.0, p2 = 0.0, Sv = 0.0, Pzs = 0.0;
       int I = 1;
       bool ok = spl;
       if (spl) {
@@ -681,7 +679,7 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
         }
         const double DX1 = X[1] - X[0], DX2 = X[2] - X[1], DX3 = X[3] - X[2];
         ok = (DX1 > 0.0) && (DX2 > 0.0) && (DX3 > 0.0);
-        if (!ok) slowmask |= (1u << s);
+        if (!ok) degenerate |= (1u << slot9);
         // YPC1 (tension_module.f90:852-977) with the chord slopes kept for SIGS/HVAL
         SL[0] = (Y[1] - Y[0]) / DX1;
         SL[1] = (Y[2] - Y[1]) / DX2;
@@ -699,64 +697,69 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
         p2 = (I == 1) ? YP[1] : (I == 2) ? YP[2] : YP[3];
         Sv = (I == 1) ? SL[0] : (I == 2) ? SL[1] : SL[2];
       }
-      // SIGS: classify the three intervals (tension_module.f90:448-776).  Only the
-      // evaluation interval's tension is ever used by HVAL; the other two matter
-      // only through SigErr, which only the convexity Newton iteration can raise.
-      int pend = -1;
+      // SIGS (tension_module.f90:448-776), screened without divisions or loops.
+      // Only the evaluation interval's tension is used by HVAL; the other two
+      // matter only through SigErr, which only the convexity Newton iteration
+      // can raise, so they are queued just when they are Newton candidates.
       bool evdone = false;
       double sigI = 0.0;
-#pragma unroll
-      for (int iv = 0; iv < 3; iv++) {
-        double sigma = 0.0, T = 0.0;
-        int kind = SIGK_DONE;
-        if (ok) kind = sigs_classify(SL[iv], YP[iv], YP[iv + 1], sigma, T);
-        const bool isev = ok && (iv + 1 == I);
-        const bool needc = ok && (kind == SIGK_NEWTON) && !isev;
-        const bool neede = isev && (kind != SIGK_DONE);
-        const unsigned long long mc = __ballot(needc), me = __ballot(neede);
+      {
+        double n0, d0, n1, d1, n2, d2;
+        const bool c0 = ok && sigs_candidate(SL[0], YP[0], YP[1], n0, d0);
+        const bool c1 = ok && sigs_candidate(SL[1], YP[1], YP[2], n1, d1);
+        const bool c2 = ok && sigs_candidate(SL[2], YP[2], YP[3], n2, d2);
+        // the two non-evaluation intervals: I=1 -> (2,3), I=2 -> (1,3), I=3 -> (1,2)
+        const bool ca = (I == 1) ? c1 : c0, cb = (I == 3) ? c1 : c2;
+        const double na = (I == 1) ? n1 : n0, da = (I == 1) ? d1 : d0;
+        const double nb = (I == 3) ? n1 : n2, db = (I == 3) ? d1 : d2;
+        if (ok) evdone = sigs_eval_known(Sv, p1, p2, sigI);
+        const bool neede = ok && !evdone;
+        const unsigned long long ma = __ballot(ca), mb = __ballot(cb), me = __ballot(neede);
         const unsigned long long below = (1ull << lane) - 1ull;
-        if (needc) {
-          const int idx = nchk + __popcll(mc & below);
-          ws.chk[idx] = T;
-          ws.chk_owner[idx] = (unsigned short)(lane | (s << 6));
+        if (ca) {
+          const int idx = nchk + __popcll(ma & below);
+          ws.chk[idx][0] = na; ws.chk[idx][1] = da;
+          ws.chk_owner[idx] = (unsigned short)(lane | (slot9 << 6));
         }
+        nchk += __popcll(ma);
+        if (cb) {
+          const int idx = nchk + __popcll(mb & below);
+          ws.chk[idx][0] = nb; ws.chk[idx][1] = db;
+          ws.chk_owner[idx] = (unsigned short)(lane | (slot9 << 6));
+        }
+        nchk += __popcll(mb);
         if (neede) {
           const int idx = nev + __popcll(me & below);
           double* e = ws.ev[idx];
-          e[0] = T; e[1] = x1; e[2] = x2; e[3] = y1; e[4] = p1; e[5] = p2; e[6] = Sv; e[7] = Pzs;
-          ws.ev_owner[idx] = (unsigned short)(lane | (s << 6) | ((kind == SIGK_SECANT) ? 0x100 : 0));
-          pend = idx;
+          e[0] = x1; e[1] = x2; e[2] = y1; e[3] = p1; e[4] = p2; e[5] = Sv; e[6] = Pzs;
+          ws.ev_owner[idx] = (unsigned short)(lane | (slot9 << 6));
         }
-        nchk += __popcll(mc);
         nev += __popcll(me);
-        if (isev && kind == SIGK_DONE) { evdone = true; sigI = sigma; }
       }
       // HVAL now when the evaluation interval's tension is already known
-      if (evdone) r = hval_interval_s(Pzs, x1, x2, y1, p1, p2, Sv, sigI);
-      if (s == 0) { Pv0 = spl ? r : Pv0; pend0 = pend; }
-      else if (s == 1) { Pv1 = spl ? r : Pv1; pend1 = pend; }
-      else { Pv2 = spl ? r : Pv2; pend2 = pend; }
+      if (evdone) ws.res[slot9][lane] = hval_interval_s(Pzs, x1, x2, y1, p1, p2, Sv, sigI);
     }
-    // ---------------- pass B + C
-    run_tasks(ws, nchk, nev, lane);
-    if (spl) {
-      if (pend0 >= 0) Pv0 = ws.ev[pend0][0];
-      if (pend1 >= 0) Pv1 = ws.ev[pend1][0];
-      if (pend2 >= 0) Pv2 = ws.ev[pend2][0];
-      const unsigned em = ws.errmask[lane];
-      if (em) sigerr_count += __popc(em);
-      if (slowmask | em) slow = true;  // this particle-step is redone by k_rk_slow
-    }
-    // the next variable reuses the scratch: all lanes must have read their results
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // time interpolation :1534-1598 / hydrodynamic_module.f90:2653-2670
-    if (act && !zero) {
+  }
+  // ---------------- pass B: everything that iterates, once per stage
+  run_tasks(ws, nchk, nev, lane);
+  // ---------------- pass C: time interpolation :1534-1598 / hydrodynamic_module.f90:2653-2670
+  if (act && !zero) {
+    const unsigned em = ws.errmask[lane];
+    if (em) sigerr_count += __popc(em);
+    if (spl && (degenerate | em)) slow = true;  // this particle-step is redone by k_rk_slow
+    const double ixv = (version == 1) ? P.ix0 : (version == 2) ? P.ix1 : P.ix2;
+#pragma unroll
+    for (int var = 0; var < 3; var++) {
+      const double Pv0 = ws.res[var * 3 + 0][lane], Pv1 = ws.res[var * 3 + 1][lane],
+                   Pv2 = ws.res[var * 3 + 2][lane];
       double e1 = Pv0, e2 = (P.p == 1) ? Pv0 : Pv1, e3 = (P.p == 1) ? Pv1 : Pv2;
       double val = polintd3(P.ex0, P.ex1, P.ex2, e1, e2, e3, ixv);
       if (var == 0) Uad = val; else if (var == 1) Vad = val; else Wad = val;
     }
   }
+  // the next stage reuses the scratch: all lanes must have read their results
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
 }
 
 // ------------------------------------------------------------ the step

@@ -446,6 +446,40 @@ LT_DEV int sigs_classify(double S, double S1, double S2, double& sigma, double& 
   return SIGK_SECANT;
 }
 
+// Division-free screening of one SIGS interval.  Newton CANDIDATE: the data
+// are convex on the interval (D1*D2 > 0) and the larger second difference
+// exceeds twice the smaller, i.e. T = MAX(D1/D2,D2/D1) is not certainly <= 2.
+// num/den are the operands of the one quotient that equals T.
+LT_DEV bool sigs_candidate(double S, double S1, double S2, double& num, double& den) {
+  const double D1 = S - S1, D2 = S2 - S;
+  const double a = fabs(D1), b = fabs(D2);
+  const bool ab = a > b;
+  num = ab ? D1 : D2;
+  den = ab ? D2 : D1;
+  return (D1 * D2 > 0.0) && ((ab ? a : b) > 2.0 * (ab ? b : a));
+}
+
+// Screening of the EVALUATION interval: true = its tension factor is known
+// without iterating (sigma = 0 or SBIG); false = needs sigs_classify + an
+// iteration (done by the batched pass).
+LT_DEV bool sigs_eval_known(double S, double S1, double S2, double& sigma) {
+  const double D1 = S - S1, D2 = S2 - S, D1D2 = D1 * D2;
+  sigma = 0.0;
+  if ((D1D2 == 0.0 && S1 != S2) || (S == 0.0 && S1 * S2 > 0.0)) {
+    sigma = LT_SBIG;
+    return true;
+  }
+  if (D1D2 >= 0.0) {
+    if (D1D2 == 0.0) return true;
+    const double a = fabs(D1), b = fabs(D2);
+    return ((a > b) ? a : b) <= 2.0 * ((a > b) ? b : a);
+  }
+  if (S1 * S < 0.0 || S2 * S < 0.0) return true;
+  const double T0 = 3.0 * S - S1 - S2;
+  const double D0 = T0 * T0 - S1 * S2;
+  return (D0 <= 0.0 || S * T0 >= 0.0);
+}
+
 // convexity Newton iteration, tension_module.f90:531-580.  Returns the tension
 // factor; failed = true when the iteration count exceeds 10000 (SigErr).
 LT_DEV double sigs_newton(double T, bool& failed) {
