@@ -104,10 +104,10 @@ LT_DEV Quad load_quad_rho(const RhoNode* nodes, int4 n) {
 // contains the point (the reference then reports error 4/5/6).
 template <bool RHO>
 LT_DEV bool find_element(const void* nodes, const int4* EL, const int* Adj, double X, double Y,
-                         int& ele, int4& nd) {
+                         int& ele, int4& nd, int first = 0) {
   int cand = ele;
 #pragma unroll 1
-  for (int i = 0; i < 10; i++) {
+  for (int i = first; i < 10; i++) {
     if (i > 0) {
       cand = Adj[(size_t)(ele - 1) * 10 + i];
       if (cand == 0) break;  // zero-filled tail: nothing further to probe
@@ -122,6 +122,27 @@ LT_DEV bool find_element(const void* nodes, const int4* EL, const int* Adj, doub
   }
   nd = EL[ele - 1];
   return false;
+}
+
+// setEle for the three grids (hydrodynamic_module.f90:1462-1510) with the FIRST
+// probe of each grid (the particle's current element, almost always the hit)
+// issued together: the three dependent load chains element -> node ids -> node
+// coordinates overlap instead of running one after the other.  A grid whose
+// first probe misses continues with the neighbour walk.
+LT_DEV void find_elements3(const StepParams& P, double X, double Y, int& er, int& eu, int& ev,
+                           int4& rn, int4& un, int4& vn, bool& okr, bool& oku, bool& okv) {
+  rn = P.RE[er - 1];
+  un = P.UE[eu - 1];
+  vn = P.VE[ev - 1];
+  const Quad qr = load_quad_rho(P.rnode, rn);
+  const Quad qu = load_quad_xy(P.unode, un);
+  const Quad qv = load_quad_xy(P.vnode, vn);
+  okr = gridcell_one(qr.x, qr.y, X, Y);
+  oku = gridcell_one(qu.x, qu.y, X, Y);
+  okv = gridcell_one(qv.x, qv.y, X, Y);
+  if (!okr) okr = find_element<true>(P.rnode, P.RE, P.rAdj, X, Y, er, rn, 1);
+  if (!oku) oku = find_element<false>(P.unode, P.UE, P.uAdj, X, Y, eu, un, 1);
+  if (!okv) okv = find_element<false>(P.vnode, P.VE, P.vAdj, X, Y, ev, vn, 1);
 }
 
 // --------------------------------------------------- point in polygon
@@ -806,9 +827,8 @@ __global__ __launch_bounds__(256) void k_pre(const StepParams P) {
       int er = P.P_r_element[n], eu = P.P_u_element[n], ev = P.P_v_element[n];
       int4 rn, un, vn;
       // setEle :830 (all three grids are searched even after a miss)
-      bool okr = find_element<true>(P.rnode, P.RE, P.rAdj, X, Y, er, rn);
-      bool oku = find_element<false>(P.unode, P.UE, P.uAdj, X, Y, eu, un);
-      bool okv = find_element<false>(P.vnode, P.VE, P.vAdj, X, Y, ev, vn);
+      bool okr, oku, okv;
+      find_elements3(P, X, Y, er, eu, ev, rn, un, vn, okr, oku, okv);
       P.P_r_element[n] = er; P.P_u_element[n] = eu; P.P_v_element[n] = ev;
       if (!okv) err = 6; else if (!oku) err = 5; else if (!okr) err = 4;  // last assignment wins
       if (err == 0) {
@@ -1177,10 +1197,9 @@ __global__ __launch_bounds__(256) void k_post(const StepParams P) {
             nX = newXpos; nY = newYpos; nZ = newZpos;  // :1312-1314
             // setEle on the new position :1317
             int er = P.P_r_element[n], eu = P.P_u_element[n], ev = P.P_v_element[n];
-            int4 nd;
-            bool okr2 = find_element<true>(P.rnode, P.RE, P.rAdj, nXpos, nYpos, er, nd);
-            bool oku2 = find_element<false>(P.unode, P.UE, P.uAdj, nXpos, nYpos, eu, nd);
-            bool okv2 = find_element<false>(P.vnode, P.VE, P.vAdj, nXpos, nYpos, ev, nd);
+            int4 nr, nu, nv;
+            bool okr2, oku2, okv2;
+            find_elements3(P, nXpos, nYpos, er, eu, ev, nr, nu, nv, okr2, oku2, okv2);
             P.P_r_element[n] = er; P.P_u_element[n] = eu; P.P_v_element[n] = ev;
             if (!okv2) err = 29; else if (!oku2) err = 28; else if (!okr2) err = 27;
             if (err == 0 && P.settlementon) {

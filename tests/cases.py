@@ -16,6 +16,10 @@ CASES = {
                       numpar=608, near_land=0.2, cfg=dict(Behavior=0)),
     "mid_adv": dict(grid=(128, 64, 30), islands=[], numpar=20000, near_land=0.1,
                     cfg=dict(Behavior=0)),
+    "tiny_vt2": dict(grid=(24, 16, 8), islands=[(10, 12, 6, 8)], numpar=512, near_land=0.3,
+                     cfg=dict(Behavior=0, Vtransform=2, hc=5.0)),
+    "tiny_vt3": dict(grid=(24, 16, 8), islands=[(10, 12, 6, 8)], numpar=512, near_land=0.3,
+                     cfg=dict(Behavior=0, Vtransform=3)),
     # uniform drift into the west/south coast and the island: many reflections
     "tiny_reflect": dict(grid=(24, 16, 8), islands=[(10, 12, 6, 8)], numpar=768, near_land=0.6,
                          drift=(-0.35, -0.25), cfg=dict(Behavior=0)),

@@ -34,7 +34,7 @@ def _check(hip, ora):
     return err
 
 
-@pytest.mark.parametrize("name", ["tiny_adv", "tiny_sink", "small_adv"])
+@pytest.mark.parametrize("name", ["tiny_adv", "tiny_sink", "small_adv", "tiny_vt2", "tiny_vt3"])
 def test_parity_two_external_steps(name):
     case = cases.build_case(name)
     hip, ora = _both(case, n_external=2)
