@@ -19,6 +19,7 @@
 #define LT_RK_WAVES 1
 #endif
 #include "lt_kernels.h"
+#include "lt_mt.h"
 
 using namespace ltd;
 
@@ -66,10 +67,18 @@ struct lt_engine {
   bool sort_particles = true;
   DevBuf par, pr, pu, pv, P_behave, dead, oob, settle, endpoly, hitBottom, hitLand, err_code,
       P_swim, P_pediage, P_deadage, settletime;
-  // rng (host copy of the state; turbulence kernels are not part of this build yet)
+  // rng: the reference's single serial MT19937 stream, materialised on the device
+  // in blocks (lt_mt.h).  Stream word k ("virtual stream"): k < 624 -> mt[k] of the
+  // state given at start, k >= 624 -> generated; the cursor starts at mti.
   uint32_t mt[624];
   int32_t mti = 624;
   int64_t rng_before = 0, rng_total = -1;
+  bool rng_ready = false;
+  uint64_t rng_cur = 624;          // next stream word to be consumed
+  long long rng_next_block = 0;    // next block to generate
+  int rng_P = 128;                 // generator states
+  int rng_R = 0;                   // ring capacity in blocks (power of two)
+  DevBuf rng_states, rng_ring, rng_gJ;
   // counters
   DevBuf counters;
   unsigned long long* h_counters = nullptr;  // pinned
@@ -352,6 +361,94 @@ int get_field(lt_engine* e, const DevBuf& buf, T* dst, int cols) {
   return LT_OK;
 }
 
+// ---- device MT19937 stream --------------------------------------------------
+constexpr int RNG_LOG2_S = 20;
+constexpr size_t RNG_S = (size_t)1 << RNG_LOG2_S;  // words per block
+
+const ltmt::Poly& mt_phi() {
+  static const ltmt::Poly phi = ltmt::characteristic_polynomial();
+  return phi;
+}
+
+int rng_configure_kernels(lt_engine* e) {
+  static bool done = false;
+  if (!done) {
+    HIPCHK(e, hipFuncSetAttribute((const void*)ltmt::k_mt_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ltmt::LDS_BYTES));
+    HIPCHK(e, hipFuncSetAttribute((const void*)ltmt::k_mt_jump, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ltmt::LDS_BYTES));
+    done = true;
+  }
+  return LT_OK;
+}
+
+// position the P generator states: state p at stream position p*S (p >= 1), state 0
+// = the given mt array (position 624; block 0 starts with those words themselves)
+int rng_init_device(lt_engine* e) {
+  TRY(rng_configure_kernels(e));
+  const int P = e->rng_P;
+  const ltmt::Poly& phi = mt_phi();
+  if (phi.empty()) return fail(e, LT_ERR_DEVICE, "MT19937 characteristic polynomial failed");
+  std::vector<uint32_t> g0 = ltmt::jump_polynomial(phi, RNG_S - 624);
+  std::vector<uint32_t> gS = ltmt::jump_polynomial(phi, RNG_S);
+  std::vector<uint32_t> gJ = ltmt::jump_polynomial(phi, (uint64_t)(P - 1) * RNG_S);
+  DevBuf d_g0, d_gS;
+  TRY(upload(e, d_g0, g0.data(), g0.size() * 4));
+  TRY(upload(e, d_gS, gS.data(), gS.size() * 4));
+  TRY(upload(e, e->rng_gJ, gJ.data(), gJ.size() * 4));
+  TRY(dev_alloc(e, e->rng_states, (size_t)P * 624 * 4));
+  HIPCHK(e, hipMemcpyAsync(e->rng_states.p, e->mt, 624 * 4, hipMemcpyHostToDevice, e->stream));
+  for (int p = 1; p < P; p++) {
+    hipLaunchKernelGGL(ltmt::k_mt_jump, dim3(1), dim3(256), ltmt::LDS_BYTES, e->stream,
+                       (uint32_t*)e->rng_states.p, p - 1, p,
+                       (const uint32_t*)(p == 1 ? d_g0.p : d_gS.p));
+  }
+  HIPCHK(e, hipGetLastError());
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  (void)hipFree(d_g0.p);
+  (void)hipFree(d_gS.p);
+  e->rng_next_block = 0;
+  e->rng_cur = (uint64_t)e->mti;
+  e->rng_ready = true;
+  return LT_OK;
+}
+
+// make stream words [first, last] resident in the ring
+int rng_ensure(lt_engine* e, uint64_t first, uint64_t last) {
+  if (!e->rng_ready) TRY(rng_init_device(e));
+  const long long b_lo = (long long)(first >> RNG_LOG2_S) - 1;  // keep one block of history
+  const long long b_hi = (long long)(last >> RNG_LOG2_S);
+  long long need = b_hi - std::max<long long>(b_lo, 0) + 2;
+  int R = 4;
+  while (R < need) R <<= 1;
+  if (R > e->rng_R) {
+    // (re)allocate the ring; blocks still needed are regenerated from scratch only
+    // when the ring is first created, otherwise copied into the larger ring
+    DevBuf nr;
+    TRY(dev_alloc(e, nr, (size_t)R * RNG_S * 4));
+    if (e->rng_ring.p) {
+      for (long long b = std::max<long long>(b_lo, 0); b < e->rng_next_block; b++) {
+        HIPCHK(e, hipMemcpyAsync((uint32_t*)nr.p + (size_t)(b % R) * RNG_S,
+                                 (uint32_t*)e->rng_ring.p + (size_t)(b % e->rng_R) * RNG_S,
+                                 RNG_S * 4, hipMemcpyDeviceToDevice, e->stream));
+      }
+      HIPCHK(e, hipStreamSynchronize(e->stream));
+      (void)hipFree(e->rng_ring.p);
+    }
+    e->rng_ring = nr;
+    e->rng_R = R;
+  }
+  while (e->rng_next_block <= b_hi) {
+    const int P = e->rng_P;
+    long long nb = std::min<long long>(P, b_hi - e->rng_next_block + 1);
+    hipLaunchKernelGGL(ltmt::k_mt_block, dim3((unsigned)nb), dim3(256), ltmt::LDS_BYTES, e->stream,
+                       (uint32_t*)e->rng_states.p, (uint32_t*)e->rng_ring.p, e->rng_next_block,
+                       std::max<long long>(b_lo, 0), P,
+                       e->rng_R, (const uint32_t*)e->rng_gJ.p, (int)RNG_S, P > 1 ? 1 : 0);
+    HIPCHK(e, hipGetLastError());
+    e->rng_next_block += nb;
+  }
+  return LT_OK;
+}
+
 // k_rk is instantiated per slab type and per Vtransform (the s-level formula is
 // then straight-line code in the hot loop)
 template <typename SlabT>
@@ -438,7 +535,7 @@ int lt_destroy(lt_engine* e) {
                     &e->ep_ptr, &e->ep_ids, &e->ph_ptr, &e->ph_ids, &e->par, &e->pr, &e->pu,
                     &e->pv, &e->P_behave, &e->dead, &e->oob, &e->settle, &e->endpoly,
                     &e->hitBottom, &e->hitLand, &e->err_code, &e->P_swim, &e->P_pediage,
-                    &e->P_deadage, &e->settletime, &e->counters, &e->ws_d, &e->ws_i, &e->orig};
+                    &e->P_deadage, &e->settletime, &e->counters, &e->ws_d, &e->ws_i, &e->orig, &e->rng_states, &e->rng_ring, &e->rng_gJ};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
@@ -678,13 +775,74 @@ int lt_set_rng(lt_engine* e, const int32_t* mt624, int32_t mti) {
   if (!e || !mt624 || mti < 0 || mti > 624) return LT_ERR_ARG;
   for (int i = 0; i < 624; i++) e->mt[i] = (uint32_t)mt624[i];
   e->mti = mti;
+  e->rng_ready = false;  // the generator states are re-positioned at the next use
+  e->rng_cur = (uint64_t)mti;
+  e->rng_next_block = 0;
   return LT_OK;
 }
 
 int lt_get_rng(lt_engine* e, int32_t* mt624, int32_t* mti) {
   if (!e || !mt624 || !mti) return LT_ERR_ARG;
-  for (int i = 0; i < 624; i++) mt624[i] = (int32_t)e->mt[i];
-  *mti = e->mti;
+  if (!e->rng_ready || e->rng_cur <= 624) {
+    // nothing (or only words of the given array) consumed: the array is still the state
+    for (int i = 0; i < 624; i++) mt624[i] = (int32_t)e->mt[i];
+    *mti = (int32_t)(e->rng_ready ? e->rng_cur : (uint64_t)e->mti);
+    return LT_OK;
+  }
+  // the 624 raw words before the cursor are the history window: as an mt array with
+  // mti = 624 the reference's genrand regenerates exactly the words that follow
+  HIPCHK(e, hipSetDevice(e->device));
+  TRY(rng_ensure(e, e->rng_cur - 624, e->rng_cur - 1));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  const size_t ringw = (size_t)e->rng_R * RNG_S;
+  for (int i = 0; i < 624; i++) {
+    uint64_t k = e->rng_cur - 624 + i;
+    uint32_t w;
+    HIPCHK(e, hipMemcpy(&w, (uint32_t*)e->rng_ring.p + (k % ringw), 4, hipMemcpyDeviceToHost));
+    mt624[i] = (int32_t)w;
+  }
+  *mti = 624;
+  return LT_OK;
+}
+
+/* test aid (host only, no device): n tempered words of the stream that starts at
+ * the given (mt, mti) state, beginning `offset` words after the next draw, computed
+ * with the polynomial jump-ahead that positions the device generators. */
+int lt_test_mt_stream(const int32_t* mt624, int32_t mti, uint64_t offset, int32_t n, uint32_t* out) {
+  if (!mt624 || !out || mti < 0 || mti > 624 || n < 0) return LT_ERR_ARG;
+  const ltmt::Poly& phi = mt_phi();
+  if (phi.empty()) return LT_ERR_DEVICE;
+  std::vector<uint32_t> h(624), w(624);
+  for (int i = 0; i < 624; i++) h[i] = (uint32_t)mt624[i];
+  uint64_t k = (uint64_t)mti + offset;  // virtual stream index of the first word wanted
+  int i = 0;
+  while (i < n && k < 624) out[i++] = ltmt::temper(h[k++]);
+  if (i == n) return LT_OK;
+  std::vector<uint32_t> g = ltmt::jump_polynomial(phi, k - 624);
+  ltmt::host_jump(h.data(), g.data(), w.data());
+  int p = 0;
+  while (i < n) out[i++] = ltmt::temper(ltmt::host_next(w.data(), p));
+  return LT_OK;
+}
+
+/* test aid (device): n tempered words of the engine's stream starting `offset` words
+ * after the cursor, read back from the materialised ring. */
+int lt_test_mt_ring(lt_engine* e, uint64_t offset, int32_t n, uint32_t* out) {
+  if (!e || !out || n < 0) return LT_ERR_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  if (!e->rng_ready) TRY(rng_init_device(e));
+  const uint64_t first = e->rng_cur + offset;
+  TRY(rng_ensure(e, first, first + (uint64_t)n));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  const size_t ringw = (size_t)e->rng_R * RNG_S;
+  std::vector<uint32_t> tmp(n);
+  for (int i = 0; i < n;) {
+    size_t pos = (size_t)((first + i) % ringw);
+    size_t run = std::min<size_t>((size_t)(n - i), ringw - pos);
+    HIPCHK(e, hipMemcpy(tmp.data() + i, (uint32_t*)e->rng_ring.p + pos, run * 4, hipMemcpyDeviceToHost));
+    i += (int)run;
+  }
+  for (int i = 0; i < n; i++) out[i] = ltmt::temper(tmp[i]);
   return LT_OK;
 }
 

@@ -1,0 +1,269 @@
+// lt_mt.h -- the reference's single serial Mersenne-Twister stream
+// (random_module.f90:86-197, MT19937 of Matsumoto & Nishimura) produced in
+// parallel on the device, bit-identical to sequential generation.
+//
+// The reference draws every random number of a run from ONE generator in
+// particle order.  Here the same stream is MATERIALISED in HBM in blocks of
+// LT_MT_BLOCK raw words: block b holds stream words [b*S, (b+1)*S).  P
+// generator workgroups each own the blocks b = p (mod P): after writing its
+// block (which advances its state by S words) a workgroup jumps ahead by
+// (P-1)*S words with the polynomial method of Haramoto, Matsumoto, Nishimura,
+// Panneton & L'Ecuyer (2008): F^J s = g(F) s with g(x) = x^J mod phi(x), phi =
+// characteristic polynomial of the MT19937 recurrence (degree 19937), evaluated
+// as  XOR_{i: g_i = 1} window_i(E)  over the sequence E generated from s.
+//
+// State representation ("history window"): h[0..623] = the 624 most recent raw
+// words; the next raw word is  h[397] ^ twist(h[0], h[1]).  Only the top bit of
+// h[0] is ever used again, so the 31 low bits of h[0] (the part of the state the
+// polynomial identity does not preserve) are irrelevant to every later output.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+namespace ltmt {
+
+constexpr int N = 624, M = 397;
+constexpr int DEG = 19937;
+constexpr int GW = 624;  // uint32 words that hold a polynomial of degree < 19968
+
+__host__ __device__ inline uint32_t twist(uint32_t a, uint32_t b) {
+  uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+  return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+__host__ __device__ inline uint32_t temper(uint32_t y) {  // random_module.f90:190-193
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
+
+// ------------------------------------------------------------------ host side
+// GF(2) polynomials as little-endian bit arrays in uint64 words.
+using Poly = std::vector<uint64_t>;
+inline bool pbit(const Poly& p, int i) { return (p[i >> 6] >> (i & 63)) & 1ull; }
+inline void pflip(Poly& p, int i) { p[i >> 6] ^= 1ull << (i & 63); }
+
+// advance a history window by one word (host reference of the device code)
+inline uint32_t host_next(uint32_t* h, int& p) {  // circular, p = index of h[0]
+  uint32_t nw = h[(p + M) % N] ^ twist(h[p], h[(p + 1) % N]);
+  h[p] = nw;
+  p = (p + 1) % N;
+  return nw;
+}
+
+// characteristic polynomial of the recurrence by Berlekamp-Massey on one output
+// bit of 2*DEG+2 consecutive words; phi[i] = coefficient of x^i, degree DEG
+inline Poly characteristic_polynomial() {
+  const int LEN = 2 * DEG + 64;
+  std::vector<uint32_t> h(N);
+  h[0] = 5489u;
+  for (int i = 1; i < N; i++) h[i] = 1812433253u * (h[i - 1] ^ (h[i - 1] >> 30)) + (uint32_t)i;
+  int p = 0;
+  std::vector<uint8_t> s(LEN);
+  for (int i = 0; i < LEN; i++) s[i] = (uint8_t)(host_next(h.data(), p) & 1u);
+  const int W = (DEG + 64 + 63) / 64 + 1;
+  Poly C(W, 0), B(W, 0), T(W, 0), srev(W, 0);
+  C[0] = 1; B[0] = 1;
+  int L = 0, m = 1;
+  for (int n = 0; n < LEN; n++) {
+    // srev bit j = s[n-j]
+    uint64_t carry = s[n];
+    for (int w = 0; w < W; w++) {
+      uint64_t nc = srev[w] >> 63;
+      srev[w] = (srev[w] << 1) | carry;
+      carry = nc;
+    }
+    uint64_t acc = 0;
+    const int lw = (L >> 6) + 1;
+    for (int w = 0; w < lw && w < W; w++) acc ^= C[w] & srev[w];
+    int d = __builtin_parityll(acc);
+    if (!d) { m++; continue; }
+    auto xor_shift = [&](Poly& dst, const Poly& src, int sh) {  // dst ^= src << sh
+      int ws = sh >> 6, bs = sh & 63;
+      for (int w = W - 1; w >= ws; w--) {
+        uint64_t v = src[w - ws] << bs;
+        if (bs && w - ws - 1 >= 0) v |= src[w - ws - 1] >> (64 - bs);
+        dst[w] ^= v;
+      }
+    };
+    if (2 * L <= n) {
+      T = C;
+      xor_shift(C, B, m);
+      L = n + 1 - L;
+      B = T;
+      m = 1;
+    } else {
+      xor_shift(C, B, m);
+      m++;
+    }
+  }
+  // connection polynomial C (degree L) -> characteristic polynomial x^L C(1/x)
+  Poly phi((DEG + 64) / 64 + 1, 0);
+  if (L != DEG) return Poly();  // cannot happen for MT19937
+  for (int i = 0; i <= L; i++)
+    if (pbit(C, i)) pflip(phi, L - i);
+  return phi;
+}
+
+// g(x) = x^e mod phi(x) as GW uint32 words (bit i = coefficient of x^i)
+inline std::vector<uint32_t> jump_polynomial(const Poly& phi, uint64_t e) {
+  const int W2 = (2 * DEG + 64) / 64 + 2;
+  Poly r(W2, 0), t(W2, 0);
+  r[0] = 1;  // 1
+  auto reduce = [&](Poly& a, int top) {  // a mod phi, a has bits < top
+    for (int i = top - 1; i >= DEG; i--) {
+      if (!pbit(a, i)) continue;
+      int sh = i - DEG, ws = sh >> 6, bs = sh & 63;
+      for (size_t w = 0; w < phi.size() && w + ws < a.size(); w++) {
+        a[w + ws] ^= phi[w] << bs;
+        if (bs && w + ws + 1 < a.size()) a[w + ws + 1] ^= phi[w] >> (64 - bs);
+      }
+    }
+  };
+  int hb = 63;
+  while (hb > 0 && !((e >> hb) & 1ull)) hb--;
+  if (e == 0) hb = -1;
+  for (int b = hb; b >= 0; b--) {
+    // square: spread bits
+    std::fill(t.begin(), t.end(), 0);
+    for (int i = 0; i < DEG; i++)
+      if (pbit(r, i)) pflip(t, 2 * i);
+    reduce(t, 2 * DEG);
+    if ((e >> b) & 1ull) {  // multiply by x
+      uint64_t carry = 0;
+      for (size_t w = 0; w < t.size(); w++) {
+        uint64_t nc = t[w] >> 63;
+        t[w] = (t[w] << 1) | carry;
+        carry = nc;
+      }
+      reduce(t, DEG + 1);
+    }
+    r = t;
+  }
+  std::vector<uint32_t> g(GW, 0);
+  for (int i = 0; i < DEG; i++)
+    if (pbit(r, i)) g[i >> 5] |= 1u << (i & 31);
+  return g;
+}
+
+// host reference of the jump: out = g(F) h  (linear windows, h[0] oldest)
+inline void host_jump(const uint32_t* h, const uint32_t* g, uint32_t* out) {
+  std::vector<uint32_t> E(DEG + N);
+  for (int i = 0; i < N; i++) E[i] = h[i];
+  for (int i = 0; i + N < DEG + N; i++) E[i + N] = E[i + M] ^ twist(E[i], E[i + 1]);
+  for (int j = 0; j < N; j++) out[j] = 0;
+  for (int i = 0; i < DEG; i++)
+    if ((g[i >> 5] >> (i & 31)) & 1u)
+      for (int j = 0; j < N; j++) out[j] ^= E[i + j];
+}
+
+// ---------------------------------------------------------------- device side
+constexpr int CHUNK = 227 * 16;  // words generated per LDS pass (227 = N - M independent words)
+
+// window (lds[0..N)) <- g(F) window; needs DEG + N words of LDS
+__device__ inline void jump_in_lds(uint32_t* lds, const uint32_t* __restrict__ g, int tid) {
+  // E = sequence generated from the window: DEG more words
+  for (int base = 0; base < DEG; base += (N - M)) {
+    const int i = base + tid;
+    if (tid < (N - M) && i < DEG) lds[N + i] = lds[M + i] ^ twist(lds[i], lds[i + 1]);
+    __syncthreads();
+  }
+  // new window[j] = XOR_{i: g_i} E[i+j]; thread t owns j = t, t+256, t+512
+  uint32_t acc0 = 0, acc1 = 0, acc2 = 0;
+  for (int w = 0; w < GW; w++) {
+    uint32_t bits = g[w];
+    const int i0 = w * 32;
+    while (bits) {
+      const int b = __ffs(bits) - 1;
+      bits &= bits - 1;
+      const int i = i0 + b;
+      acc0 ^= lds[i + tid];
+      acc1 ^= lds[i + tid + 256];
+      if (tid + 512 < N) acc2 ^= lds[i + tid + 512];
+    }
+  }
+  __syncthreads();
+  lds[tid] = acc0;
+  lds[tid + 256] = acc1;
+  if (tid + 512 < N) lds[tid + 512] = acc2;
+  __syncthreads();
+}
+
+// One workgroup (256 threads) per generator state:
+//   1. write `count` raw stream words, starting with the word that follows the
+//      history window `state`, to out[0..count);
+//   2. leave the state advanced by `count` words, then (do_jump) jump it ahead
+//      with polynomial g.
+// Stream block 0 starts with the 624 words of the state itself (= the words
+// already in the reference's mt array, "virtual stream" V[0..623]).
+__global__ __launch_bounds__(256) void k_mt_block(uint32_t* __restrict__ states,
+                                                  uint32_t* __restrict__ ring,
+                                                  long long first_block,  // stream block of workgroup 0
+                                                  long long keep_from,    // blocks before this one are not stored
+                                                  int nstates, int ring_blocks,
+                                                  const uint32_t* __restrict__ g, int count,
+                                                  int do_jump) {
+  extern __shared__ uint32_t lds[];  // max(N + CHUNK, DEG + N) words
+  const int tid = threadIdx.x;
+  const long long blk = first_block + blockIdx.x;
+  uint32_t* st = states + (size_t)(blk % nstates) * N;
+  uint32_t* out = ring + (size_t)(blk % ring_blocks) * (size_t)count;
+  const int first_copy = (blk == 0) ? N : 0;  // block 0 begins with the words of the mt array
+  const bool store = blk >= keep_from;        // skipped blocks only advance the state
+  for (int i = tid; i < N; i += blockDim.x) lds[i] = st[i];
+  __syncthreads();
+  int done = 0;
+  if (first_copy > 0) {
+    if (store)
+      for (int i = tid; i < first_copy; i += blockDim.x) out[i] = lds[N - first_copy + i];
+    done = first_copy;
+  }
+  while (done < count) {
+    const int todo = (count - done < CHUNK) ? (count - done) : CHUNK;
+    // rounds of up to 227 independent words: E[N+i] = E[M+i] ^ twist(E[i], E[i+1])
+    for (int base = 0; base < todo; base += (N - M)) {
+      const int i = base + tid;
+      if (tid < (N - M) && i < todo) lds[N + i] = lds[M + i] ^ twist(lds[i], lds[i + 1]);
+      __syncthreads();
+    }
+    if (store)
+      for (int i = tid; i < todo; i += blockDim.x) out[done + i] = lds[N + i];
+    __syncthreads();
+    // slide the history window
+    uint32_t keep[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      int i = tid + q * 256;
+      keep[q] = (i < N) ? lds[todo + i] : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      int i = tid + q * 256;
+      if (i < N) lds[i] = keep[q];
+    }
+    __syncthreads();
+    done += todo;
+  }
+  if (do_jump) jump_in_lds(lds, g, tid);
+  for (int i = tid; i < N; i += blockDim.x) st[i] = lds[i];
+}
+
+// states[dst] = g(F) states[src]   (positioning of the generator states at start-up)
+__global__ __launch_bounds__(256) void k_mt_jump(uint32_t* __restrict__ states, int src, int dst,
+                                                 const uint32_t* __restrict__ g) {
+  extern __shared__ uint32_t lds[];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < N; i += blockDim.x) lds[i] = states[(size_t)src * N + i];
+  __syncthreads();
+  jump_in_lds(lds, g, tid);
+  for (int i = tid; i < N; i += blockDim.x) states[(size_t)dst * N + i] = lds[i];
+}
+
+constexpr size_t LDS_BYTES = (size_t)(DEG + N) * 4;  // > (N + CHUNK) * 4
+
+}  // namespace ltmt

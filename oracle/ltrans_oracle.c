@@ -58,6 +58,12 @@ uint32_t lto_genrand_int32(lto_mt *s) {
   return y;
 }
 
+/* test helper: discard `skip` outputs, then write n outputs */
+void lto_genrand_fill(lto_mt *s, uint64_t skip, int n, uint32_t *out) {
+  for (uint64_t i = 0; i < skip; i++) (void)lto_genrand_int32(s);
+  for (int i = 0; i < n; i++) out[i] = lto_genrand_int32(s);
+}
+
 /* genrand_real1, random_module.f90:213-220: [0,1] */
 double lto_genrand_real1(lto_mt *s) {
   return (double)lto_genrand_int32(s) / 4294967295.0;

@@ -53,6 +53,7 @@ int lto_get_particles(lto_engine *e, lt_particles *out);
 typedef struct lto_mt { uint32_t mt[624]; int32_t mti; } lto_mt;
 void     lto_init_genrand(lto_mt *s, uint32_t seed);      /* random_module.f90:108 */
 uint32_t lto_genrand_int32(lto_mt *s);                    /* :166 */
+void     lto_genrand_fill(lto_mt *s, uint64_t skip, int n, uint32_t *out);
 double   lto_genrand_real1(lto_mt *s);                    /* :213 */
 double   lto_genrand_real3(lto_mt *s);                    /* :239 */
 double   lto_norm(lto_mt *s, double PI);                  /* norm_module.f90:25 */

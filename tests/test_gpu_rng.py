@@ -1,0 +1,62 @@
+"""The materialised MT19937 stream on the device (block generation + (P-1)*S
+jump-ahead per workgroup) against the oracle's sequential generator: bit-exact,
+including reads that straddle block boundaries and blocks reached only through
+jumps."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ltrans_amd
+import oracle_lib
+
+pytestmark = pytest.mark.gpu
+
+S = 1 << 20
+P = 128
+
+
+def _oracle_stream(oracle, seed, skip, n):
+    st = oracle_lib.MT()
+    oracle.lto_init_genrand(C.byref(st), C.c_uint32(seed))
+    out = np.zeros(n, dtype=np.uint32)
+    oracle.lto_genrand_fill(C.byref(st), C.c_uint64(skip), C.c_int(n), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+@pytest.mark.parametrize("seed", [9, 5489])
+def test_ring_matches_sequential_stream(oracle, seed):
+    cfg = ltrans_amd.LtConfig(numpar=4, us=8, ws=9, seed=seed)
+    e = ltrans_amd.Engine(cfg)
+    f = e.lib.lt_test_mt_ring
+    f.restype = C.c_int
+    # offsets relative to the cursor (= first draw after init_genrand)
+    offsets = [0, 100, S - 624 - 50, S - 10, 3 * S + 17, (P - 1) * S - 5, P * S - 300,
+               (P + 2) * S + 12345, (2 * P + 1) * S - 100]
+    for off in offsets:
+        out = np.zeros(1000, dtype=np.uint32)
+        rc = f(e._h, C.c_uint64(off), C.c_int32(out.size), out.ctypes.data_as(C.c_void_p))
+        assert rc == 0, e.lib.lt_last_error
+        assert np.array_equal(out, _oracle_stream(oracle, seed, off, out.size)), off
+    mt, mti = e.get_rng()
+    e.close()
+
+
+def test_set_rng_mid_batch(oracle):
+    """a state handed over with mti < 624 (part of the array still unconsumed)."""
+    st = oracle_lib.MT()
+    oracle.lto_init_genrand(C.byref(st), C.c_uint32(77))
+    burn = np.zeros(1000, dtype=np.uint32)
+    oracle.lto_genrand_fill(C.byref(st), C.c_uint64(0), C.c_int(1000), burn.ctypes.data_as(C.c_void_p))
+    assert 0 < st.mti < 624
+    cfg = ltrans_amd.LtConfig(numpar=4, us=8, ws=9)
+    e = ltrans_amd.Engine(cfg)
+    e.set_rng(np.array(st.mt, dtype=np.uint32), st.mti)
+    f = e.lib.lt_test_mt_ring
+    f.restype = C.c_int
+    out = np.zeros(3000, dtype=np.uint32)
+    assert f(e._h, C.c_uint64(0), C.c_int32(out.size), out.ctypes.data_as(C.c_void_p)) == 0
+    exp = np.zeros(3000, dtype=np.uint32)
+    oracle.lto_genrand_fill(C.byref(st), C.c_uint64(0), C.c_int(3000), exp.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(out, exp)
+    e.close()
