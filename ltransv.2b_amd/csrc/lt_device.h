@@ -96,6 +96,16 @@ struct StepParams {
   const int* elepolys_ptr; const int* elepolys_ids;
   const int* polyholes_ptr; const int* polyholes_ids;
   int minpolyid, minholeid;
+  // ---- turbulence (HTurb / VTurb) and the materialised MT19937 stream
+  int HTurbOn, VTurbOn;
+  double ConstantHTurb, PI;
+  const uint32_t* rng_ring;       // raw stream words, ring of rng_mask+1 words
+  unsigned long long rng_mask;    // ring size - 1 (power of two)
+  unsigned long long rng_base;    // stream index of the first draw of THIS shard's first active particle
+  int rng_draws;                  // draws per active particle (4 HTurb + 2*(idt/2) VTurb)
+  const int* rank;                // [numpar] rank of the particle among the active ones, indexed by reference index
+  const int* orig;                // [numpar] reference index of internal slot i
+  double* vt_x; double* vt_y; double* vt_yp; double* vt_sig;  // VTurb spline tables [4*ws][numpar]
   // ---- per-step workspace exchanged between k_pre / k_rk / k_post
   double* ws_d;   // [WS_NDOUBLE][numpar]
   int* ws_i;      // [numpar] flags | err << 8

@@ -5,6 +5,7 @@
 // and launches the step kernel of lt_kernels.h.  There is NO CPU fallback: every
 // entry point that computes runs on the HIP device or fails with LT_ERR_DEVICE.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -79,6 +80,8 @@ struct lt_engine {
   int rng_P = 128;                 // generator states
   int rng_R = 0;                   // ring capacity in blocks (power of two)
   DevBuf rng_states, rng_ring, rng_gJ;
+  DevBuf flag, rank, scan_tmp, vt_x, vt_y, vt_yp, vt_sig;
+  size_t scan_tmp_bytes = 0;
   // counters
   DevBuf counters;
   unsigned long long* h_counters = nullptr;  // pinned
@@ -169,6 +172,9 @@ int check_particle_elements(lt_engine* e, const int32_t* pe, int numpar, int ele
   return LT_OK;
 }
 
+constexpr int RNG_LOG2_S = 20;
+constexpr size_t RNG_S = (size_t)1 << RNG_LOG2_S;  // MT19937 stream words per block
+
 size_t slab_elem(const lt_engine* e) { return e->cfg.slab_storage == LT_SLAB_F32 ? 4 : 8; }
 
 void fill_params(lt_engine* e, StepParams& P) {
@@ -212,6 +218,12 @@ void fill_params(lt_engine* e, StepParams& P) {
   P.elepolys_ptr = (const int*)e->ep_ptr.p; P.elepolys_ids = (const int*)e->ep_ids.p;
   P.polyholes_ptr = (const int*)e->ph_ptr.p; P.polyholes_ids = (const int*)e->ph_ids.p;
   P.minpolyid = e->hab.minpolyid; P.minholeid = e->hab.minholeid;
+  P.HTurbOn = c.HTurbOn; P.VTurbOn = c.VTurbOn; P.ConstantHTurb = c.ConstantHTurb; P.PI = c.PI;
+  P.rng_ring = (const uint32_t*)e->rng_ring.p;
+  P.rng_mask = e->rng_R ? ((unsigned long long)e->rng_R * RNG_S - 1ull) : 0ull;
+  P.rng_draws = (c.HTurbOn ? 4 : 0) + (c.VTurbOn ? 2 * (c.idt / 2) : 0);
+  P.rank = (const int*)e->rank.p; P.orig = (const int*)e->orig.p;
+  P.vt_x = (double*)e->vt_x.p; P.vt_y = (double*)e->vt_y.p; P.vt_yp = (double*)e->vt_yp.p; P.vt_sig = (double*)e->vt_sig.p;
   P.ws_d = (double*)e->ws_d.p;
   P.ws_i = (int*)e->ws_i.p;
   P.counters = (unsigned long long*)e->counters.p;
@@ -362,8 +374,6 @@ int get_field(lt_engine* e, const DevBuf& buf, T* dst, int cols) {
 }
 
 // ---- device MT19937 stream --------------------------------------------------
-constexpr int RNG_LOG2_S = 20;
-constexpr size_t RNG_S = (size_t)1 << RNG_LOG2_S;  // words per block
 
 const ltmt::Poly& mt_phi() {
   static const ltmt::Poly phi = ltmt::characteristic_polynomial();
@@ -459,6 +469,18 @@ void launch_rk_t(lt_engine* e, const StepParams& P, unsigned blocks) {
     default: hipLaunchKernelGGL((k_rk<SlabT, 3, LT_RK_WAVES>), dim3(blocks), dim3(256), 0, e->stream, P); break;
   }
 }
+template <typename SlabT>
+void launch_vturb_t(lt_engine* e, const StepParams& P, unsigned blocks) {
+  switch (e->cfg.Vtransform) {
+    case 1: hipLaunchKernelGGL((k_vturb<SlabT, 1>), dim3(blocks), dim3(256), 0, e->stream, P); break;
+    case 2: hipLaunchKernelGGL((k_vturb<SlabT, 2>), dim3(blocks), dim3(256), 0, e->stream, P); break;
+    default: hipLaunchKernelGGL((k_vturb<SlabT, 3>), dim3(blocks), dim3(256), 0, e->stream, P); break;
+  }
+}
+void launch_vturb(lt_engine* e, const StepParams& P, unsigned blocks) {
+  if (e->cfg.slab_storage == LT_SLAB_F32) launch_vturb_t<float>(e, P, blocks);
+  else launch_vturb_t<double>(e, P, blocks);
+}
 void launch_rk(lt_engine* e, const StepParams& P, unsigned blocks) {
   if (e->cfg.slab_storage == LT_SLAB_F32) launch_rk_t<float>(e, P, blocks);
   else launch_rk_t<double>(e, P, blocks);
@@ -482,7 +504,6 @@ int lt_create(const lt_config* cfg, lt_engine** out) {
     return LT_ERR_ARG;
   if (cfg->FreeSlip || cfg->SaltTempOn) return LT_ERR_UNSUPPORTED;
   if (!(cfg->Behavior == 0 || cfg->Behavior == 6)) return LT_ERR_UNSUPPORTED;
-  if (cfg->HTurbOn || cfg->VTurbOn) return LT_ERR_UNSUPPORTED;  // device MT19937 stream: next milestone
   if (cfg->slab_storage != LT_SLAB_F32 && cfg->slab_storage != LT_SLAB_F64) return LT_ERR_ARG;
   lt_engine* e = new (std::nothrow) lt_engine();
   if (!e) return LT_ERR_NOMEM;
@@ -535,7 +556,8 @@ int lt_destroy(lt_engine* e) {
                     &e->ep_ptr, &e->ep_ids, &e->ph_ptr, &e->ph_ids, &e->par, &e->pr, &e->pu,
                     &e->pv, &e->P_behave, &e->dead, &e->oob, &e->settle, &e->endpoly,
                     &e->hitBottom, &e->hitLand, &e->err_code, &e->P_swim, &e->P_pediage,
-                    &e->P_deadage, &e->settletime, &e->counters, &e->ws_d, &e->ws_i, &e->orig, &e->rng_states, &e->rng_ring, &e->rng_gJ};
+                    &e->P_deadage, &e->settletime, &e->counters, &e->ws_d, &e->ws_i, &e->orig, &e->rng_states, &e->rng_ring, &e->rng_gJ, &e->flag, &e->rank, &e->scan_tmp,
+                    &e->vt_x, &e->vt_y, &e->vt_yp, &e->vt_sig};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
@@ -706,6 +728,15 @@ int lt_set_particles(lt_engine* e, const lt_particles* p) {
     TRY(upload(e, e->orig, e->perm.data(), n * 4));
     TRY(dev_alloc(e, e->ws_d, (size_t)WS_NDOUBLE * n * 8));
     TRY(dev_alloc(e, e->ws_i, n * 4));
+    if (e->cfg.HTurbOn || e->cfg.VTurbOn) {
+      TRY(dev_alloc(e, e->flag, (n + 1) * 4));
+      TRY(dev_alloc(e, e->rank, (n + 1) * 4));
+    }
+    if (e->cfg.VTurbOn) {
+      const size_t tb = (size_t)4 * e->cfg.ws * n * 8;  // p2 = 4*ws knots per particle
+      TRY(dev_alloc(e, e->vt_x, tb)); TRY(dev_alloc(e, e->vt_y, tb));
+      TRY(dev_alloc(e, e->vt_yp, tb)); TRY(dev_alloc(e, e->vt_sig, tb));
+    }
   }
   TRY(put_field<double>(e, e->par, p->par, 13));
   TRY(put_field<int32_t>(e, e->pr, p->P_r_element, 1));
@@ -754,8 +785,9 @@ int lt_get_particles(lt_engine* e, lt_particles* out) {
 int lt_set_slab(lt_engine* e, int32_t slot, const lt_slab* s) {
   if (!e || !s) return LT_ERR_ARG;
   if (!e->have_grid) return fail(e, LT_ERR_STATE, "lt_set_slab before lt_set_grid");
-  if (slot < 1 || slot > 3 || !s->zeta || !s->Uvel || !s->Vvel || !s->Wvel)
-    return fail(e, LT_ERR_ARG, "lt_set_slab: bad arguments");
+  if (slot < 1 || slot > 3 || !s->zeta || !s->Uvel || !s->Vvel || !s->Wvel ||
+      (e->cfg.VTurbOn && !s->Kh))
+    return fail(e, LT_ERR_ARG, "lt_set_slab: bad arguments (Kh is required when VTurbOn)");
   HIPCHK(e, hipSetDevice(e->device));
   int rc = (e->cfg.slab_storage == LT_SLAB_F32) ? set_slab_t<float>(e, slot, s)
                                                 : set_slab_t<double>(e, slot, s);
@@ -891,11 +923,46 @@ int lt_step(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32
   P.p = p; P.it = it;
   HIPCHK(e, hipMemsetAsync(e->counters.p, 0, CNT_COUNT * sizeof(unsigned long long), e->stream));
   unsigned blocks = (unsigned)((e->cfg.numpar + 255) / 256);
+  const bool turb = e->cfg.HTurbOn || e->cfg.VTurbOn;
+  e->stats.rng_draws = 0;
   if (blocks) {
     const bool prof = e->prof_on && e->prof_used + 2 <= e->prof_ev.size();
     const bool f32 = e->cfg.slab_storage == LT_SLAB_F32;
     if (f32) hipLaunchKernelGGL((k_pre<float>), dim3(blocks), dim3(256), 0, e->stream, P);
     else hipLaunchKernelGGL((k_pre<double>), dim3(blocks), dim3(256), 0, e->stream, P);
+    if (turb) {
+      // rank of every tracked particle among the tracked ones, in REFERENCE order: the
+      // reference's generator is advanced particle by particle (LTRANS.f90:778,1087,1098)
+      const int n = e->cfg.numpar;
+      hipLaunchKernelGGL(k_flag_scatter, dim3(blocks), dim3(256), 0, e->stream, (const int*)e->ws_i.p,
+                         (const int*)e->orig.p, (int*)e->flag.p, n);
+      size_t need = 0;
+      HIPCHK(e, hipcub::DeviceScan::ExclusiveSum(nullptr, need, (int*)e->flag.p, (int*)e->rank.p, n + 1, e->stream));
+      if (need > e->scan_tmp_bytes) {
+        TRY(dev_alloc(e, e->scan_tmp, need));
+        e->scan_tmp_bytes = e->scan_tmp.bytes;
+      }
+      HIPCHK(e, hipMemsetAsync((int*)e->flag.p + n, 0, 4, e->stream));
+      size_t tb = e->scan_tmp_bytes;
+      HIPCHK(e, hipcub::DeviceScan::ExclusiveSum(e->scan_tmp.p, tb, (int*)e->flag.p, (int*)e->rank.p, n + 1, e->stream));
+      int own = 0;  // rank[n] = number of tracked particles of this shard
+      HIPCHK(e, hipMemcpyAsync(&own, (int*)e->rank.p + n, 4, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(e, hipStreamSynchronize(e->stream));
+      const int64_t before = (e->rng_total >= 0) ? e->rng_before : 0;
+      const int64_t total = (e->rng_total >= 0) ? e->rng_total : own;
+      if (before + own > total) return fail(e, LT_ERR_ARG, "lt_set_rng_window: window smaller than the shard's active count");
+      const uint64_t D = (uint64_t)P.rng_draws;
+      if (!e->rng_ready) TRY(rng_init_device(e));
+      const uint64_t base = e->rng_cur + D * (uint64_t)before;
+      if (own > 0) TRY(rng_ensure(e, base, base + D * (uint64_t)own));
+      P.rng_ring = (const uint32_t*)e->rng_ring.p;
+      P.rng_mask = (unsigned long long)e->rng_R * RNG_S - 1ull;
+      P.rng_base = base;
+      e->rng_cur += D * (uint64_t)total;
+      e->rng_total = -1;
+      e->rng_before = 0;
+      e->stats.rng_draws = (int64_t)(D * (uint64_t)own);
+    }
     if (prof) HIPCHK(e, hipEventRecord(e->prof_ev[e->prof_used], e->stream));
     launch_rk(e, P, blocks);
     if (prof) {
@@ -904,6 +971,7 @@ int lt_step(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32
     }
     if (f32) hipLaunchKernelGGL((k_rk_slow<float>), dim3(blocks), dim3(256), 0, e->stream, P);
     else hipLaunchKernelGGL((k_rk_slow<double>), dim3(blocks), dim3(256), 0, e->stream, P);
+    if (e->cfg.VTurbOn) launch_vturb(e, P, blocks);
     hipLaunchKernelGGL(k_post, dim3(blocks), dim3(256), 0, e->stream, P);
     HIPCHK(e, hipGetLastError());
   }
@@ -926,7 +994,6 @@ int lt_get_stats(lt_engine* e, lt_step_stats* out) {
   if (!e->stats_valid) {
     e->stats.active = (int64_t)e->h_counters[CNT_ACTIVE];
     e->stats.errors = (int64_t)e->h_counters[CNT_ERRORS];
-    e->stats.rng_draws = 0;
     e->stats_valid = true;
   }
   *out = e->stats;

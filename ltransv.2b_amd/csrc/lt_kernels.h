@@ -28,6 +28,14 @@
 
 namespace ltd {
 
+LT_DEV uint32_t ltmt_temper(uint32_t y) {  // random_module.f90:190-193
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
+
 // par(n,k) column indices (LTRANS.f90:106-118), 0-based
 enum { pX = 0, pY, pZ, pnX, pnY, pnZ, ppX, ppY, ppZ, pStatus, pDOB, pAge, pLifespan };
 
@@ -35,7 +43,7 @@ enum { pX = 0, pY, pZ, pnX, pnY, pnZ, ppX, ppY, ppZ, pStatus, pDOB, pAge, pLifes
 
 // per-step workspace columns (doubles, SoA stride numpar) and the flag word
 enum { WS_PDEPTH = 0, WS_COSA, WS_SINA, WS_ZETA0, WS_ZETA1, WS_ZETA2, WS_PZ0, WS_PZ1, WS_PZ2,
-       WS_ZPAR, WS_SUMU, WS_SUMV, WS_SUMW, WS_NDOUBLE };
+       WS_ZPAR, WS_SUMU, WS_SUMV, WS_SUMW, WS_TURBV, WS_NDOUBLE };
 enum { FL_ACT = 1, FL_KEEP_PN = 2, FL_SLOW = 4, FL_ERR_SHIFT = 8 };
 
 template <typename SlabT> struct SlabTraits;
@@ -1081,6 +1089,237 @@ __global__ __launch_bounds__(256) void k_rk_slow(const StepParams P) {
   wsd[(size_t)WS_SUMW * N] = sumW;
 }
 
+// ---------------------------------------------------------------- turbulence
+// one uniform deviate of genrand_real3 (random_module.f90:239-246) from the
+// materialised stream
+LT_DEV double draw_real3(const StepParams& P, unsigned long long idx) {
+  const uint32_t y = ltmt_temper(P.rng_ring[idx & P.rng_mask]);
+  return ((double)y + 0.5) / 4294967296.0;
+}
+// norm(), norm_module.f90:25-39: two uniforms per deviate, cos branch only
+LT_DEV double draw_norm(const StepParams& P, unsigned long long idx) {
+  const double dev1 = draw_real3(P, idx), dev2 = draw_real3(P, idx + 1);
+  return sqrt(-2.0 * log(dev1)) * cos(2.0 * P.PI * dev2);
+}
+
+// HVAL / HPVAL on a spline table in memory (element k of array a at a[k*stride]),
+// tension_module.f90:980-1253.  `il` caches the last interval like INTRVL's SAVE IL.
+template <bool DERIV>
+LT_DEV double hval_table(double T, int n, const double* x, const double* y, const double* yp,
+                         const double* sig, size_t stride, int& il) {
+  int I;
+  if (T < x[0]) I = 1;
+  else if (T > x[(size_t)(n - 1) * stride]) I = n - 1;
+  else {
+    // INTRVL :1287-1354: try the previous interval, else bisection
+    bool hit = false;
+    if (il >= 1 && il < n) hit = (x[(size_t)(il - 1) * stride] <= T) && (T < x[(size_t)il * stride]);
+    if (!hit) {
+      int lo = 1, hi = n;
+      while (hi > lo + 1) {
+        int kk = (lo + hi) >> 1;
+        if (T < x[(size_t)(kk - 1) * stride]) hi = kk; else lo = kk;
+      }
+      il = lo;
+    }
+    I = il;
+  }
+  const size_t a = (size_t)(I - 1) * stride, b = (size_t)I * stride;
+  const double X1 = x[a], X2 = x[b], Y1 = y[a], Y2 = y[b], P1 = yp[a], P2 = yp[b], SG = sig[a];
+  if (X2 - X1 <= 0.0) return 0.0;  // IER = -2
+  if (DERIV) return hpval_interval(T, X1, X2, Y1, Y2, P1, P2, SG);
+  return hval_interval(T, X1, X2, Y1, Y2, P1, P2, SG);
+}
+
+// VTurb, ver_turb_module.f90:30-380, one lane per particle.  The ~30 work arrays
+// of the reference are never materialised: the proliferated / smoothed profile is
+// produced as a stream over k (8-point window in registers), the YPC1 derivative
+// and SIGS tension of interval k-2 are formed as soon as point k exists, and only
+// the final spline table (x, y, yp, sigma)(k) goes to HBM, [k][particle] so that
+// every table access of the build phase is coalesced.
+template <typename SlabT, int VT>
+__global__ __launch_bounds__(256) void k_vturb(const StepParams P) {
+  __shared__ double lev[6 * LT_LEV_STRIDE];
+  for (int i = threadIdx.x; i < 6 * LT_LEV_STRIDE; i += blockDim.x) lev[i] = P.lev[i];
+  __syncthreads();
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= P.numpar) return;
+  if (!(P.ws_i[n] & FL_ACT)) return;
+  const size_t N = (size_t)P.numpar;
+  double* wsd = P.ws_d + n;
+  const double* wtab = lev + 3 * LT_LEV_STRIDE;
+  const int ws = P.ws, p2 = 4 * P.ws;
+  const double P_depth = wsd[(size_t)WS_PDEPTH * N], h = -1.0 * P_depth;
+  const double P_zc = wsd[(size_t)WS_PZ1 * N], P_zetac = wsd[(size_t)WS_ZETA1 * N];
+  double zeta[3] = {wsd[(size_t)WS_ZETA0 * N], wsd[(size_t)WS_ZETA1 * N], wsd[(size_t)WS_ZETA2 * N]};
+  // getInterp weights of the start position in the rho element (setInterp :882)
+  const double X = P.par[(size_t)pX * N + n], Y = P.par[(size_t)pY * N + n];
+  const int4 rn = P.RE[P.P_r_element[n] - 1];
+  QuadWeights w0;
+  {
+    Quad q = load_quad_rho(P.rnode, rn);
+    w0 = quad_weights(X, Y, q.x, q.y);
+  }
+  const SlabT* K = (const SlabT*)P.Kh;
+  const int pslot[3] = {P.tb, P.tc, P.tf};
+  auto KH = [&](int s, int i) -> double {  // Pwc_KH{b,c,f}(i) :102-108
+    return apply_getinterp(w0, fld(K, rn.x, ws, i, pslot[s]), fld(K, rn.y, ws, i, pslot[s]),
+                           fld(K, rn.z, ws, i, pslot[s]), fld(K, rn.w, ws, i, pslot[s]));
+  };
+  auto WZ = [&](int s, int i) -> double {  // Pwc_wz{b,c,f}(i)
+    return level_at(level_coef(wtab, i, h, P.hc, VT), zeta[s], h, VT);
+  };
+  double wz1[3], wzN[3], kh1[3], khN[3], rng_[3];
+#pragma unroll
+  for (int s = 0; s < 3; s++) {
+    wz1[s] = WZ(s, 1); wzN[s] = WZ(s, ws);
+    kh1[s] = KH(s, 1); khN[s] = KH(s, ws);
+    rng_[s] = wzN[s] - wz1[s];
+  }
+  auto NEWX = [&](int s, int j) -> double {  // :121-123
+    return wz1[s] + ((double)(float)(j - 4)) * rng_[s] / (double)p2;
+  };
+  // piecewise-linear profile segment per slot :126-163
+  int jlo[3] = {1, 1, 1};
+  double slope[3], icpt[3], wzhi[3];
+  auto SEGMENT = [&](int s) {
+    const double a = WZ(s, jlo[s]), b = WZ(s, jlo[s] + 1);
+    const double ka = KH(s, jlo[s]), kb = KH(s, jlo[s] + 1);
+    slope[s] = (ka - kb) / (a - b);
+    icpt[s] = ka - slope[s] * a;
+    wzhi[s] = b;
+  };
+#pragma unroll
+  for (int s = 0; s < 3; s++) SEGMENT(s);
+  auto NEWY = [&](int s, int j) -> double {  // newy{b,c,f}(j), j = 1..p2+7
+    if (j <= 4) return kh1[0];             // :170-173: all three low pads use Pwc_KHb(1)
+    if (j >= p2 + 4) return khN[s];
+    const double xj = NEWX(s, j);
+    while (!(wzhi[s] > xj) && jlo[s] < ws - 1) { jlo[s] += 1; SEGMENT(s); }
+    return slope[s] * xj + icpt[s];
+  };
+  double win[3][8];
+#pragma unroll
+  for (int s = 0; s < 3; s++)
+#pragma unroll
+    for (int q = 0; q < 8; q++) win[s][q] = NEWY(s, 1 + q);
+  double* tx = P.vt_x + n; double* ty = P.vt_y + n; double* typ = P.vt_yp + n; double* tsg = P.vt_sig + n;
+  // streaming YPC1 / SIGS state: previous point, previous interval, YP(k-2)
+  double xm1 = 0.0, ym1 = 0.0, ym2 = 0.0, Sp = 0.0, DXp = 0.0, YPp = 0.0;
+  bool ypc_fail = false;
+  int sigerr = 0;
+#pragma unroll 1
+  for (int k = 1; k <= p2; k++) {
+    double mx[3], my[3];
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+      if (k == 1) { mx[s] = wz1[s]; my[s] = kh1[s]; }            // :197-210 pinned ends
+      else if (k == p2) { mx[s] = wzN[s]; my[s] = khN[s]; }
+      else {                                                      // :184-194 8-point average
+        my[s] = (win[s][0] + win[s][1] + win[s][2] + win[s][3] + win[s][4] + win[s][5] + win[s][6] + win[s][7]) / 8.0;
+        const double xa = NEWX(s, k);
+        mx[s] = xa + (NEWX(s, k + 7) - xa) / 2.0;
+      }
+    }
+    // :220-275 interpolation to the internal times, clamp, Simpson in time
+    const double ex1 = mx[0], ex2 = (P.p == 1) ? mx[0] : mx[1], ex3 = (P.p == 1) ? mx[1] : mx[2];
+    const double ey1 = my[0], ey2 = (P.p == 1) ? my[0] : my[1], ey3 = (P.p == 1) ? my[1] : my[2];
+    const double fxb = polintd3(P.ex0, P.ex1, P.ex2, ex1, ex2, ex3, P.ix0);
+    const double fxc = polintd3(P.ex0, P.ex1, P.ex2, ex1, ex2, ex3, P.ix1);
+    const double fxf = polintd3(P.ex0, P.ex1, P.ex2, ex1, ex2, ex3, P.ix2);
+    double fyb = polintd3(P.ex0, P.ex1, P.ex2, ey1, ey2, ey3, P.ix0);
+    double fyc = polintd3(P.ex0, P.ex1, P.ex2, ey1, ey2, ey3, P.ix1);
+    double fyf = polintd3(P.ex0, P.ex1, P.ex2, ey1, ey2, ey3, P.ix2);
+    if (fyb < 0.0) fyb = 0.0;
+    if (fyc < 0.0) fyc = 0.0;
+    if (fyf < 0.0) fyf = 0.0;
+    const double yk = (fyb + 4.0 * fyc + fyf) / 6.0;
+    const double xk = (fxb + 4.0 * fxc + fxf) / 6.0;
+    tx[(size_t)(k - 1) * N] = xk;
+    ty[(size_t)(k - 1) * N] = yk;
+    typ[(size_t)(k - 1) * N] = 0.0;
+    tsg[(size_t)(k - 1) * N] = 0.0;
+    // TSPSI(p2) as a stream: YPC1 (tension_module.f90:852-977), SIGS (:314-781)
+    if (k >= 2 && !ypc_fail) {
+      const double DX = xk - xm1;  // DX_{k-1}
+      if (DX <= 0.0) {
+        ypc_fail = true;  // YPC1 fails -> TSPSI returns IER = -4 and SIGS never runs
+      } else {
+        const double S = (yk - ym1) / DX;  // S_{k-1}
+        if (k == 3) {
+          YPp = ypc1_end(Sp, Sp + DXp * (Sp - S) / (DXp + DX));  // YP(1)
+          typ[0] = YPp;
+        }
+        if (k >= 3) {
+          const double YPc = ypc1_mid(DXp, DX, Sp, S);  // YP(k-1)
+          typ[(size_t)(k - 2) * N] = YPc;
+          if (sigerr == 0)  // interval k-2
+            tsg[(size_t)(k - 3) * N] = sigs_interval(DXp, ym2, ym1, YPp, YPc, sigerr);
+          YPp = YPc;
+        }
+        if (k == p2) {
+          const double YPn = ypc1_end(S, S + DX * (S - Sp) / (DXp + DX));  // YP(N)
+          typ[(size_t)(k - 1) * N] = YPn;
+          if (sigerr == 0)  // interval N-1
+            tsg[(size_t)(k - 2) * N] = sigs_interval(DX, ym1, yk, YPp, YPn, sigerr);
+        }
+        Sp = S;
+        DXp = DX;
+      }
+    }
+    ym2 = ym1;
+    xm1 = xk;
+    ym1 = yk;
+    // slide the 8-point window: drop newy(k), append newy(k+8)
+    if (k + 8 <= p2 + 7) {
+#pragma unroll
+      for (int s = 0; s < 3; s++) {
+        const double nv = NEWY(s, k + 8);
+#pragma unroll
+        for (int q = 0; q < 7; q++) win[s][q] = win[s][q + 1];
+        win[s][7] = nv;
+      }
+    }
+  }
+  if (ypc_fail) {
+    // SIGS was never called: every tension factor stays 0 and SigErr = 0
+    for (int k = 0; k < p2; k++) tsg[(size_t)k * N] = 0.0;
+    sigerr = 0;
+  }
+  // :282-335 random displacement model, idt/2 sub-steps of 2 s
+  const double background = (double)1.0E-6f, deltat = 2.0;
+  const int loop = P.idt / (int)deltat;
+  // this particle's window of the serial stream: HTurb's 4 draws come first (:1087,1098)
+  unsigned long long di = P.rng_base + (unsigned long long)P.rng_draws * (unsigned long long)P.rank[P.orig[n]] +
+                          (P.HTurbOn ? 4ull : 0ull);
+  double ParZc = P_zc;
+  int il = 1;
+#pragma unroll 1
+  for (int i = 1; i <= loop; i++) {
+    double Kprimec = 0.0;
+    if (!(ParZc < P_depth || ParZc > P_zetac)) {
+      if (sigerr == 0) Kprimec = hval_table<true>(ParZc, p2, tx, ty, typ, tsg, N, il);
+      else { double yy; linint_n(tx, ty, p2, (int)N, ParZc, yy, Kprimec); }
+    }
+    const double KprimeZc = -1.0 * Kprimec * deltat;
+    const double Z3rdc = ParZc + 0.5 * KprimeZc;
+    double KH3rdc;
+    if (Z3rdc < P_depth || Z3rdc > P_zetac) {
+      KH3rdc = background;
+    } else {
+      if (sigerr == 0) KH3rdc = hval_table<false>(Z3rdc, p2, tx, ty, typ, tsg, N, il);
+      else { double mm; linint_n(tx, ty, p2, (int)N, Z3rdc, KH3rdc, mm); }
+      if (KH3rdc < background) KH3rdc = background;
+    }
+    const double DEV = draw_norm(P, di);
+    di += 2;
+    // (2/r * KH3rd * deltat)**0.5 with r = 1
+    ParZc = ParZc + KprimeZc + DEV * sqrt(2.0 / 1.0 * KH3rdc * deltat);
+  }
+  wsd[(size_t)WS_TURBV * N] = P_zc - ParZc;  // :342
+  if (sigerr != 0) atomicAdd(&P.counters[CNT_SIGERR], 1ull);
+}
+
 __global__ __launch_bounds__(256) void k_post(const StepParams P) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned c_err = 0, c_brute = 0, c_pipslow = 0;
@@ -1106,7 +1345,16 @@ __global__ __launch_bounds__(256) void k_post(const StepParams P) {
       const double AdvectX = P.idt * (P_U * cosA - P_V * sinA);
       const double AdvectY = P.idt * (P_U * sinA + P_V * cosA);
       const double AdvectZ = P.idt * P_W;
-      const double TurbHx = 0.0, TurbHy = 0.0, TurbV = 0.0;
+      // HTurb, hor_turb_module.f90:29-50: X deviate before Y; VTurb's TurbV from k_vturb
+      double TurbHx = 0.0, TurbHy = 0.0, TurbV = 0.0;
+      if (P.HTurbOn) {
+        const unsigned long long di = P.rng_base + (unsigned long long)P.rng_draws * (unsigned long long)P.rank[P.orig[n]];
+        const double devX = draw_norm(P, di), devY = draw_norm(P, di + 2);
+        const double amp = sqrt(2.0 / 1.0 * P.ConstantHTurb * P.idt);  // (2/r*KM*idt)**0.5
+        TurbHx = devX * amp;
+        TurbHy = devY * amp;
+      }
+      if (P.VTurbOn) TurbV = wsd[(size_t)WS_TURBV * N];
       // behave (types 0 and 6), behavior_module.f90:181-551
       double ZBehav = 0.0;
       if (P.Behavior != 0) {
@@ -1295,6 +1543,13 @@ __global__ void k_pack_positions(const double* __restrict__ par, const int* __re
   dst[o] = par[i];
   dst[N + o] = par[N + i];
   dst[2 * N + o] = par[2 * N + i];
+}
+
+// act flag of every particle in REFERENCE order (input of the rank scan)
+__global__ void k_flag_scatter(const int* __restrict__ ws_i, const int* __restrict__ orig,
+                               int* __restrict__ flag, int numpar) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < numpar) flag[orig[i]] = (ws_i[i] & FL_ACT) ? 1 : 0;
 }
 
 // number of particles that pass the gates and the first setEle (= draw RNG)

@@ -20,6 +20,15 @@ CASES = {
                      cfg=dict(Behavior=0, Vtransform=2, hc=5.0)),
     "tiny_vt3": dict(grid=(24, 16, 8), islands=[(10, 12, 6, 8)], numpar=512, near_land=0.3,
                      cfg=dict(Behavior=0, Vtransform=3)),
+    # random-walk turbulence: Mersenne-Twister stream consumed in particle order
+    "tiny_turb": dict(grid=(24, 16, 8), islands=[(10, 12, 6, 8)], numpar=512, near_land=0.3,
+                      cfg=dict(Behavior=0, HTurbOn=1, VTurbOn=1, ConstantHTurb=1.0)),
+    "tiny_hturb": dict(grid=(24, 16, 8), islands=[(10, 12, 6, 8)], numpar=512, near_land=0.5,
+                       cfg=dict(Behavior=0, HTurbOn=1, VTurbOn=0, ConstantHTurb=20.0)),
+    "tiny_vturb": dict(grid=(24, 16, 8), islands=[(10, 12, 6, 8)], numpar=512, near_land=0.3,
+                       cfg=dict(Behavior=6, sink=-0.001, HTurbOn=0, VTurbOn=1)),
+    "small_turb": dict(grid=(100, 100, 20), islands=[(40, 44, 50, 53), (70, 71, 20, 30)],
+                       numpar=608, near_land=0.2, cfg=dict(Behavior=0, HTurbOn=1, VTurbOn=1)),
     # uniform drift into the west/south coast and the island: many reflections
     "tiny_reflect": dict(grid=(24, 16, 8), islands=[(10, 12, 6, 8)], numpar=768, near_land=0.6,
                          drift=(-0.35, -0.25), cfg=dict(Behavior=0)),

@@ -1,0 +1,90 @@
+"""Parity with random-walk turbulence on (BASELINE configs[2]): HTurb + VTurb driven
+by the reference's single serial MT19937 stream, consumed in particle order."""
+import numpy as np
+import pytest
+
+import cases
+import ltrans_amd
+import oracle_lib
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6
+
+
+def _run(case, engine_kw, n_external, max_internal, unreleased=None):
+    e = cases.make_engine(case, ltrans_amd.Engine, engine_kw)
+    from ltrans_amd.driver import LtransRun
+    run = LtransRun(e, case["cfg"].dt, case["cfg"].idt, case["record"])
+    run.init_hydro()
+    run.run(n_external, max_internal=max_internal)
+    out = e.get_particles()
+    out["stats"] = e.stats()
+    out["rng"] = e.get_rng()
+    e.close()
+    return out
+
+
+def _next_draws(oracle, mt, mti, n=8):
+    import ctypes as C
+    st = oracle_lib.MT()
+    for i in range(624):
+        st.mt[i] = int(mt[i])
+    st.mti = int(mti)
+    return [oracle.lto_genrand_int32(C.byref(st)) for _ in range(n)]
+
+
+@pytest.mark.parametrize("name", ["tiny_hturb", "tiny_vturb", "tiny_turb", "small_turb"])
+def test_parity_turbulence(oracle, name):
+    case = cases.build_case(name)
+    hip = _run(case, {}, 2, 6)
+    ora = _run(case, dict(lib=oracle, prefix="lto_"), 2, 6)
+    err = cases.rel_error(hip["par"], ora["par"])
+    print(f"{name}: max rel err {err:.3e}; draws/step {ora['stats']['rng_draws']}")
+    assert err <= RTOL
+    for k in ("P_r_element", "err_code", "hitBottom", "hitLand"):
+        assert np.array_equal(hip[k], ora[k]), k
+    assert hip["stats"]["rng_draws"] == ora["stats"]["rng_draws"] > 0
+    # the generator is left where the reference's would be
+    assert _next_draws(oracle, *hip["rng"]) == _next_draws(oracle, *ora["rng"])
+
+
+def test_turbulence_skips_unreleased_particles(oracle):
+    """inactive particles draw nothing: stream offsets follow the active rank."""
+    case = cases.build_case("tiny_turb")
+    case["parts"]["par"][::3, 10] = 1e9          # every third particle not yet released
+    hip = _run(case, {}, 1, 5)
+    ora = _run(case, dict(lib=oracle, prefix="lto_"), 1, 5)
+    assert cases.rel_error(hip["par"], ora["par"]) <= RTOL
+    assert hip["stats"]["active"] == ora["stats"]["active"] < case["cfg"].numpar
+    assert _next_draws(oracle, *hip["rng"]) == _next_draws(oracle, *ora["rng"])
+
+
+def test_turbulence_sharded_windows(oracle):
+    """two shards with lt_set_rng_window reproduce the unsharded run (multi-GPU path)."""
+    from ltrans_amd import sharding
+    from ltrans_amd.driver import LtransRun
+    case = cases.build_case("tiny_turb")
+    N = case["cfg"].numpar
+    full = _run(case, {}, 1, 4)
+    engines, runs = [], []
+    for r in range(2):
+        lo, hi = sharding.shard_range(N, 2, r)
+        shard = dict(case)
+        shard["cfg"] = case["cfg"].copy(numpar=hi - lo)
+        shard["parts"] = {k: (v[lo:hi] if v.ndim == 1 else v[lo:hi, :]) for k, v in case["parts"].items()}
+        e = cases.make_engine(shard, ltrans_amd.Engine, {})
+        run = LtransRun(e, 3600, 120, case["record"])
+        run.init_hydro()
+        engines.append(e)
+        runs.append(run)
+    ex = runs[0].external_times(1)
+    for it in range(1, 5):
+        ix = runs[0].internal_times(ex, it)
+        counts = [e.count_active(ix) for e in engines]
+        for r, e in enumerate(engines):
+            e.set_rng_window(sum(counts[:r]), sum(counts))
+            e.update_particles(ex, ix, 1, it)
+    got = np.vstack([e.get_particles(fields=("par",))["par"] for e in engines])
+    assert np.array_equal(got, full["par"])
+    for e in engines:
+        e.close()
