@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--numpar", type=int, default=1_000_000, help="particles per GPU")
     ap.add_argument("--grid", type=str, default="512x256x30")
     ap.add_argument("--slab", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--turb", action="store_true",
+                    help="BASELINE configs[2]: RK4 + HTurb + VTurb (MT19937 stream on device)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=40000,
                     help="particles of the bounded CPU-baseline sample")
@@ -77,8 +79,9 @@ def cpu_baseline(ltrans_amd, args, vi, uj, us, g, geo, bounds, records):
     from ltrans_amd import roms_synth as rs
     n = args.cpu_sample
     parts = rs.make_particles(g, geo, bounds, n, seed=777)
+    turb = 1 if args.turb else 0
     cfg = ltrans_amd.LtConfig(numpar=n, us=us, ws=us + 1, dt=3600, idt=120, Behavior=0,
-                              ErrorFlag=1)
+                              ErrorFlag=1, HTurbOn=turb, VTurbOn=turb)
     e, run = make_engine(ltrans_amd, cfg, g, geo, bounds, parts, records,
                          lib=oracle_lib.load_oracle(), prefix="lto_")
     ex = run.external_times(2)
@@ -119,11 +122,12 @@ def main():
 
     def records(r):
         if r not in rec_cache:
-            rec_cache[r] = rs.make_record(g, geo, r, with_kh=False)
+            rec_cache[r] = rs.make_record(g, geo, r, with_kh=bool(args.turb))
         return rec_cache[r]
 
+    turb = 1 if args.turb else 0
     cfg = ltrans_amd.LtConfig(numpar=n, us=us, ws=us + 1, dt=3600, idt=120, Behavior=0,
-                              ErrorFlag=1, device=dev.index,
+                              ErrorFlag=1, device=dev.index, HTurbOn=turb, VTurbOn=turb,
                               slab_storage=(ltrans_amd.abi.LT_SLAB_F32 if args.slab == "f32"
                                             else ltrans_amd.abi.LT_SLAB_F64))
     e, run = make_engine(ltrans_amd, cfg, g, geo, bounds, parts, records)
@@ -153,6 +157,11 @@ def main():
     def one_step():
         state["it"] += 1
         ix = run.internal_times(state["ex"], state["it"])
+        if world > 1 and args.turb:
+            # every rank's place in the single serial random stream of this step
+            from ltrans_amd import sharding
+            before, total = sharding.rng_window(dist, torch, e.count_active(ix), world, rank, device=dev)
+            e.set_rng_window(before, total)
         e.update_particles(state["ex"], ix, state["p"], state["it"])
         if world > 1:
             e.pack_positions(send.data_ptr())
@@ -199,6 +208,11 @@ def main():
     total_particle_steps = float(n) * world * args.steps
     value = total_particle_steps / wall
     A = A_ADV_F32 if args.slab == "f32" else A_ADV_F64
+    if args.turb:
+        # + Kh 4 nodes x ws x 3 slots, + the materialised stream (124 draws
+        # of 4 B written once and read once)
+        ws_ = us + 1
+        A += (48 if args.slab == "f32" else 96) * ws_ + 124 * 4 * 2
     k_avg_s = (k_ms / max(k_n, 1)) * 1e-3
     achieved = (A * n / k_avg_s) / 1e9 if k_avg_s > 0 else 0.0
 
@@ -207,8 +221,9 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{n} particles per GPU, synthetic {vi}x{uj}x{us} ROMS grid, RK4 "
-                               "advection only (HTurb/VTurb/behavior off), idt=120 s"
+        "config": {"workload": f"{n} particles per GPU, synthetic {vi}x{uj}x{us} ROMS grid, "
+                               + ("RK4 + HTurb + VTurb (MT19937 stream on device), idt=120 s" if args.turb
+                                  else "RK4 advection only (HTurb/VTurb/behavior off), idt=120 s")
                                + (", RCCL all-gather of (x,y,z) per step" if world > 1 else ""),
                    "particles_per_gpu": n, "grid": args.grid, "slab_storage": args.slab,
                    "active_last_step": active, "errors_last_step": stats["errors"],
@@ -216,7 +231,7 @@ def main():
                    "slab_rotation_s_excluded": upload_s},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "k_step", "kernel_ms_avg": k_avg_s * 1e3,
+                     "kernel": "k_vturb" if args.turb else "k_rk", "kernel_ms_avg": k_avg_s * 1e3,
                      "algorithmic_bytes_per_particle_step": A},
     }
     if rank == 0 and not args.no_cpu_baseline:

@@ -49,7 +49,8 @@ extern "C" {
 #define LT_ERR_ARG           -1  /* NULL / out-of-range argument                   */
 #define LT_ERR_ABI           -2  /* struct_size / abi_version mismatch             */
 #define LT_ERR_STATE         -3  /* call order: grid / slabs / particles missing   */
-#define LT_ERR_UNSUPPORTED   -4  /* namelist option outside the implemented path   */
+#define LT_ERR_UNSUPPORTED   -4  /* namelist option outside the implemented path:
+                                    FreeSlip, SaltTempOn, Behavior other than 0 / 6  */
 #define LT_ERR_DEVICE        -5  /* HIP runtime error (see lt_last_error)          */
 #define LT_ERR_SLAB_NOT_F32  -6  /* slab_storage = F32 but a value is not a float  */
 #define LT_ERR_NOMEM         -7
@@ -94,7 +95,8 @@ typedef struct lt_config {
   int32_t Vtransform;         /* 1,2,3 (hydrodynamic_module.f90:2691-2777)             */
   double  z0;
   /* $turbparam */
-  int32_t HTurbOn, VTurbOn;
+  int32_t HTurbOn, VTurbOn;   /* hor_turb_module.f90:29 / ver_turb_module.f90:30; the single
+                                 serial MT19937 stream is reproduced on the device        */
   double  ConstantHTurb;
   /* $behavparam */
   int32_t Behavior;           /* 0 passive, 6 constant sink/float; 1-5,7 unsupported   */

@@ -963,15 +963,23 @@ int lt_step(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32
       e->rng_before = 0;
       e->stats.rng_draws = (int64_t)(D * (uint64_t)own);
     }
-    if (prof) HIPCHK(e, hipEventRecord(e->prof_ev[e->prof_used], e->stream));
+    // lt_profile_* times the dominant kernel of the configuration: k_vturb when
+    // vertical turbulence is on, k_rk otherwise
+    const bool prof_rk = prof && !e->cfg.VTurbOn, prof_vt = prof && e->cfg.VTurbOn;
+    if (prof_rk) HIPCHK(e, hipEventRecord(e->prof_ev[e->prof_used], e->stream));
     launch_rk(e, P, blocks);
-    if (prof) {
+    if (prof_rk) {
       HIPCHK(e, hipEventRecord(e->prof_ev[e->prof_used + 1], e->stream));
       e->prof_used += 2;
     }
     if (f32) hipLaunchKernelGGL((k_rk_slow<float>), dim3(blocks), dim3(256), 0, e->stream, P);
     else hipLaunchKernelGGL((k_rk_slow<double>), dim3(blocks), dim3(256), 0, e->stream, P);
+    if (prof_vt) HIPCHK(e, hipEventRecord(e->prof_ev[e->prof_used], e->stream));
     if (e->cfg.VTurbOn) launch_vturb(e, P, blocks);
+    if (prof_vt) {
+      HIPCHK(e, hipEventRecord(e->prof_ev[e->prof_used + 1], e->stream));
+      e->prof_used += 2;
+    }
     hipLaunchKernelGGL(k_post, dim3(blocks), dim3(256), 0, e->stream, P);
     HIPCHK(e, hipGetLastError());
   }

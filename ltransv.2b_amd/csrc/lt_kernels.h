@@ -1138,7 +1138,7 @@ LT_DEV double hval_table(double T, int n, const double* x, const double* y, cons
 // the final spline table (x, y, yp, sigma)(k) goes to HBM, [k][particle] so that
 // every table access of the build phase is coalesced.
 template <typename SlabT, int VT>
-__global__ __launch_bounds__(256) void k_vturb(const StepParams P) {
+__global__ __launch_bounds__(256, 2) void k_vturb(const StepParams P) {
   __shared__ double lev[6 * LT_LEV_STRIDE];
   for (int i = threadIdx.x; i < 6 * LT_LEV_STRIDE; i += blockDim.x) lev[i] = P.lev[i];
   __syncthreads();
