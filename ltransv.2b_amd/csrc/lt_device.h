@@ -107,6 +107,8 @@ struct StepParams {
   const int* orig;                // [numpar] reference index of internal slot i
   double* vt_x; double* vt_y; double* vt_yp; double* vt_sig;  // VTurb spline tables [4*ws][numpar]
   // ---- per-step workspace exchanged between k_pre / k_rk / k_post
+  unsigned char* ele_ok;  // [numpar] 1: the stored elements were found for the CURRENT position
+                          //     by the setEle at the end of the previous step (LTRANS.f90:1317)
   double* ws_d;   // [WS_NDOUBLE][numpar]
   int* ws_i;      // [numpar] flags | err << 8
   // ---- counters

@@ -61,7 +61,7 @@ struct lt_engine {
   lt_habitat hab{};
   int npoly = 0, nhole = 0;
   // particles
-  DevBuf ws_d, ws_i, orig;
+  DevBuf ws_d, ws_i, orig, ele_ok;
   // internal particle order: slot i of every device array holds the reference's
   // particle perm[i] (0-based); sorted by rho element for memory locality
   std::vector<int> perm;
@@ -224,6 +224,7 @@ void fill_params(lt_engine* e, StepParams& P) {
   P.rng_draws = (c.HTurbOn ? 4 : 0) + (c.VTurbOn ? 2 * (c.idt / 2) : 0);
   P.rank = (const int*)e->rank.p; P.orig = (const int*)e->orig.p;
   P.vt_x = (double*)e->vt_x.p; P.vt_y = (double*)e->vt_y.p; P.vt_yp = (double*)e->vt_yp.p; P.vt_sig = (double*)e->vt_sig.p;
+  P.ele_ok = (unsigned char*)e->ele_ok.p;
   P.ws_d = (double*)e->ws_d.p;
   P.ws_i = (int*)e->ws_i.p;
   P.counters = (unsigned long long*)e->counters.p;
@@ -556,7 +557,7 @@ int lt_destroy(lt_engine* e) {
                     &e->ep_ptr, &e->ep_ids, &e->ph_ptr, &e->ph_ids, &e->par, &e->pr, &e->pu,
                     &e->pv, &e->P_behave, &e->dead, &e->oob, &e->settle, &e->endpoly,
                     &e->hitBottom, &e->hitLand, &e->err_code, &e->P_swim, &e->P_pediage,
-                    &e->P_deadage, &e->settletime, &e->counters, &e->ws_d, &e->ws_i, &e->orig, &e->rng_states, &e->rng_ring, &e->rng_gJ, &e->flag, &e->rank, &e->scan_tmp,
+                    &e->P_deadage, &e->settletime, &e->counters, &e->ws_d, &e->ws_i, &e->orig, &e->ele_ok, &e->rng_states, &e->rng_ring, &e->rng_gJ, &e->flag, &e->rank, &e->scan_tmp,
                     &e->vt_x, &e->vt_y, &e->vt_yp, &e->vt_sig};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
@@ -738,6 +739,9 @@ int lt_set_particles(lt_engine* e, const lt_particles* p) {
       TRY(dev_alloc(e, e->vt_yp, tb)); TRY(dev_alloc(e, e->vt_sig, tb));
     }
   }
+  // positions / elements may change: nothing is known to be verified any more
+  TRY(dev_alloc(e, e->ele_ok, n));
+  HIPCHK(e, hipMemsetAsync(e->ele_ok.p, 0, e->ele_ok.bytes, e->stream));
   TRY(put_field<double>(e, e->par, p->par, 13));
   TRY(put_field<int32_t>(e, e->pr, p->P_r_element, 1));
   TRY(put_field<int32_t>(e, e->pu, p->P_u_element, 1));

@@ -834,10 +834,17 @@ __global__ __launch_bounds__(256) void k_pre(const StepParams P) {
     if (track) {
       int er = P.P_r_element[n], eu = P.P_u_element[n], ev = P.P_v_element[n];
       int4 rn, un, vn;
-      // setEle :830 (all three grids are searched even after a miss)
-      bool okr, oku, okv;
-      find_elements3(P, X, Y, er, eu, ev, rn, un, vn, okr, oku, okv);
-      P.P_r_element[n] = er; P.P_u_element[n] = eu; P.P_v_element[n] = ev;
+      // setEle :830 (all three grids are searched even after a miss).  When the
+      // previous step's closing setEle (:1317) found these very elements for this
+      // very position, the first probe of each grid is that element and succeeds
+      // again: the search is skipped and only the rho nodes are fetched.
+      bool okr = true, oku = true, okv = true;
+      if (P.ele_ok[n]) {
+        rn = P.RE[er - 1];
+      } else {
+        find_elements3(P, X, Y, er, eu, ev, rn, un, vn, okr, oku, okv);
+        P.P_r_element[n] = er; P.P_u_element[n] = eu; P.P_v_element[n] = ev;
+      }
       if (!okv) err = 6; else if (!oku) err = 5; else if (!okr) err = 4;  // last assignment wins
       if (err == 0) {
         flags |= FL_ACT;
@@ -1335,7 +1342,7 @@ __global__ __launch_bounds__(256) void k_post(const StepParams P) {
     const double X = PARV(pX), Y = PARV(pY);
     double Z = act ? wsd[(size_t)WS_ZPAR * N] : PARV(pZ);
     double nX = X, nY = Y, nZ = Z, lifespan = 0.0;
-    bool set_lifespan = false;
+    bool set_lifespan = false, verified = false;
     if (act) {
       const double age = PARV(pAge);
       const double P_depth = wsd[(size_t)WS_PDEPTH * N], P_zetac = wsd[(size_t)WS_ZETA1 * N];
@@ -1450,6 +1457,7 @@ __global__ __launch_bounds__(256) void k_post(const StepParams P) {
             find_elements3(P, nXpos, nYpos, er, eu, ev, nr, nu, nv, okr2, oku2, okv2);
             P.P_r_element[n] = er; P.P_u_element[n] = eu; P.P_v_element[n] = ev;
             if (!okv2) err = 29; else if (!oku2) err = 28; else if (!okr2) err = 27;
+            verified = (err == 0);  // the committed position lies in the stored elements
             if (err == 0 && P.settlementon) {
               // testSettlement with the OLD position and the NEW element :1375
               if (age >= P.settletime[n]) {
@@ -1476,6 +1484,7 @@ __global__ __launch_bounds__(256) void k_post(const StepParams P) {
       else { nX = X; nY = Y; nZ = Z; keep_pn = false; }
     }
     P.err_code[n] = err;
+    P.ele_ok[n] = verified ? 1 : 0;
     // commit loop :1407-1414 fused: pp <- p, p <- pn
     if (keep_pn) {
       nX = PARV(pnX); nY = PARV(pnY); nZ = PARV(pnZ);
