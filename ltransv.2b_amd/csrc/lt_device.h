@@ -76,6 +76,10 @@ struct StepParams {
   // ---- time
   double ex0, ex1, ex2, ix0, ix1, ix2;
   int p, it, idt;
+  // reciprocals of the divisors shared by all particles (div_by in lt_math.h):
+  // ex(2)-ex(3), ex(1)-ex(2), ex(1)-ex(3), 4*ws, 6; fastdiv = 0 falls back to '/'
+  double r_d23, r_d12, r_d13, r_p2, r_6;
+  int fastdiv;
   // ---- options
   int Behavior, OpenOceanBoundary, mortality, settlementon, holesExist, ErrorFlag, TrackCollisions;
   double swimstart, swimfast, sink;

@@ -473,10 +473,12 @@ void launch_rk_t(lt_engine* e, const StepParams& P, unsigned blocks) {
 template <typename SlabT>
 void launch_vturb_t(lt_engine* e, const StepParams& P, unsigned blocks) {
   switch (e->cfg.Vtransform) {
-    case 1: hipLaunchKernelGGL((k_vturb<SlabT, 1>), dim3(blocks), dim3(256), 0, e->stream, P); break;
-    case 2: hipLaunchKernelGGL((k_vturb<SlabT, 2>), dim3(blocks), dim3(256), 0, e->stream, P); break;
-    default: hipLaunchKernelGGL((k_vturb<SlabT, 3>), dim3(blocks), dim3(256), 0, e->stream, P); break;
+    case 1: hipLaunchKernelGGL((k_vt_table<SlabT, 1>), dim3(blocks), dim3(256), 0, e->stream, P); break;
+    case 2: hipLaunchKernelGGL((k_vt_table<SlabT, 2>), dim3(blocks), dim3(256), 0, e->stream, P); break;
+    default: hipLaunchKernelGGL((k_vt_table<SlabT, 3>), dim3(blocks), dim3(256), 0, e->stream, P); break;
   }
+  hipLaunchKernelGGL(k_vt_sigs, dim3(blocks), dim3(256), 0, e->stream, P);
+  hipLaunchKernelGGL(k_vt_walk, dim3(blocks), dim3(256), 0, e->stream, P);
 }
 void launch_vturb(lt_engine* e, const StepParams& P, unsigned blocks) {
   if (e->cfg.slab_storage == LT_SLAB_F32) launch_vturb_t<float>(e, P, blocks);
@@ -734,7 +736,7 @@ int lt_set_particles(lt_engine* e, const lt_particles* p) {
       TRY(dev_alloc(e, e->rank, (n + 1) * 4));
     }
     if (e->cfg.VTurbOn) {
-      const size_t tb = (size_t)4 * e->cfg.ws * n * 8;  // p2 = 4*ws knots per particle
+      const size_t tb = (size_t)4 * e->cfg.ws * ((n + 63) / 64 * 64) * 8;  // p2 = 4*ws knots per particle, [wave][k][lane]
       TRY(dev_alloc(e, e->vt_x, tb)); TRY(dev_alloc(e, e->vt_y, tb));
       TRY(dev_alloc(e, e->vt_yp, tb)); TRY(dev_alloc(e, e->vt_sig, tb));
     }
@@ -923,6 +925,19 @@ int lt_step(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32
   StepParams P;
   fill_params(e, P);
   P.ex0 = ex3[0]; P.ex1 = ex3[1]; P.ex2 = ex3[2];
+  {
+    const double dv[5] = {ex3[1] - ex3[2], ex3[0] - ex3[1], ex3[0] - ex3[2], (double)(4 * e->cfg.ws), 6.0};
+    double rc[5];
+    int ok = 1;
+    for (int i = 0; i < 5; i++) {
+      int ex;
+      const double mant = std::fabs(std::frexp(dv[i], &ex));  // [0.5, 1)
+      if (!(std::fabs(dv[i]) > 1e-290 && std::fabs(dv[i]) < 1e290) || mant == 1.0 - 0x1p-53) ok = 0;
+      rc[i] = 1.0 / dv[i];
+    }
+    P.r_d23 = rc[0]; P.r_d12 = rc[1]; P.r_d13 = rc[2]; P.r_p2 = rc[3]; P.r_6 = rc[4];
+    P.fastdiv = (ok && !getenv("LT_NO_FASTDIV")) ? 1 : 0;
+  }
   P.ix0 = ix3[0]; P.ix1 = ix3[1]; P.ix2 = ix3[2];
   P.p = p; P.it = it;
   HIPCHK(e, hipMemsetAsync(e->counters.p, 0, CNT_COUNT * sizeof(unsigned long long), e->stream));

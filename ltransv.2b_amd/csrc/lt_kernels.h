@@ -44,7 +44,7 @@ enum { pX = 0, pY, pZ, pnX, pnY, pnZ, ppX, ppY, ppZ, pStatus, pDOB, pAge, pLifes
 // per-step workspace columns (doubles, SoA stride numpar) and the flag word
 enum { WS_PDEPTH = 0, WS_COSA, WS_SINA, WS_ZETA0, WS_ZETA1, WS_ZETA2, WS_PZ0, WS_PZ1, WS_PZ2,
        WS_ZPAR, WS_SUMU, WS_SUMV, WS_SUMW, WS_TURBV, WS_NDOUBLE };
-enum { FL_ACT = 1, FL_KEEP_PN = 2, FL_SLOW = 4, FL_ERR_SHIFT = 8 };
+enum { FL_ACT = 1, FL_KEEP_PN = 2, FL_SLOW = 4, FL_VT_YPCFAIL = 16, FL_VT_SIGERR = 32, FL_ERR_SHIFT = 8 };
 
 template <typename SlabT> struct SlabTraits;
 template <> struct SlabTraits<float> { using zeta4 = float4; };
@@ -1138,34 +1138,132 @@ LT_DEV double hval_table(double T, int n, const double* x, const double* y, cons
   return hval_interval(T, X1, X2, Y1, Y2, P1, P2, SG);
 }
 
-// VTurb, ver_turb_module.f90:30-380, one lane per particle.  The ~30 work arrays
-// of the reference are never materialised: the proliferated / smoothed profile is
-// produced as a stream over k (8-point window in registers), the YPC1 derivative
-// and SIGS tension of interval k-2 are formed as soon as point k exists, and only
-// the final spline table (x, y, yp, sigma)(k) goes to HBM, [k][particle] so that
-// every table access of the build phase is coalesced.
+// polintd at the three internal times ix(1..3) of one (ex, ey) triple
+// (ver_turb_module.f90:236-238,258-260): the two inner quotients of polintd do
+// not depend on x, so they are formed once (same values, 5 divisions instead of 9).
+LT_DEV void polintd3x3(const StepParams& P, double ya1, double ya2, double ya3,
+                       double& rb, double& rc, double& rf) {
+  const double xa1 = P.ex0, xa2 = P.ex1, xa3 = P.ex2;
+  const bool fd = P.fastdiv != 0;
+  const double q32 = div_by(ya3 - ya2, xa2 - xa3, P.r_d23, fd);
+  const double q21 = div_by(ya2 - ya1, xa1 - xa2, P.r_d12, fd);
+  auto one = [&](double x) -> double {
+    int ns = 1;
+    double dif = fabs(x - xa1), dift = fabs(x - xa2);
+    if (dift < dif) { ns = 2; dif = dift; }
+    dift = fabs(x - xa3);
+    if (dift < dif) { ns = 3; dif = dift; }
+    double c = (xa2 - x) * q32;
+    c = c - (xa2 - x) * q21;
+    c = div_by(c, xa1 - xa3, P.r_d13, fd);
+    const double a = (ns == 3) ? q32 : q21;
+    const double bb = (ns == 3) ? (xa3 - x) : (xa1 - x);
+    const double yns = (ns == 1) ? ya1 : (ns == 2) ? ya2 : ya3;
+    const double xns = (ns == 1) ? xa1 : (ns == 2) ? xa2 : xa3;
+    return yns + (xns - x) * a + bb * c;
+  };
+  rb = one(P.ix0); rc = one(P.ix1); rf = one(P.ix2);
+}
+
+// The interval of the VTurb spline table a walk is in, kept in registers: HVAL and
+// HPVAL (tension_module.f90:980-1253) reload from HBM only when the depth leaves it.
+// For a strictly increasing abscissa table INTRVL's answer (:1287-1354) is the unique
+// I with X(I) <= T < X(I+1), clamped to 1..N-1, whatever its saved IL was, so
+// stepping from the cached interval finds the same I as its bisection.
+struct VtInterval { int I; double X1, X2, Y1, Y2, P1, P2, SG; };
+LT_DEV void vt_seek(VtInterval& c, double T, int n, const double* x, const double* y,
+                    const double* yp, const double* sig, size_t stride) {
+  bool moved = false;
+  if (c.I == 0) {  // first use: bisection
+    int lo = 1, hi = n;
+    while (hi > lo + 1) {
+      const int kk = (lo + hi) >> 1;
+      if (T < x[(size_t)(kk - 1) * stride]) hi = kk; else lo = kk;
+    }
+    c.I = lo;
+    c.X1 = x[(size_t)(lo - 1) * stride];
+    c.X2 = x[(size_t)lo * stride];
+    moved = true;
+  }
+  while (T < c.X1 && c.I > 1) { c.I -= 1; c.X2 = c.X1; c.X1 = x[(size_t)(c.I - 1) * stride]; moved = true; }
+  while (T >= c.X2 && c.I < n - 1) { c.I += 1; c.X1 = c.X2; c.X2 = x[(size_t)c.I * stride]; moved = true; }
+  if (moved) {
+    const size_t a = (size_t)(c.I - 1) * stride, b = (size_t)c.I * stride;
+    c.Y1 = y[a]; c.Y2 = y[b]; c.P1 = yp[a]; c.P2 = yp[b]; c.SG = sig[a];
+  }
+}
+
+// per-wave LDS queue of the spline intervals of the VTurb table whose tension
+// factor needs an iteration (SIGS, tension_module.f90:531-760)
+#define LT_VT_CAP 256
+struct VtScratch {
+  double S[LT_VT_CAP], S1[LT_VT_CAP], S2[LT_VT_CAP];
+  unsigned short where[LT_VT_CAP];  // interval index k (0-based)
+  unsigned char lane[LT_VT_CAP];
+  unsigned int failed[64];
+};
+
+LT_DEV void vt_run_tasks(VtScratch& q, int ntask, int lane, int wave_first, double* vt_sig,
+                         int p2) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+  for (int t = lane; t < ntask; t += 64) {
+    double sg, T;
+    bool failed = false;
+    const int kind = sigs_classify(q.S[t], q.S1[t], q.S2[t], sg, T);
+    if (kind == SIGK_NEWTON) sg = sigs_newton(T, failed);
+    else if (kind == SIGK_SECANT) sg = sigs_secant(q.S[t], q.S1[t], q.S2[t]);
+    vt_sig[((size_t)(wave_first >> 6) * (size_t)p2 + q.where[t]) * 64 + q.lane[t]] = sg;
+    if (failed) atomicOr(&q.failed[q.lane[t]], 1u);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// VTurb, ver_turb_module.f90:30-380, as three kernels, one lane per particle:
+//   k_vt_table  builds the spline table of the time-interpolated, smoothed Kh profile
+//               (the register-heavy, arithmetic part);
+//   k_vt_sigs   chooses the tension factors (SIGS), iterating only the intervals that
+//               need it, 64 at a time per wave;
+//   k_vt_walk   runs the idt/2 random-walk sub-steps on the table.
+// The ~30 work arrays of the reference are never materialised: the proliferated /
+// smoothed profile is produced as a stream over k (8-point window in registers),
+// the YPC1 derivative of point k-1 is formed as soon as point k exists, and only the
+// final spline table (x, y, yp, sigma)(k) goes to HBM, [wave][k][lane], so every table
+// access of the build phases is coalesced and a wave streams one contiguous block.
+// SIGS' "RETURN at the first SigErr" leaves later tensions at 0 in the reference;
+// since SigErr switches every later evaluation to linint, which ignores the
+// tensions, computing all of them here changes nothing.
 template <typename SlabT, int VT>
-__global__ __launch_bounds__(256, 2) void k_vturb(const StepParams P) {
+__global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
   __shared__ double lev[6 * LT_LEV_STRIDE];
   for (int i = threadIdx.x; i < 6 * LT_LEV_STRIDE; i += blockDim.x) lev[i] = P.lev[i];
   __syncthreads();
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= P.numpar) return;
-  if (!(P.ws_i[n] & FL_ACT)) return;
+  if (n >= P.numpar || !(P.ws_i[n] & FL_ACT)) return;
+  const bool act = true;
   const size_t N = (size_t)P.numpar;
-  double* wsd = P.ws_d + n;
+  const int na = act ? n : 0;
+  double* wsd = P.ws_d + na;
   const double* wtab = lev + 3 * LT_LEV_STRIDE;
   const int ws = P.ws, p2 = 4 * P.ws;
-  const double P_depth = wsd[(size_t)WS_PDEPTH * N], h = -1.0 * P_depth;
-  const double P_zc = wsd[(size_t)WS_PZ1 * N], P_zetac = wsd[(size_t)WS_ZETA1 * N];
-  double zeta[3] = {wsd[(size_t)WS_ZETA0 * N], wsd[(size_t)WS_ZETA1 * N], wsd[(size_t)WS_ZETA2 * N]};
-  // getInterp weights of the start position in the rho element (setInterp :882)
-  const double X = P.par[(size_t)pX * N + n], Y = P.par[(size_t)pY * N + n];
-  const int4 rn = P.RE[P.P_r_element[n] - 1];
+  double P_depth = -1.0, h = 1.0, P_zc = 0.0, P_zetac = 0.0;
+  double zeta[3] = {0.0, 0.0, 0.0};
+  int4 rn = make_int4(1, 1, 1, 1);
   QuadWeights w0;
-  {
-    Quad q = load_quad_rho(P.rnode, rn);
-    w0 = quad_weights(X, Y, q.x, q.y);
+  w0.regime = 1; w0.node_hit = 0; w0.t = w0.u = w0.W1 = w0.W2 = w0.W3 = w0.W4 = 0.0;
+  if (act) {
+    P_depth = wsd[(size_t)WS_PDEPTH * N]; h = -1.0 * P_depth;
+    P_zc = wsd[(size_t)WS_PZ1 * N]; P_zetac = wsd[(size_t)WS_ZETA1 * N];
+    zeta[0] = wsd[(size_t)WS_ZETA0 * N]; zeta[1] = wsd[(size_t)WS_ZETA1 * N]; zeta[2] = wsd[(size_t)WS_ZETA2 * N];
+    // getInterp weights of the start position in the rho element (setInterp :882)
+    const double X = P.par[(size_t)pX * N + n], Y = P.par[(size_t)pY * N + n];
+    rn = P.RE[P.P_r_element[n] - 1];
+    Quad qq = load_quad_rho(P.rnode, rn);
+    w0 = quad_weights(X, Y, qq.x, qq.y);
   }
   const SlabT* K = (const SlabT*)P.Kh;
   const int pslot[3] = {P.tb, P.tc, P.tf};
@@ -1184,7 +1282,7 @@ __global__ __launch_bounds__(256, 2) void k_vturb(const StepParams P) {
     rng_[s] = wzN[s] - wz1[s];
   }
   auto NEWX = [&](int s, int j) -> double {  // :121-123
-    return wz1[s] + ((double)(float)(j - 4)) * rng_[s] / (double)p2;
+    return wz1[s] + div_by(((double)(float)(j - 4)) * rng_[s], (double)p2, P.r_p2, P.fastdiv != 0);
   };
   // piecewise-linear profile segment per slot :126-163
   int jlo[3] = {1, 1, 1};
@@ -1209,90 +1307,164 @@ __global__ __launch_bounds__(256, 2) void k_vturb(const StepParams P) {
 #pragma unroll
   for (int s = 0; s < 3; s++)
 #pragma unroll
-    for (int q = 0; q < 8; q++) win[s][q] = NEWY(s, 1 + q);
-  double* tx = P.vt_x + n; double* ty = P.vt_y + n; double* typ = P.vt_yp + n; double* tsg = P.vt_sig + n;
+    for (int qi = 0; qi < 8; qi++) win[s][qi] = act ? NEWY(s, 1 + qi) : 0.0;
+  // table layout: [wave][k][lane], a wave streams one contiguous 4*ws*512 B block per array
+  const size_t TS = 64, toff = (size_t)(na >> 6) * (size_t)p2 * 64 + (size_t)(na & 63);
+  double* tx = P.vt_x + toff; double* ty = P.vt_y + toff; double* typ = P.vt_yp + toff; double* tsg = P.vt_sig + toff;
   // streaming YPC1 / SIGS state: previous point, previous interval, YP(k-2)
-  double xm1 = 0.0, ym1 = 0.0, ym2 = 0.0, Sp = 0.0, DXp = 0.0, YPp = 0.0;
+  double xm1 = 0.0, ym1 = 0.0, Sp = 0.0, DXp = 0.0, YPp = 0.0;
   bool ypc_fail = false;
-  int sigerr = 0;
 #pragma unroll 1
   for (int k = 1; k <= p2; k++) {
-    double mx[3], my[3];
-#pragma unroll
-    for (int s = 0; s < 3; s++) {
-      if (k == 1) { mx[s] = wz1[s]; my[s] = kh1[s]; }            // :197-210 pinned ends
-      else if (k == p2) { mx[s] = wzN[s]; my[s] = khN[s]; }
-      else {                                                      // :184-194 8-point average
-        my[s] = (win[s][0] + win[s][1] + win[s][2] + win[s][3] + win[s][4] + win[s][5] + win[s][6] + win[s][7]) / 8.0;
-        const double xa = NEWX(s, k);
-        mx[s] = xa + (NEWX(s, k + 7) - xa) / 2.0;
-      }
-    }
-    // :220-275 interpolation to the internal times, clamp, Simpson in time
-    const double ex1 = mx[0], ex2 = (P.p == 1) ? mx[0] : mx[1], ex3 = (P.p == 1) ? mx[1] : mx[2];
-    const double ey1 = my[0], ey2 = (P.p == 1) ? my[0] : my[1], ey3 = (P.p == 1) ? my[1] : my[2];
-    const double fxb = polintd3(P.ex0, P.ex1, P.ex2, ex1, ex2, ex3, P.ix0);
-    const double fxc = polintd3(P.ex0, P.ex1, P.ex2, ex1, ex2, ex3, P.ix1);
-    const double fxf = polintd3(P.ex0, P.ex1, P.ex2, ex1, ex2, ex3, P.ix2);
-    double fyb = polintd3(P.ex0, P.ex1, P.ex2, ey1, ey2, ey3, P.ix0);
-    double fyc = polintd3(P.ex0, P.ex1, P.ex2, ey1, ey2, ey3, P.ix1);
-    double fyf = polintd3(P.ex0, P.ex1, P.ex2, ey1, ey2, ey3, P.ix2);
-    if (fyb < 0.0) fyb = 0.0;
-    if (fyc < 0.0) fyc = 0.0;
-    if (fyf < 0.0) fyf = 0.0;
-    const double yk = (fyb + 4.0 * fyc + fyf) / 6.0;
-    const double xk = (fxb + 4.0 * fxc + fxf) / 6.0;
-    tx[(size_t)(k - 1) * N] = xk;
-    ty[(size_t)(k - 1) * N] = yk;
-    typ[(size_t)(k - 1) * N] = 0.0;
-    tsg[(size_t)(k - 1) * N] = 0.0;
-    // TSPSI(p2) as a stream: YPC1 (tension_module.f90:852-977), SIGS (:314-781)
-    if (k >= 2 && !ypc_fail) {
-      const double DX = xk - xm1;  // DX_{k-1}
-      if (DX <= 0.0) {
-        ypc_fail = true;  // YPC1 fails -> TSPSI returns IER = -4 and SIGS never runs
-      } else {
-        const double S = (yk - ym1) / DX;  // S_{k-1}
-        if (k == 3) {
-          YPp = ypc1_end(Sp, Sp + DXp * (Sp - S) / (DXp + DX));  // YP(1)
-          typ[0] = YPp;
-        }
-        if (k >= 3) {
-          const double YPc = ypc1_mid(DXp, DX, Sp, S);  // YP(k-1)
-          typ[(size_t)(k - 2) * N] = YPc;
-          if (sigerr == 0)  // interval k-2
-            tsg[(size_t)(k - 3) * N] = sigs_interval(DXp, ym2, ym1, YPp, YPc, sigerr);
-          YPp = YPc;
-        }
-        if (k == p2) {
-          const double YPn = ypc1_end(S, S + DX * (S - Sp) / (DXp + DX));  // YP(N)
-          typ[(size_t)(k - 1) * N] = YPn;
-          if (sigerr == 0)  // interval N-1
-            tsg[(size_t)(k - 2) * N] = sigs_interval(DX, ym1, yk, YPp, YPn, sigerr);
-        }
-        Sp = S;
-        DXp = DX;
-      }
-    }
-    ym2 = ym1;
-    xm1 = xk;
-    ym1 = yk;
-    // slide the 8-point window: drop newy(k), append newy(k+8)
-    if (k + 8 <= p2 + 7) {
+    if (act) {
+      double mx[3], my[3];
 #pragma unroll
       for (int s = 0; s < 3; s++) {
-        const double nv = NEWY(s, k + 8);
+        if (k == 1) { mx[s] = wz1[s]; my[s] = kh1[s]; }            // :197-210 pinned ends
+        else if (k == p2) { mx[s] = wzN[s]; my[s] = khN[s]; }
+        else {                                                      // :184-194 8-point average
+          my[s] = (win[s][0] + win[s][1] + win[s][2] + win[s][3] + win[s][4] + win[s][5] + win[s][6] + win[s][7]) / 8.0;
+          const double xa = NEWX(s, k);
+          mx[s] = xa + (NEWX(s, k + 7) - xa) / 2.0;
+        }
+      }
+      // :220-275 interpolation to the internal times, clamp, Simpson in time
+      const double ex1 = mx[0], ex2 = (P.p == 1) ? mx[0] : mx[1], ex3 = (P.p == 1) ? mx[1] : mx[2];
+      const double ey1 = my[0], ey2 = (P.p == 1) ? my[0] : my[1], ey3 = (P.p == 1) ? my[1] : my[2];
+      double fxb, fxc, fxf, fyb, fyc, fyf;
+      polintd3x3(P, ex1, ex2, ex3, fxb, fxc, fxf);
+      polintd3x3(P, ey1, ey2, ey3, fyb, fyc, fyf);
+      if (fyb < 0.0) fyb = 0.0;
+      if (fyc < 0.0) fyc = 0.0;
+      if (fyf < 0.0) fyf = 0.0;
+      const double yk = div_by(fyb + 4.0 * fyc + fyf, 6.0, P.r_6, P.fastdiv != 0);
+      const double xk = div_by(fxb + 4.0 * fxc + fxf, 6.0, P.r_6, P.fastdiv != 0);
+      tx[(size_t)(k - 1) * TS] = xk;
+      ty[(size_t)(k - 1) * TS] = yk;
+      typ[(size_t)(k - 1) * TS] = 0.0;
+      tsg[(size_t)(k - 1) * TS] = 0.0;
+      // TSPSI(p2) as a stream: YPC1 (tension_module.f90:852-977), SIGS (:314-781)
+      if (k >= 2 && !ypc_fail) {
+        const double DX = xk - xm1;  // DX_{k-1}
+        if (DX <= 0.0) {
+          ypc_fail = true;  // YPC1 fails -> TSPSI returns IER = -4 and SIGS never runs
+        } else {
+          const double S = (yk - ym1) / DX;  // S_{k-1}
+          if (k == 3) {
+            YPp = ypc1_end(Sp, Sp + DXp * (Sp - S) / (DXp + DX));  // YP(1)
+            typ[0] = YPp;
+          }
+          if (k >= 3) {
+            const double YPc = ypc1_mid(DXp, DX, Sp, S);  // YP(k-1)
+            typ[(size_t)(k - 2) * TS] = YPc;
+            YPp = YPc;
+          }
+          if (k == p2) {
+            const double YPn = ypc1_end(S, S + DX * (S - Sp) / (DXp + DX));  // YP(N)
+            typ[(size_t)(k - 1) * TS] = YPn;
+          }
+          Sp = S;
+          DXp = DX;
+        }
+      }
+      xm1 = xk;
+      ym1 = yk;
+      // slide the 8-point window: drop newy(k), append newy(k+8)
+      if (k + 8 <= p2 + 7) {
 #pragma unroll
-        for (int q = 0; q < 7; q++) win[s][q] = win[s][q + 1];
-        win[s][7] = nv;
+        for (int s = 0; s < 3; s++) {
+          const double nv = NEWY(s, k + 8);
+#pragma unroll
+          for (int qi = 0; qi < 7; qi++) win[s][qi] = win[s][qi + 1];
+          win[s][7] = nv;
+        }
       }
     }
   }
-  if (ypc_fail) {
-    // SIGS was never called: every tension factor stays 0 and SigErr = 0
-    for (int k = 0; k < p2; k++) tsg[(size_t)k * N] = 0.0;
-    sigerr = 0;
+  if (ypc_fail) P.ws_i[n] |= FL_VT_YPCFAIL;
+}
+
+// SIGS over the finished tables (tension_module.f90:314-781): intervals whose tension
+// is known without iterating are stored at once, the others are queued for the wave.
+// Whole waves stay converged (ballots); a particle whose YPC1 failed is skipped: TSPSI
+// returned IER = -4 before SIGS, so its tensions stay 0 and SigErr = 0.
+__global__ __launch_bounds__(256) void k_vt_sigs(const StepParams P) {
+  __shared__ VtScratch vsc[4];
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wave_first = n - lane;
+  VtScratch& q = vsc[threadIdx.x >> 6];
+  q.failed[lane] = 0;
+  const int fl = (n < P.numpar) ? P.ws_i[n] : 0;
+  const bool act = (fl & FL_ACT) != 0;
+  const bool ypc_fail = (fl & FL_VT_YPCFAIL) != 0;
+  const int na = act ? n : 0;
+  const int p2 = 4 * P.ws;
+  const size_t TS = 64, toff = (size_t)(na >> 6) * (size_t)p2 * 64 + (size_t)(na & 63);
+  const double* tx = P.vt_x + toff; const double* ty = P.vt_y + toff; const double* typ = P.vt_yp + toff;
+  double* tsg = P.vt_sig + toff;
+  int ntask = 0;  // wave-uniform
+  {
+    double x0 = 0.0, y0 = 0.0, p0 = 0.0;
+    const bool run = act && !ypc_fail;
+    if (run) { x0 = tx[0]; y0 = ty[0]; p0 = typ[0]; }
+#pragma unroll 1
+    for (int k0 = 0; k0 < p2 - 1; k0 += 4) {
+      // the table comes back from HBM: 12 loads in flight per lane, then the arithmetic
+      double xs[4], ys[4], ps[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int kk = (k0 + j + 1 < p2) ? (k0 + j + 1) : (p2 - 1);
+        xs[j] = ys[j] = ps[j] = 0.0;
+        if (run) { xs[j] = tx[(size_t)kk * TS]; ys[j] = ty[(size_t)kk * TS]; ps[j] = typ[(size_t)kk * TS]; }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (k0 + j < p2 - 1) {
+          if (ntask > LT_VT_CAP - 64) {
+            vt_run_tasks(q, ntask, lane, wave_first, P.vt_sig, p2);
+            ntask = 0;
+          }
+          double S = 0.0, sg = 0.0;
+          bool need = false;
+          if (run) {
+            S = (ys[j] - y0) / (xs[j] - x0);
+            need = !sigs_eval_known(S, p0, ps[j], sg);
+            if (!need) tsg[(size_t)(k0 + j) * TS] = sg;
+          }
+          const unsigned long long m = __ballot(need);
+          if (need) {
+            const int idx = ntask + __popcll(m & ((1ull << lane) - 1ull));
+            q.S[idx] = S; q.S1[idx] = p0; q.S2[idx] = ps[j];
+            q.where[idx] = (unsigned short)(k0 + j);
+            q.lane[idx] = (unsigned char)lane;
+          }
+          ntask += __popcll(m);
+          x0 = xs[j]; y0 = ys[j]; p0 = ps[j];
+        }
+      }
+    }
   }
+  vt_run_tasks(q, ntask, lane, wave_first, P.vt_sig, p2);
+  if (act && q.failed[lane]) P.ws_i[n] = fl | FL_VT_SIGERR;
+}
+
+// :282-335 random displacement model, idt/2 sub-steps of 2 s
+__global__ __launch_bounds__(256) void k_vt_walk(const StepParams P) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= P.numpar) return;
+  const int fl = P.ws_i[n];
+  if (!(fl & FL_ACT)) return;
+  const bool ypc_fail = (fl & FL_VT_YPCFAIL) != 0;
+  const int sigerr = (fl & FL_VT_SIGERR) ? 1 : 0;
+  const size_t N = (size_t)P.numpar;
+  double* wsd = P.ws_d + n;
+  const int p2 = 4 * P.ws;
+  const size_t TS = 64, toff = (size_t)(n >> 6) * (size_t)p2 * 64 + (size_t)(n & 63);
+  const double* tx = P.vt_x + toff; const double* ty = P.vt_y + toff; const double* typ = P.vt_yp + toff;
+  const double* tsg = P.vt_sig + toff;
+  const double P_depth = wsd[(size_t)WS_PDEPTH * N], P_zc = wsd[(size_t)WS_PZ1 * N];
+  const double P_zetac = wsd[(size_t)WS_ZETA1 * N];
   // :282-335 random displacement model, idt/2 sub-steps of 2 s
   const double background = (double)1.0E-6f, deltat = 2.0;
   const int loop = P.idt / (int)deltat;
@@ -1301,12 +1473,22 @@ __global__ __launch_bounds__(256, 2) void k_vturb(const StepParams P) {
                           (P.HTurbOn ? 4ull : 0ull);
   double ParZc = P_zc;
   int il = 1;
+  VtInterval ci;
+  ci.I = 0; ci.X1 = ci.X2 = ci.Y1 = ci.Y2 = ci.P1 = ci.P2 = ci.SG = 0.0;
+  const bool cached = (sigerr == 0) && !ypc_fail;
 #pragma unroll 1
   for (int i = 1; i <= loop; i++) {
+    // the two raw words of this sub-step's deviate do not depend on the walk: ask first
+    const uint32_t raw1 = P.rng_ring[di & P.rng_mask], raw2 = P.rng_ring[(di + 1) & P.rng_mask];
+    di += 2;
     double Kprimec = 0.0;
     if (!(ParZc < P_depth || ParZc > P_zetac)) {
-      if (sigerr == 0) Kprimec = hval_table<true>(ParZc, p2, tx, ty, typ, tsg, N, il);
-      else { double yy; linint_n(tx, ty, p2, (int)N, ParZc, yy, Kprimec); }
+      if (cached) {
+        vt_seek(ci, ParZc, p2, tx, ty, typ, tsg, TS);
+        Kprimec = hpval_interval(ParZc, ci.X1, ci.X2, ci.Y1, ci.Y2, ci.P1, ci.P2, ci.SG);
+      } else if (sigerr == 0) {
+        Kprimec = hval_table<true>(ParZc, p2, tx, ty, typ, tsg, TS, il);
+      } else { double yy; linint_n(tx, ty, p2, (int)TS, ParZc, yy, Kprimec); }
     }
     const double KprimeZc = -1.0 * Kprimec * deltat;
     const double Z3rdc = ParZc + 0.5 * KprimeZc;
@@ -1314,12 +1496,18 @@ __global__ __launch_bounds__(256, 2) void k_vturb(const StepParams P) {
     if (Z3rdc < P_depth || Z3rdc > P_zetac) {
       KH3rdc = background;
     } else {
-      if (sigerr == 0) KH3rdc = hval_table<false>(Z3rdc, p2, tx, ty, typ, tsg, N, il);
-      else { double mm; linint_n(tx, ty, p2, (int)N, Z3rdc, KH3rdc, mm); }
+      if (cached) {
+        vt_seek(ci, Z3rdc, p2, tx, ty, typ, tsg, TS);
+        KH3rdc = hval_interval(Z3rdc, ci.X1, ci.X2, ci.Y1, ci.Y2, ci.P1, ci.P2, ci.SG);
+      } else if (sigerr == 0) {
+        KH3rdc = hval_table<false>(Z3rdc, p2, tx, ty, typ, tsg, TS, il);
+      } else { double mm; linint_n(tx, ty, p2, (int)TS, Z3rdc, KH3rdc, mm); }
       if (KH3rdc < background) KH3rdc = background;
     }
-    const double DEV = draw_norm(P, di);
-    di += 2;
+    // norm(), norm_module.f90:25-39
+    const double dev1 = ((double)ltmt_temper(raw1) + 0.5) / 4294967296.0;
+    const double dev2 = ((double)ltmt_temper(raw2) + 0.5) / 4294967296.0;
+    const double DEV = sqrt(-2.0 * log(dev1)) * cos(2.0 * P.PI * dev2);
     // (2/r * KH3rd * deltat)**0.5 with r = 1
     ParZc = ParZc + KprimeZc + DEV * sqrt(2.0 / 1.0 * KH3rdc * deltat);
   }

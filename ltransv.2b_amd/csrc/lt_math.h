@@ -30,6 +30,40 @@ namespace ltd {
 LT_DEV double dmin(double a, double b) { return (a < b) ? a : b; }
 LT_DEV double dmax(double a, double b) { return (a > b) ? a : b; }
 
+// a / b for a divisor b that is the same for every particle, given y = RN(1/b)
+// from the host.  q0 = a*y is within 2 ulp; one residual correction makes it a
+// faithful quotient and the second one (Markstein's theorem, valid unless the
+// significand of b is all ones -- the host checks and then clears `ok`) makes it
+// the correctly rounded quotient, i.e. exactly the value of `a / b`.
+// 5 full-rate operations instead of the ~14-instruction v_rcp_f64 sequence.
+LT_DEV double div_by(double a, double b, double y, bool ok) {
+  if (!ok) return a / b;
+  double q = a * y;
+  double r = __builtin_fma(-b, q, a);
+  q = __builtin_fma(r, y, q);
+  r = __builtin_fma(-b, q, a);
+  return __builtin_fma(r, y, q);
+}
+
+// SIGS' convexity Newton iteration (tension_module.f90:531-580) gives up after
+// 10000 evaluations (SigErr).  Each iterate is a function of the previous one
+// only, so once an iterate REPEATS the sequence is periodic, none of the states
+// on the cycle passed a stopping test, and the reference is certain to run into
+// its cap: the outcome (SigErr) is known at the first repeat.  Brent's cycle
+// detection finds it within ~2x(tail + period) iterations instead of 10000
+// (the usual case is a 2-cycle in the last ulp).  A NaN iterate never passes a
+// stopping test either.
+struct NewtonCycle {
+  double mark;
+  int power, lam;
+  __device__ __forceinline__ explicit NewtonCycle(double s0) : mark(s0), power(1), lam(0) {}
+  __device__ __forceinline__ bool repeats(double s) {
+    if (s == mark || s != s) return true;
+    if (++lam == power) { mark = s; power <<= 1; lam = 0; }
+    return false;
+  }
+};
+
 // ---------------------------------------------------------------- INT_MOD
 // polintd, interpolation_module.f90:70-107 (n = 3)
 LT_DEV double polintd3(double xa1, double xa2, double xa3, double ya1, double ya2, double ya3,
@@ -148,6 +182,7 @@ LT_DEV double sigs_interval(double DX, double Y1, double Y2, double S1, double S
     // convexity: Newton on F(SIG) = SIG*COSHM/SINHM - TP1  :531-580
     SIG = sqrt(10.0 * T - 20.0);
     int NIT = 0;
+    NewtonCycle cyc(SIG);
     for (;;) {
       double T1, FP;
       if (SIG <= .5) {
@@ -171,6 +206,10 @@ LT_DEV double sigs_interval(double DX, double Y1, double Y2, double S1, double S
       double DSIG = -F / FP;
       if (fabs(DSIG) <= RTOL * SIG || (F >= 0.0 && F <= FTOL) || fabs(F) <= RTOL) break;
       SIG = SIG + DSIG;
+      if (cyc.repeats(SIG)) {
+        sigerr = sigerr + 1;
+        return 0.0;
+      }
     }
     SIG = dmin(SIG, SBIG);
     return (SIG > 0.0) ? SIG : 0.0;
@@ -488,6 +527,7 @@ LT_DEV double sigs_newton(double T, bool& failed) {
   double SIG = sqrt(10.0 * T - 20.0);
   int NIT = 0;
   failed = false;
+  NewtonCycle cyc(SIG);
   for (;;) {
     double T1, FP;
     if (SIG <= .5) {
@@ -511,6 +551,10 @@ LT_DEV double sigs_newton(double T, bool& failed) {
     double DSIG = -F / FP;
     if (fabs(DSIG) <= RTOL * SIG || (F >= 0.0 && F <= FTOL) || fabs(F) <= RTOL) break;
     SIG = SIG + DSIG;
+    if (cyc.repeats(SIG)) {
+      failed = true;
+      return 0.0;
+    }
   }
   SIG = dmin(SIG, SBIG);
   return (SIG > 0.0) ? SIG : 0.0;
