@@ -1141,28 +1141,33 @@ LT_DEV double hval_table(double T, int n, const double* x, const double* y, cons
 // polintd at the three internal times ix(1..3) of one (ex, ey) triple
 // (ver_turb_module.f90:236-238,258-260): the two inner quotients of polintd do
 // not depend on x, so they are formed once (same values, 5 divisions instead of 9).
+LT_DEV double polintd_shared(double xa1, double xa2, double xa3, double ya1, double ya2, double ya3,
+                             double q32, double q21, double r13, bool fd, double x) {
+  int ns = 1;
+  double dif = fabs(x - xa1), dift = fabs(x - xa2);
+  if (dift < dif) { ns = 2; dif = dift; }
+  dift = fabs(x - xa3);
+  if (dift < dif) { ns = 3; dif = dift; }
+  double c = (xa2 - x) * q32;
+  c = c - (xa2 - x) * q21;
+  c = div_by(c, xa1 - xa3, r13, fd);
+  const double a = (ns == 3) ? q32 : q21;
+  // xa(ns) - x picked among the three differences (selects on computed values only)
+  const double d1 = xa1 - x, d2 = xa2 - x, d3 = xa3 - x;
+  const double bb = (ns == 3) ? d3 : d1;
+  const double yns = (ns == 1) ? ya1 : (ns == 2) ? ya2 : ya3;
+  const double dns = (ns == 1) ? d1 : (ns == 2) ? d2 : d3;
+  return yns + dns * a + bb * c;
+}
 LT_DEV void polintd3x3(const StepParams& P, double ya1, double ya2, double ya3,
                        double& rb, double& rc, double& rf) {
   const double xa1 = P.ex0, xa2 = P.ex1, xa3 = P.ex2;
   const bool fd = P.fastdiv != 0;
   const double q32 = div_by(ya3 - ya2, xa2 - xa3, P.r_d23, fd);
   const double q21 = div_by(ya2 - ya1, xa1 - xa2, P.r_d12, fd);
-  auto one = [&](double x) -> double {
-    int ns = 1;
-    double dif = fabs(x - xa1), dift = fabs(x - xa2);
-    if (dift < dif) { ns = 2; dif = dift; }
-    dift = fabs(x - xa3);
-    if (dift < dif) { ns = 3; dif = dift; }
-    double c = (xa2 - x) * q32;
-    c = c - (xa2 - x) * q21;
-    c = div_by(c, xa1 - xa3, P.r_d13, fd);
-    const double a = (ns == 3) ? q32 : q21;
-    const double bb = (ns == 3) ? (xa3 - x) : (xa1 - x);
-    const double yns = (ns == 1) ? ya1 : (ns == 2) ? ya2 : ya3;
-    const double xns = (ns == 1) ? xa1 : (ns == 2) ? xa2 : xa3;
-    return yns + (xns - x) * a + bb * c;
-  };
-  rb = one(P.ix0); rc = one(P.ix1); rf = one(P.ix2);
+  rb = polintd_shared(xa1, xa2, xa3, ya1, ya2, ya3, q32, q21, P.r_d13, fd, P.ix0);
+  rc = polintd_shared(xa1, xa2, xa3, ya1, ya2, ya3, q32, q21, P.r_d13, fd, P.ix1);
+  rf = polintd_shared(xa1, xa2, xa3, ya1, ya2, ya3, q32, q21, P.r_d13, fd, P.ix2);
 }
 
 // The interval of the VTurb spline table a walk is in, kept in registers: HVAL and
@@ -1240,6 +1245,7 @@ LT_DEV void vt_run_tasks(VtScratch& q, int ntask, int lane, int wave_first, doub
 template <typename SlabT, int VT>
 __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
   __shared__ double lev[6 * LT_LEV_STRIDE];
+  __shared__ double wring[3][8][256];
   for (int i = threadIdx.x; i < 6 * LT_LEV_STRIDE; i += blockDim.x) lev[i] = P.lev[i];
   __syncthreads();
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1284,30 +1290,48 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
   auto NEWX = [&](int s, int j) -> double {  // :121-123
     return wz1[s] + div_by(((double)(float)(j - 4)) * rng_[s], (double)p2, P.r_p2, P.fastdiv != 0);
   };
-  // piecewise-linear profile segment per slot :126-163
+  // piecewise-linear profile segment per slot :126-163.  Moving up one level reuses
+  // the upper end of the previous segment (same values), and the Kh of the level after
+  // that was asked for one segment earlier, so its latency is off the critical path.
   int jlo[3] = {1, 1, 1};
-  double slope[3], icpt[3], wzhi[3];
-  auto SEGMENT = [&](int s) {
-    const double a = WZ(s, jlo[s]), b = WZ(s, jlo[s] + 1);
-    const double ka = KH(s, jlo[s]), kb = KH(s, jlo[s] + 1);
+  double slope[3], icpt[3], wzhi[3], khhi[3];
+  SlabT rawn[3][4];
+  auto RAW = [&](int s, int i) {
+    const size_t o = (size_t)(i - 1) * 3 + pslot[s], L3 = (size_t)ws * 3;
+    rawn[s][0] = K[(size_t)(rn.x - 1) * L3 + o]; rawn[s][1] = K[(size_t)(rn.y - 1) * L3 + o];
+    rawn[s][2] = K[(size_t)(rn.z - 1) * L3 + o]; rawn[s][3] = K[(size_t)(rn.w - 1) * L3 + o];
+  };
+  auto LINE = [&](int s, double a, double b, double ka, double kb) {
     slope[s] = (ka - kb) / (a - b);
     icpt[s] = ka - slope[s] * a;
     wzhi[s] = b;
+    khhi[s] = kb;
   };
 #pragma unroll
-  for (int s = 0; s < 3; s++) SEGMENT(s);
-  auto NEWY = [&](int s, int j) -> double {  // newy{b,c,f}(j), j = 1..p2+7
-    if (j <= 4) return kh1[0];             // :170-173: all three low pads use Pwc_KHb(1)
-    if (j >= p2 + 4) return khN[s];
+  for (int s = 0; s < 3; s++) {
+    LINE(s, wz1[s], WZ(s, 2), kh1[s], KH(s, 2));
+    RAW(s, 3);  // ws >= 6
+  }
+  auto NEWY = [&](int s, int j) -> double {  // newy{b,c,f}(j), j = 5..p2+3
     const double xj = NEWX(s, j);
-    while (!(wzhi[s] > xj) && jlo[s] < ws - 1) { jlo[s] += 1; SEGMENT(s); }
+    while (!(wzhi[s] > xj) && jlo[s] < ws - 1) {
+      jlo[s] += 1;
+      const double kb = apply_getinterp(w0, (double)rawn[s][0], (double)rawn[s][1], (double)rawn[s][2],
+                                        (double)rawn[s][3]);
+      LINE(s, wzhi[s], WZ(s, jlo[s] + 1), khhi[s], kb);
+      if (jlo[s] + 2 <= ws) RAW(s, jlo[s] + 2);
+    }
     return slope[s] * xj + icpt[s];
   };
-  double win[3][8];
+  // newy(1..8): the low pads (:170-173, all three use Pwc_KHb(1)) and the first 4 points.
+  // The 8-point window lives in LDS as a ring: newy(j) of slot s at wring[s][j & 7][thread].
 #pragma unroll
-  for (int s = 0; s < 3; s++)
+  for (int s = 0; s < 3; s++) {
 #pragma unroll
-    for (int qi = 0; qi < 8; qi++) win[s][qi] = act ? NEWY(s, 1 + qi) : 0.0;
+    for (int j = 1; j <= 4; j++) wring[s][j & 7][threadIdx.x] = kh1[0];
+#pragma unroll
+    for (int j = 5; j <= 8; j++) wring[s][j & 7][threadIdx.x] = NEWY(s, j);
+  }
   // table layout: [wave][k][lane], a wave streams one contiguous 4*ws*512 B block per array
   const size_t TS = 64, toff = (size_t)(na >> 6) * (size_t)p2 * 64 + (size_t)(na & 63);
   double* tx = P.vt_x + toff; double* ty = P.vt_y + toff; double* typ = P.vt_yp + toff; double* tsg = P.vt_sig + toff;
@@ -1323,14 +1347,18 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
         if (k == 1) { mx[s] = wz1[s]; my[s] = kh1[s]; }            // :197-210 pinned ends
         else if (k == p2) { mx[s] = wzN[s]; my[s] = khN[s]; }
         else {                                                      // :184-194 8-point average
-          my[s] = (win[s][0] + win[s][1] + win[s][2] + win[s][3] + win[s][4] + win[s][5] + win[s][6] + win[s][7]) / 8.0;
+          const int t = threadIdx.x;
+          my[s] = (wring[s][k & 7][t] + wring[s][(k + 1) & 7][t] + wring[s][(k + 2) & 7][t] + wring[s][(k + 3) & 7][t] +
+                   wring[s][(k + 4) & 7][t] + wring[s][(k + 5) & 7][t] + wring[s][(k + 6) & 7][t] + wring[s][(k + 7) & 7][t]) / 8.0;
           const double xa = NEWX(s, k);
           mx[s] = xa + (NEWX(s, k + 7) - xa) / 2.0;
         }
       }
       // :220-275 interpolation to the internal times, clamp, Simpson in time
-      const double ex1 = mx[0], ex2 = (P.p == 1) ? mx[0] : mx[1], ex3 = (P.p == 1) ? mx[1] : mx[2];
-      const double ey1 = my[0], ey2 = (P.p == 1) ? my[0] : my[1], ey3 = (P.p == 1) ? my[1] : my[2];
+      // (selects on values, not on array elements: those would turn into stack indexing)
+      const double mx0 = mx[0], mx1 = mx[1], mx2 = mx[2], my0 = my[0], my1 = my[1], my2 = my[2];
+      double ex1 = mx0, ex2 = mx1, ex3 = mx2, ey1 = my0, ey2 = my1, ey3 = my2;
+      if (P.p == 1) { ex2 = mx0; ex3 = mx1; ey2 = my0; ey3 = my1; }
       double fxb, fxc, fxf, fyb, fyc, fyf;
       polintd3x3(P, ex1, ex2, ex3, fxb, fxc, fxf);
       polintd3x3(P, ey1, ey2, ey3, fyb, fyc, fyf);
@@ -1373,10 +1401,7 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
       if (k + 8 <= p2 + 7) {
 #pragma unroll
         for (int s = 0; s < 3; s++) {
-          const double nv = NEWY(s, k + 8);
-#pragma unroll
-          for (int qi = 0; qi < 7; qi++) win[s][qi] = win[s][qi + 1];
-          win[s][7] = nv;
+          wring[s][k & 7][threadIdx.x] = (k + 8 >= p2 + 4) ? khN[s] : NEWY(s, k + 8);  // high pads
         }
       }
     }
