@@ -90,6 +90,9 @@ struct lt_engine {
   // optional HIP-event timing of the step kernel (lt_profile_*)
   bool prof_on = false;
   std::vector<hipEvent_t> prof_ev;  // pairs (start, stop)
+  hipStream_t rng_stream = nullptr;  // the MT19937 blocks of a step are generated beside k_rk
+  hipEvent_t rng_done = nullptr;
+  bool rng_pending = false;
   size_t prof_used = 0;
 };
 
@@ -423,7 +426,8 @@ int rng_init_device(lt_engine* e) {
 }
 
 // make stream words [first, last] resident in the ring
-int rng_ensure(lt_engine* e, uint64_t first, uint64_t last) {
+int rng_ensure(lt_engine* e, uint64_t first, uint64_t last, hipStream_t gen_stream = nullptr) {
+  if (!gen_stream) gen_stream = e->stream;
   if (!e->rng_ready) TRY(rng_init_device(e));
   const long long b_lo = (long long)(first >> RNG_LOG2_S) - 1;  // keep one block of history
   const long long b_hi = (long long)(last >> RNG_LOG2_S);
@@ -450,7 +454,7 @@ int rng_ensure(lt_engine* e, uint64_t first, uint64_t last) {
   while (e->rng_next_block <= b_hi) {
     const int P = e->rng_P;
     long long nb = std::min<long long>(P, b_hi - e->rng_next_block + 1);
-    hipLaunchKernelGGL(ltmt::k_mt_block, dim3((unsigned)nb), dim3(256), ltmt::LDS_BYTES, e->stream,
+    hipLaunchKernelGGL(ltmt::k_mt_block, dim3((unsigned)nb), dim3(256), ltmt::LDS_BYTES, gen_stream,
                        (uint32_t*)e->rng_states.p, (uint32_t*)e->rng_ring.p, e->rng_next_block,
                        std::max<long long>(b_lo, 0), P,
                        e->rng_R, (const uint32_t*)e->rng_gJ.p, (int)RNG_S, P > 1 ? 1 : 0);
@@ -470,6 +474,11 @@ void launch_rk_t(lt_engine* e, const StepParams& P, unsigned blocks) {
     default: hipLaunchKernelGGL((k_rk<SlabT, 3, LT_RK_WAVES>), dim3(blocks), dim3(256), 0, e->stream, P); break;
   }
 }
+// the first consumer of the step's random words waits for the generators
+void wait_rng(lt_engine* e) {
+  if (e->rng_pending) (void)hipStreamWaitEvent(e->stream, e->rng_done, 0);
+  e->rng_pending = false;
+}
 template <typename SlabT>
 void launch_vturb_t(lt_engine* e, const StepParams& P, unsigned blocks) {
   switch (e->cfg.Vtransform) {
@@ -478,6 +487,7 @@ void launch_vturb_t(lt_engine* e, const StepParams& P, unsigned blocks) {
     default: hipLaunchKernelGGL((k_vt_table<SlabT, 3>), dim3(blocks), dim3(256), 0, e->stream, P); break;
   }
   hipLaunchKernelGGL(k_vt_sigs, dim3(blocks), dim3(256), 0, e->stream, P);
+  wait_rng(e);
   hipLaunchKernelGGL(k_vt_walk, dim3(blocks), dim3(256), 0, e->stream, P);
 }
 void launch_vturb(lt_engine* e, const StepParams& P, unsigned blocks) {
@@ -521,7 +531,9 @@ int lt_create(const lt_config* cfg, lt_engine** out) {
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
   }
   if (dev >= ndev || hipSetDevice(dev) != hipSuccess ||
-      hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+      hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&e->rng_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&e->rng_done, hipEventDisableTiming) != hipSuccess) {
     delete e;
     return LT_ERR_DEVICE;
   }
@@ -565,6 +577,8 @@ int lt_destroy(lt_engine* e) {
     if (b->p) (void)hipFree(b->p);
   for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
   if (e->h_counters) (void)hipHostFree(e->h_counters);
+  if (e->rng_done) (void)hipEventDestroy(e->rng_done);
+  if (e->rng_stream) (void)hipStreamDestroy(e->rng_stream);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return LT_OK;
@@ -973,7 +987,13 @@ int lt_step(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32
       const uint64_t D = (uint64_t)P.rng_draws;
       if (!e->rng_ready) TRY(rng_init_device(e));
       const uint64_t base = e->rng_cur + D * (uint64_t)before;
-      if (own > 0) TRY(rng_ensure(e, base, base + D * (uint64_t)own));
+      if (own > 0) {
+        // everything earlier on e->stream has completed (the synchronize above), so the
+        // generators may overwrite old ring blocks while k_rk runs on the main stream
+        TRY(rng_ensure(e, base, base + D * (uint64_t)own, e->rng_stream));
+        HIPCHK(e, hipEventRecord(e->rng_done, e->rng_stream));
+        e->rng_pending = true;
+      }
       P.rng_ring = (const uint32_t*)e->rng_ring.p;
       P.rng_mask = (unsigned long long)e->rng_R * RNG_S - 1ull;
       P.rng_base = base;
@@ -999,6 +1019,7 @@ int lt_step(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32
       HIPCHK(e, hipEventRecord(e->prof_ev[e->prof_used + 1], e->stream));
       e->prof_used += 2;
     }
+    wait_rng(e);
     hipLaunchKernelGGL(k_post, dim3(blocks), dim3(256), 0, e->stream, P);
     HIPCHK(e, hipGetLastError());
   }
