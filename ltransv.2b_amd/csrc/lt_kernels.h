@@ -1369,13 +1369,12 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
       const double xk = div_by(fxb + 4.0 * fxc + fxf, 6.0, P.r_6, P.fastdiv != 0);
       tx[(size_t)(k - 1) * TS] = xk;
       ty[(size_t)(k - 1) * TS] = yk;
-      typ[(size_t)(k - 1) * TS] = 0.0;
-      tsg[(size_t)(k - 1) * TS] = 0.0;
       // TSPSI(p2) as a stream: YPC1 (tension_module.f90:852-977), SIGS (:314-781)
       if (k >= 2 && !ypc_fail) {
         const double DX = xk - xm1;  // DX_{k-1}
         if (DX <= 0.0) {
           ypc_fail = true;  // YPC1 fails -> TSPSI returns IER = -4 and SIGS never runs
+          typ[(size_t)(k - 2) * TS] = 0.0;  // derivatives not reached stay 0
         } else {
           const double S = (yk - ym1) / DX;  // S_{k-1}
           if (k == 3) {
@@ -1395,6 +1394,7 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
           DXp = DX;
         }
       }
+      if (ypc_fail) typ[(size_t)(k - 1) * TS] = 0.0;
       xm1 = xk;
       ym1 = yk;
       // slide the 8-point window: drop newy(k), append newy(k+8)
@@ -1432,6 +1432,8 @@ __global__ __launch_bounds__(256) void k_vt_sigs(const StepParams P) {
   {
     double x0 = 0.0, y0 = 0.0, p0 = 0.0;
     const bool run = act && !ypc_fail;
+    if (act && ypc_fail)
+      for (int k = 0; k < p2 - 1; k++) tsg[(size_t)k * TS] = 0.0;
     if (run) { x0 = tx[0]; y0 = ty[0]; p0 = typ[0]; }
 #pragma unroll 1
     for (int k0 = 0; k0 < p2 - 1; k0 += 4) {
@@ -1475,7 +1477,9 @@ __global__ __launch_bounds__(256) void k_vt_sigs(const StepParams P) {
 }
 
 // :282-335 random displacement model, idt/2 sub-steps of 2 s
+struct __attribute__((packed, aligned(4))) RawWords4 { uint32_t a, b, c, d; };
 __global__ __launch_bounds__(256) void k_vt_walk(const StepParams P) {
+  __shared__ uint2 rbuf[8][256];
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= P.numpar) return;
   const int fl = P.ws_i[n];
@@ -1503,8 +1507,29 @@ __global__ __launch_bounds__(256) void k_vt_walk(const StepParams P) {
   const bool cached = (sigerr == 0) && !ypc_fail;
 #pragma unroll 1
   for (int i = 1; i <= loop; i++) {
-    // the two raw words of this sub-step's deviate do not depend on the walk: ask first
-    const uint32_t raw1 = P.rng_ring[di & P.rng_mask], raw2 = P.rng_ring[(di + 1) & P.rng_mask];
+    // The particle's raw words are consecutive in the ring: 16 of them (8 sub-steps,
+    // one 64-B line) are fetched at a time with four 16-byte loads and parked in this
+    // thread's LDS column; word-by-word loads re-fetched the line for every sub-step.
+    const int sub = (i - 1) & 7;
+    if (sub == 0) {
+      const unsigned long long o = di & P.rng_mask;
+      if (o + 16 <= P.rng_mask + 1ull) {
+        const RawWords4* src = (const RawWords4*)(P.rng_ring + o);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const RawWords4 w = src[j];
+          rbuf[2 * j][threadIdx.x] = make_uint2(w.a, w.b);
+          rbuf[2 * j + 1][threadIdx.x] = make_uint2(w.c, w.d);
+        }
+      } else {  // the window wraps around the end of the ring
+#pragma unroll 1
+        for (int j = 0; j < 8; j++)
+          rbuf[j][threadIdx.x] = make_uint2(P.rng_ring[(di + 2 * j) & P.rng_mask],
+                                            P.rng_ring[(di + 2 * j + 1) & P.rng_mask]);
+      }
+    }
+    const uint2 rw = rbuf[sub][threadIdx.x];
+    const uint32_t raw1 = rw.x, raw2 = rw.y;
     di += 2;
     double Kprimec = 0.0;
     if (!(ParZc < P_depth || ParZc > P_zetac)) {
