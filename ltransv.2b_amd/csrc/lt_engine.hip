@@ -17,7 +17,7 @@
 
 #include "../../include/ltrans_hip.h"
 #ifndef LT_RK_WAVES
-#define LT_RK_WAVES 1
+#define LT_RK_WAVES 2  // k_rk is held to 256 VGPRs (2 waves per SIMD); the few spills sit outside the slot loop
 #endif
 #include "lt_kernels.h"
 #include "lt_mt.h"
@@ -1050,6 +1050,15 @@ int lt_get_stats(lt_engine* e, lt_step_stats* out) {
 
 /* diagnostics of the last step: [0] active [1] errors [2] SigErr fallbacks
  * [3] brute-force boundary scans [4] full point-in-polygon evaluations */
+#ifdef LT_RK_TIMING
+int lt_diag(unsigned long long* out) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(ltd::g_tim), 64);
+  unsigned long long z[8] = {0};
+  hipMemcpyToSymbol(HIP_SYMBOL(ltd::g_tim), z, 64);
+  return 0;
+}
+#endif
 int lt_get_counters(lt_engine* e, uint64_t* out8) {
   if (!e || !out8) return LT_ERR_ARG;
   TRY(lt_sync(e));

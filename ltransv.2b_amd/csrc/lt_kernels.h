@@ -502,6 +502,7 @@ struct Column {
 // s-level depth split into its zeta-independent part (one division per level
 // instead of one per level and slot): the operations and their order are those
 // of getSlevel/getWlevel (hydrodynamic_module.f90:2691-2777).
+template <typename T> struct __attribute__((packed, aligned(4))) Slab3 { T a, b, c; };  // one (node, level): 3 slots
 struct LevCoef { double a, b, c; };
 LT_DEV LevCoef level_coef(const double* tab, int k, double h, double hc, int Vtransform) {
   LevCoef r;
@@ -543,15 +544,36 @@ LT_DEV int level_window2(const double* tab, int n, double Z, const Column& C, do
 //   eval:  the evaluation interval's tension is not known without iterating:
 //          the task carries the interval, the lane that iterates evaluates HVAL.
 // Results of all 9 (variable, slot) fits of a stage are collected in res[][lane].
+#ifdef LT_RK_TIMING
+// development aid: wave time per section, accumulated in the wave's LDS scratch and
+// added to g_tim once at the end of the kernel
+__device__ unsigned long long g_tim[8];
+#define TICK(slot) do { const unsigned long long t_ = __builtin_readcyclecounter(); if ((threadIdx.x & 63) == 0) ws.tim[slot] += t_ - tprev_; tprev_ = __builtin_readcyclecounter(); } while (0)
+#define TICK_INIT unsigned long long tprev_ = __builtin_readcyclecounter()
+#else
+#ifdef LT_RK_MARK
+#define TICK(slot) asm volatile("; MARK " #slot)
+#else
+#define TICK(slot) do { } while (0)
+#endif
+#define TICK_INIT do { } while (0)
+#endif
+// One variable's three time slots are queued, then iterated (pass B), then combined in
+// time (pass C): at most 3 x 64 evaluation intervals and 6 x 64 check intervals.  The
+// evaluation queue holds the worst case; a check interval that finds the queue full
+// (never seen: ~1 % of them are candidates) sends its particle-step to k_rk_slow.
 #define LT_CHK_CAP 256
-#define LT_EV_CAP 128
+#define LT_EV_CAP 192
 struct WaveScratch {
   double chk[LT_CHK_CAP][2];         // num, den of T = MAX(D1/D2, D2/D1)
   unsigned short chk_owner[LT_CHK_CAP];  // lane | slot9 << 6
   double ev[LT_EV_CAP][7];           // x1,x2,y1,p1,p2,S,Pz
   unsigned short ev_owner[LT_EV_CAP];
-  double res[9][64];                 // H(P_z) per (variable*3+slot, lane)
+  double res[3][64];                 // H(P_z) per (slot, lane) of the current variable
   unsigned int errmask[64];          // bit (variable*3+slot): SigErr / degenerate window
+#ifdef LT_RK_TIMING
+  unsigned long long tim[8];
+#endif
 };
 
 // pass B: the queued iterations, 64 at a time, all lanes of the wave
@@ -582,7 +604,7 @@ LT_DEV void run_tasks(WaveScratch& ws, int nchk, int nev, int lane) {
     const int kind = sigs_classify(e[5], e[3], e[4], sg, T);
     if (kind == SIGK_NEWTON) sg = sigs_newton(T, failed);
     else if (kind == SIGK_SECANT) sg = sigs_secant(e[5], e[3], e[4]);  // rare
-    ws.res[o >> 6][o & 63] = hval_interval_s(e[6], e[0], e[1], e[2], e[3], e[4], e[5], sg);
+    ws.res[(o >> 6) % 3][o & 63] = hval_interval_s(e[6], e[0], e[1], e[2], e[3], e[4], e[5], sg);
     if (failed) atomicOr(&ws.errmask[o & 63], 1u << (o >> 6));
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -596,13 +618,14 @@ LT_DEV void run_tasks(WaveScratch& ws, int nchk, int nev, int lane) {
 // (coalesced, L2-resident) where needed instead of living in registers.
 template <typename SlabT, int VT>
 LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& ws, bool act, int n,
-                          double h, double Xs, double Ys, double Zs, int version, double& Uad,
-                          double& Vad, double& Wad, int& sigerr_count, bool& slow) {
+                          int er, int eu, int ev_, double h, double Xs, double Ys, double Zs, int version,
+                          double& Uad, double& Vad, double& Wad, int& sigerr_count, bool& slow) {
   const double* rtab = lev;
   const double* wtab = lev + 3 * LT_LEV_STRIDE;
   const int lane = threadIdx.x & 63;
   const size_t N = (size_t)P.numpar;
   const double* wsd = P.ws_d + (act ? n : 0);
+  TICK_INIT;
   Uad = 0.0; Vad = 0.0; Wad = 0.0;
   // regime tests :1481-1491
   bool zero = false, loglayer = false;
@@ -640,26 +663,62 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
     }
   }
   const bool spl = act && !zero && !loglayer;  // this lane fits splines
-  int nchk = 0, nev = 0;  // wave-uniform task counts of this stage
   unsigned degenerate = 0;
+  const double ixv = (version == 1) ? P.ix0 : (version == 2) ? P.ix1 : P.ix2;
   ws.errmask[lane] = 0;
-  // ---------------- pass A: fit without iterating, queue what must iterate
+  TICK(0);
+  // ---------------- pass A: fit without iterating, queue what must iterate.
+  // Memory latency is taken off the critical path by asking early: the node ids of the
+  // NEXT variable's element, and the 4x4 field values + zeta + depth of the NEXT time
+  // slot, are requested before the arithmetic of the current one (same registers: the
+  // raw values are dead once the horizontal interpolation has produced Y).
+  int4 nd_next = make_int4(1, 1, 1, 1);
+  if (act && !zero) nd_next = P.UE[eu - 1];
+  double zt = 0.0, pz = 0.0;
+  SlabT raw[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) raw[i] = (SlabT)0;
 #pragma unroll 1
   for (int var = 0; var < 3; var++) {
-    int4 nd = make_int4(1, 1, 1, 1);
+    const int4 nd = nd_next;
     const SlabT* F = (const SlabT*)((var == 0) ? P.U : (var == 1) ? P.V : P.W);
     const int L = (var == 2) ? P.ws : P.us;
     const double* tab = (var == 2) ? wtab : rtab;
     const int k0 = (var == 2) ? iii : ii;
+    int nchk = 0, nev = 0;  // wave-uniform task counts of this variable
+    // The 16 field values (4 nodes x 4 levels) of a time slot, its zeta and its depth are
+    // requested one slot ahead of their use, into the registers the previous slot's values
+    // just left (they are dead once the horizontal interpolation has produced Y).
+    const SlabT *b0 = F, *b1 = F, *b2 = F, *b3 = F;
+    if (spl) {
+      b0 = F + ((size_t)(nd.x - 1) * L + (k0 - 1)) * 3;
+      b1 = F + ((size_t)(nd.y - 1) * L + (k0 - 1)) * 3;
+      b2 = F + ((size_t)(nd.z - 1) * L + (k0 - 1)) * 3;
+      b3 = F + ((size_t)(nd.w - 1) * L + (k0 - 1)) * 3;
+    }
+    auto request = [&](int s) {
+      const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
+#pragma unroll
+      for (int l = 0; l < 4; l++) {
+        raw[4 * l + 0] = b0[3 * l + ps]; raw[4 * l + 1] = b1[3 * l + ps];
+        raw[4 * l + 2] = b2[3 * l + ps]; raw[4 * l + 3] = b3[3 * l + ps];
+      }
+      zt = wsd[(size_t)(WS_ZETA0 + s) * N];
+      pz = wsd[(size_t)(WS_PZ0 + s) * N];
+    };
+    if (spl) request(0);
     QuadWeights w;
     w.regime = 1; w.node_hit = 0; w.t = w.u = w.W1 = w.W2 = w.W3 = w.W4 = 0.0;
     if (act && !zero) {
       Quad q;
-      if (var == 2) { nd = P.RE[P.P_r_element[n] - 1]; q = load_quad_rho(P.rnode, nd); }
-      else if (var == 0) { nd = P.UE[P.P_u_element[n] - 1]; q = load_quad_xy(P.unode, nd); }
-      else { nd = P.VE[P.P_v_element[n] - 1]; q = load_quad_xy(P.vnode, nd); }
+      if (var == 2) q = load_quad_rho(P.rnode, nd);
+      else if (var == 0) q = load_quad_xy(P.unode, nd);
+      else q = load_quad_xy(P.vnode, nd);
+      if (var == 0) nd_next = P.VE[ev_ - 1];
+      else if (var == 1) nd_next = P.RE[er - 1];
       w = quad_weights(Xs, Ys, q.x, q.y);
     }
+    TICK(1);
     if (loglayer) {
       // log layer :1493-1522: level 1 of u,v; level 2 of w
       const int k = (var == 2) ? 2 : 1;
@@ -671,41 +730,32 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
         double val = apply_interp(w, fld(F, nd.x, L, k, ps), fld(F, nd.y, L, k, ps),
                                   fld(F, nd.z, L, k, ps), fld(F, nd.w, L, k, ps));
         double ztop = level_at(qt, zeta, h, VT);
-        ws.res[var * 3 + s][lane] = val * log10((Zs - wzb1) / P.z0) / log10((ztop - wzb1) / P.z0);
+        ws.res[s][lane] = val * log10((Zs - wzb1) / P.z0) / log10((ztop - wzb1) / P.z0);
       }
     }
     LevCoef lc[4];
-    const SlabT *b0 = F, *b1 = F, *b2 = F, *b3 = F;
     if (spl) {
 #pragma unroll
       for (int l = 0; l < 4; l++) lc[l] = level_coef(tab, k0 + l, h, P.hc, VT);
-      b0 = F + ((size_t)(nd.x - 1) * L + (k0 - 1)) * 3;
-      b1 = F + ((size_t)(nd.y - 1) * L + (k0 - 1)) * 3;
-      b2 = F + ((size_t)(nd.z - 1) * L + (k0 - 1)) * 3;
-      b3 = F + ((size_t)(nd.w - 1) * L + (k0 - 1)) * 3;
     }
 #pragma unroll 1
     for (int s = 0; s < 3; s++) {
-      if (nchk > LT_CHK_CAP - 128 || nev > LT_EV_CAP - 64) {
-        run_tasks(ws, nchk, nev, lane);  // scratch nearly full (rare): run what is queued
-        nchk = 0; nev = 0;
-      }
       const int slot9 = var * 3 + s;
-      const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
       double YP[4], SL[3];
       double x1 = 0.0, x2 = 0.0, y1 = 0.0, p1 = 0.0, p2 = 0.0, Sv = 0.0, Pzs = 0.0;
       int I = 1;
       bool ok = spl;
       if (spl) {
-        const double zeta = wsd[(size_t)(WS_ZETA0 + s) * N];
-        Pzs = wsd[(size_t)(WS_PZ0 + s) * N];
+        const double zeta = zt;
+        Pzs = pz;
         double X[4], Y[4];
 #pragma unroll
         for (int l = 0; l < 4; l++) {
           X[l] = level_at(lc[l], zeta, h, VT);
-          Y[l] = apply_interp(w, (double)b0[3 * l + ps], (double)b1[3 * l + ps],
-                              (double)b2[3 * l + ps], (double)b3[3 * l + ps]);
+          Y[l] = apply_interp(w, (double)raw[4 * l + 0], (double)raw[4 * l + 1],
+                              (double)raw[4 * l + 2], (double)raw[4 * l + 3]);
         }
+        if (s < 2) request(s + 1);
         const double DX1 = X[1] - X[0], DX2 = X[2] - X[1], DX3 = X[3] - X[2];
         ok = (DX1 > 0.0) && (DX2 > 0.0) && (DX3 > 0.0);
         if (!ok) degenerate |= (1u << slot9);
@@ -726,6 +776,7 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
         p2 = (I == 1) ? YP[1] : (I == 2) ? YP[2] : YP[3];
         Sv = (I == 1) ? SL[0] : (I == 2) ? SL[1] : SL[2];
       }
+      TICK(2);
       // SIGS (tension_module.f90:448-776), screened without divisions or loops.
       // Only the evaluation interval's tension is used by HVAL; the other two
       // matter only through SigErr, which only the convexity Newton iteration
@@ -747,14 +798,18 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
         const unsigned long long below = (1ull << lane) - 1ull;
         if (ca) {
           const int idx = nchk + __popcll(ma & below);
-          ws.chk[idx][0] = na; ws.chk[idx][1] = da;
-          ws.chk_owner[idx] = (unsigned short)(lane | (slot9 << 6));
+          if (idx < LT_CHK_CAP) {
+            ws.chk[idx][0] = na; ws.chk[idx][1] = da;
+            ws.chk_owner[idx] = (unsigned short)(lane | (slot9 << 6));
+          } else degenerate |= (1u << slot9);
         }
         nchk += __popcll(ma);
         if (cb) {
           const int idx = nchk + __popcll(mb & below);
-          ws.chk[idx][0] = nb; ws.chk[idx][1] = db;
-          ws.chk_owner[idx] = (unsigned short)(lane | (slot9 << 6));
+          if (idx < LT_CHK_CAP) {
+            ws.chk[idx][0] = nb; ws.chk[idx][1] = db;
+            ws.chk_owner[idx] = (unsigned short)(lane | (slot9 << 6));
+          } else degenerate |= (1u << slot9);
         }
         nchk += __popcll(mb);
         if (neede) {
@@ -764,31 +819,36 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
           ws.ev_owner[idx] = (unsigned short)(lane | (slot9 << 6));
         }
         nev += __popcll(me);
+#ifdef LT_RK_TIMING
+        if (lane == 0) { ws.tim[6] += __popcll(me); ws.tim[7] += __popcll(ma) + __popcll(mb); }
+#endif
       }
       // HVAL now when the evaluation interval's tension is already known
-      if (evdone) ws.res[slot9][lane] = hval_interval_s(Pzs, x1, x2, y1, p1, p2, Sv, sigI);
+      if (evdone) ws.res[s][lane] = hval_interval_s(Pzs, x1, x2, y1, p1, p2, Sv, sigI);
+      TICK(3);
     }
+    // ---------------- pass B: everything of this variable that iterates
+    run_tasks(ws, (nchk < LT_CHK_CAP) ? nchk : LT_CHK_CAP, nev, lane);
+    TICK(4);
+    // ---------------- pass C: time interpolation :1534-1598 / hydrodynamic_module.f90:2653-2670
+    if (act && !zero) {
+      const double Pv0 = ws.res[0][lane], Pv1 = ws.res[1][lane], Pv2 = ws.res[2][lane];
+      double e1 = Pv0, e2 = Pv1, e3 = Pv2;
+      if (P.p == 1) { e2 = Pv0; e3 = Pv1; }
+      const double val = polintd3(P.ex0, P.ex1, P.ex2, e1, e2, e3, ixv);
+      if (var == 0) Uad = val; else if (var == 1) Vad = val; else Wad = val;
+    }
+    TICK(5);
   }
-  // ---------------- pass B: everything that iterates, once per stage
-  run_tasks(ws, nchk, nev, lane);
-  // ---------------- pass C: time interpolation :1534-1598 / hydrodynamic_module.f90:2653-2670
   if (act && !zero) {
     const unsigned em = ws.errmask[lane];
     if (em) sigerr_count += __popc(em);
     if (spl && (degenerate | em)) slow = true;  // this particle-step is redone by k_rk_slow
-    const double ixv = (version == 1) ? P.ix0 : (version == 2) ? P.ix1 : P.ix2;
-#pragma unroll
-    for (int var = 0; var < 3; var++) {
-      const double Pv0 = ws.res[var * 3 + 0][lane], Pv1 = ws.res[var * 3 + 1][lane],
-                   Pv2 = ws.res[var * 3 + 2][lane];
-      double e1 = Pv0, e2 = (P.p == 1) ? Pv0 : Pv1, e3 = (P.p == 1) ? Pv1 : Pv2;
-      double val = polintd3(P.ex0, P.ex1, P.ex2, e1, e2, e3, ixv);
-      if (var == 0) Uad = val; else if (var == 1) Vad = val; else Wad = val;
-    }
   }
   // the next stage reuses the scratch: all lanes must have read their results
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
+  TICK(5);
 }
 
 // ------------------------------------------------------------ the step
@@ -918,11 +978,20 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_rk(const StepParams P) 
   int sigerr_count = 0;
   bool slow = false;
   WaveScratch& ws = wsc[threadIdx.x >> 6];
+#ifdef LT_RK_TIMING
+  if ((threadIdx.x & 63) < 8) ws.tim[threadIdx.x & 63] = 0;
+#endif
+  // the RK stages keep the elements of the start position (LTRANS.f90:990-1053)
+  int er = 1, eu = 1, ev_ = 1;
+  if (act) { er = P.P_r_element[n]; eu = P.P_u_element[n]; ev_ = P.P_v_element[n]; }
 #pragma unroll 1
   for (int st = 0; st < 4; st++) {
     const int version = (st == 0) ? 1 : (st == 3) ? 3 : 2;
     double Uad, Vad, Wad;
-    find_currents<SlabT, VT>(P, lev, ws, act, n, h, Xs, Ys, Zs, version, Uad, Vad, Wad, sigerr_count, slow);
+    // (h made opaque per stage: otherwise every h-dependent level coefficient is hoisted
+    // out of the stage loop and held in registers for the whole kernel)
+    asm volatile("" : "+v"(h));
+    find_currents<SlabT, VT>(P, lev, ws, act, n, er, eu, ev_, h, Xs, Ys, Zs, version, Uad, Vad, Wad, sigerr_count, slow);
     if (st == 0) { sumU = Uad; sumV = Vad; sumW = Wad; }
     else if (st == 3) { sumU = sumU + Uad; sumV = sumV + Vad; sumW = sumW + Wad; }
     else { sumU = sumU + 2.0 * Uad; sumV = sumV + 2.0 * Vad; sumW = sumW + 2.0 * Wad; }
@@ -959,6 +1028,9 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_rk(const StepParams P) 
       if (Zs < maxpartdepth) Zs = maxpartdepth + (double)0.000001f;
     }
   }
+#ifdef LT_RK_TIMING
+  if ((threadIdx.x & 63) < 8) atomicAdd(&g_tim[threadIdx.x & 63], ws.tim[threadIdx.x & 63]);
+#endif
   if (act) {
     double* wso = P.ws_d + n;
     wso[(size_t)WS_SUMU * N] = sumU;
