@@ -877,6 +877,32 @@ int lt_test_mt_stream(const int32_t* mt624, int32_t mti, uint64_t offset, int32_
   return LT_OK;
 }
 
+/* test aid (device): q_fast[i] = div_prep(a[i], prep_div(b[i])), q_ref[i] = a[i] / b[i]
+ * (host pointers), to check that the prepared-divisor division of lt_math.h is
+ * bit-identical to the compiler's division on the operand ranges it is used for. */
+__global__ void k_test_div(const double* a, const double* b, double* qf, double* qr, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const ltd::Divisor d = ltd::prep_div(b[i]);
+  qf[i] = ltd::div_prep(a[i], d);
+  qr[i] = a[i] / b[i];
+}
+int lt_test_div(const double* a, const double* b, double* q_fast, double* q_ref, int32_t n) {
+  if (!a || !b || !q_fast || !q_ref || n < 0) return LT_ERR_ARG;
+  double *da = nullptr, *db = nullptr, *df = nullptr, *dr = nullptr;
+  const size_t bytes = (size_t)n * 8;
+  if (hipMalloc(&da, bytes) != hipSuccess || hipMalloc(&db, bytes) != hipSuccess ||
+      hipMalloc(&df, bytes) != hipSuccess || hipMalloc(&dr, bytes) != hipSuccess) return LT_ERR_NOMEM;
+  (void)hipMemcpy(da, a, bytes, hipMemcpyHostToDevice);
+  (void)hipMemcpy(db, b, bytes, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(k_test_div, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, da, db, df, dr, (int)n);
+  const hipError_t rc = hipDeviceSynchronize();
+  (void)hipMemcpy(q_fast, df, bytes, hipMemcpyDeviceToHost);
+  (void)hipMemcpy(q_ref, dr, bytes, hipMemcpyDeviceToHost);
+  (void)hipFree(da); (void)hipFree(db); (void)hipFree(df); (void)hipFree(dr);
+  return rc == hipSuccess ? LT_OK : LT_ERR_DEVICE;
+}
+
 /* test aid (device): n tempered words of the engine's stream starting `offset` words
  * after the cursor, read back from the materialised ring. */
 int lt_test_mt_ring(lt_engine* e, uint64_t offset, int32_t n, uint32_t* out) {

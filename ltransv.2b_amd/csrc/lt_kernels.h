@@ -518,6 +518,21 @@ LT_DEV LevCoef level_coef(const double* tab, int k, double h, double hc, int Vtr
   }
   return r;
 }
+// the same with the per-particle divisor prepared once: dv = h (Vtransform 1) or hc + h (2)
+LT_DEV LevCoef level_coef_d(const double* tab, int k, double h, double hc, int Vtransform, const Divisor& dv) {
+  LevCoef r;
+  double A = tab[k - 1];
+  double B = tab[LT_LEV_STRIDE + k - 1];
+  if (Vtransform == 1) {
+    double S = A + (h - hc) * B;
+    r.a = S; r.b = 1.0 + div_prep(S, dv); r.c = 0.0;
+  } else if (Vtransform == 2) {
+    r.a = div_prep(A + h * B, dv); r.b = 0.0; r.c = 0.0;
+  } else {
+    r.a = A; r.b = 1.0 + tab[2 * LT_LEV_STRIDE + k - 1]; r.c = (h - hc) * B;
+  }
+  return r;
+}
 LT_DEV double level_at(const LevCoef& q, double zeta, double h, int Vtransform) {
   if (Vtransform == 1) return q.a + zeta * q.b;
   if (Vtransform == 2) return zeta + (zeta + h) * q.a;
@@ -618,7 +633,7 @@ LT_DEV void run_tasks(WaveScratch& ws, int nchk, int nev, int lane) {
 // (coalesced, L2-resident) where needed instead of living in registers.
 template <typename SlabT, int VT>
 LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& ws, bool act, int n,
-                          int er, int eu, int ev_, double h, double Xs, double Ys, double Zs, int version,
+                          int er, int eu, int ev_, double h, const Divisor& dv, double Xs, double Ys, double Zs, int version,
                           double& Uad, double& Vad, double& Wad, int& sigerr_count, bool& slow) {
   const double* rtab = lev;
   const double* wtab = lev + 3 * LT_LEV_STRIDE;
@@ -633,8 +648,8 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
   double wzb1 = 0.0;
   if (act) {
     const double zb = wsd[(size_t)WS_ZETA0 * N], zc = wsd[(size_t)WS_ZETA1 * N], zf = wsd[(size_t)WS_ZETA2 * N];
-    const LevCoef w1 = level_coef(wtab, 1, h, P.hc, VT);
-    const LevCoef r1 = level_coef(rtab, 1, h, P.hc, VT);
+    const LevCoef w1 = level_coef_d(wtab, 1, h, P.hc, VT, dv);
+    const LevCoef r1 = level_coef_d(rtab, 1, h, P.hc, VT, dv);
     wzb1 = level_at(w1, zb, h, VT);
     const double wzc1 = level_at(w1, zc, h, VT), wzf1 = level_at(w1, zf, h, VT);
     zero = (Zs < wzb1 + P.z0) || (Zs < wzc1 + P.z0) || (Zs < wzf1 + P.z0);
@@ -645,7 +660,7 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
       int lo = 3, hi = P.us - 1;
       while (lo < hi) {
         int mid = (lo + hi) >> 1;
-        LevCoef q = level_coef(rtab, mid, h, P.hc, VT);
+        LevCoef q = level_coef_d(rtab, mid, h, P.hc, VT, dv);
         bool below = (Zs < level_at(q, zb, h, VT)) || (Zs < level_at(q, zc, h, VT)) ||
                      (Zs < level_at(q, zf, h, VT));
         if (below) hi = mid; else lo = mid + 1;
@@ -654,7 +669,7 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
       lo = 3; hi = P.ws - 1;
       while (lo < hi) {
         int mid = (lo + hi) >> 1;
-        LevCoef q = level_coef(wtab, mid, h, P.hc, VT);
+        LevCoef q = level_coef_d(wtab, mid, h, P.hc, VT, dv);
         bool below = (Zs < level_at(q, zb, h, VT)) || (Zs < level_at(q, zc, h, VT)) ||
                      (Zs < level_at(q, zf, h, VT));
         if (below) hi = mid; else lo = mid + 1;
@@ -722,7 +737,7 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
     if (loglayer) {
       // log layer :1493-1522: level 1 of u,v; level 2 of w
       const int k = (var == 2) ? 2 : 1;
-      const LevCoef qt = level_coef((var == 2) ? wtab : rtab, k, h, P.hc, VT);
+      const LevCoef qt = level_coef_d((var == 2) ? wtab : rtab, k, h, P.hc, VT, dv);
 #pragma unroll
       for (int s = 0; s < 3; s++) {
         const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
@@ -736,7 +751,7 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
     LevCoef lc[4];
     if (spl) {
 #pragma unroll
-      for (int l = 0; l < 4; l++) lc[l] = level_coef(tab, k0 + l, h, P.hc, VT);
+      for (int l = 0; l < 4; l++) lc[l] = level_coef_d(tab, k0 + l, h, P.hc, VT, dv);
     }
 #pragma unroll 1
     for (int s = 0; s < 3; s++) {
@@ -760,13 +775,16 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
         ok = (DX1 > 0.0) && (DX2 > 0.0) && (DX3 > 0.0);
         if (!ok) degenerate |= (1u << slot9);
         // YPC1 (tension_module.f90:852-977) with the chord slopes kept for SIGS/HVAL
-        SL[0] = (Y[1] - Y[0]) / DX1;
-        SL[1] = (Y[2] - Y[1]) / DX2;
-        SL[2] = (Y[3] - Y[2]) / DX3;
-        YP[0] = ypc1_end(SL[0], SL[0] + DX1 * (SL[0] - SL[1]) / (DX1 + DX2));
-        YP[1] = ypc1_mid(DX1, DX2, SL[0], SL[1]);
-        YP[2] = ypc1_mid(DX2, DX3, SL[1], SL[2]);
-        YP[3] = ypc1_end(SL[2], SL[2] + DX3 * (SL[2] - SL[1]) / (DX2 + DX3));
+        // (seven quotients over five divisors: the reciprocals are prepared once)
+        const Divisor d1 = prep_div(DX1), d2 = prep_div(DX2), d3 = prep_div(DX3);
+        const Divisor d12 = prep_div(DX1 + DX2), d23 = prep_div(DX2 + DX3);
+        SL[0] = div_prep(Y[1] - Y[0], d1);
+        SL[1] = div_prep(Y[2] - Y[1], d2);
+        SL[2] = div_prep(Y[3] - Y[2], d3);
+        YP[0] = ypc1_end(SL[0], SL[0] + div_prep(DX1 * (SL[0] - SL[1]), d12));
+        YP[1] = ypc1_mid_d(DX1, DX2, d12, SL[0], SL[1]);
+        YP[2] = ypc1_mid_d(DX2, DX3, d23, SL[1], SL[2]);
+        YP[3] = ypc1_end(SL[2], SL[2] + div_prep(DX3 * (SL[2] - SL[1]), d23));
         I = (Pzs < X[1]) ? 1 : (Pzs < X[2]) ? 2 : 3;
         if (Pzs > X[3]) I = 3;
         x1 = (I == 1) ? X[0] : (I == 2) ? X[1] : X[2];
@@ -981,6 +999,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_rk(const StepParams P) 
 #ifdef LT_RK_TIMING
   if ((threadIdx.x & 63) < 8) ws.tim[threadIdx.x & 63] = 0;
 #endif
+  const Divisor dv = prep_div((VT == 2) ? P.hc + h : h);  // every level depth divides by it
   // the RK stages keep the elements of the start position (LTRANS.f90:990-1053)
   int er = 1, eu = 1, ev_ = 1;
   if (act) { er = P.P_r_element[n]; eu = P.P_u_element[n]; ev_ = P.P_v_element[n]; }
@@ -991,7 +1010,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_rk(const StepParams P) 
     // (h made opaque per stage: otherwise every h-dependent level coefficient is hoisted
     // out of the stage loop and held in registers for the whole kernel)
     asm volatile("" : "+v"(h));
-    find_currents<SlabT, VT>(P, lev, ws, act, n, er, eu, ev_, h, Xs, Ys, Zs, version, Uad, Vad, Wad, sigerr_count, slow);
+    find_currents<SlabT, VT>(P, lev, ws, act, n, er, eu, ev_, h, dv, Xs, Ys, Zs, version, Uad, Vad, Wad, sigerr_count, slow);
     if (st == 0) { sumU = Uad; sumV = Vad; sumW = Wad; }
     else if (st == 3) { sumU = sumU + Uad; sumV = sumV + Vad; sumW = sumW + Wad; }
     else { sumU = sumU + 2.0 * Uad; sumV = sumV + 2.0 * Vad; sumW = sumW + 2.0 * Wad; }
@@ -1013,8 +1032,8 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_rk(const StepParams P) 
       }
       // maxpartdepth / minpartdepth :981-987
       const double* wtab = lev + 3 * LT_LEV_STRIDE;
-      const LevCoef w1 = level_coef(wtab, 1, h, P.hc, VT);
-      const LevCoef wN = level_coef(wtab, P.ws, h, P.hc, VT);
+      const LevCoef w1 = level_coef_d(wtab, 1, h, P.hc, VT, dv);
+      const LevCoef wN = level_coef_d(wtab, P.ws, h, P.hc, VT, dv);
       const double zb = wsd[(size_t)WS_ZETA0 * N], zc = wsd[(size_t)WS_ZETA1 * N], zf = wsd[(size_t)WS_ZETA2 * N];
       double maxpartdepth = level_at(w1, zb, h, VT);
       double t1 = level_at(w1, zc, h, VT), t2 = level_at(w1, zf, h, VT);

@@ -45,6 +45,35 @@ LT_DEV double div_by(double a, double b, double y, bool ok) {
   return __builtin_fma(r, y, q);
 }
 
+// Division by a divisor that is used several times.  The compiler expands a / b into
+//   s,t = div_scale(b), div_scale(a); y = rcp(s); two Newton steps on y (4 fma);
+//   q = t*y; r = fma(-s,q,t); div_fmas(r,y,q); div_fixup
+// where the scale / fixup steps only act when an exponent is near the ends of the range
+// (|b| outside ~[2^-1021, 2^1021], |a| < 2^-969 and nonzero, quotient near overflow /
+// underflow) or an operand is 0 / inf / NaN.  For operands of ordinary magnitude the
+// quotient is therefore exactly  fma(fma(-b, a*y, a), y, a*y)  with the refined
+// reciprocal y, which depends on b alone: prep_div() does the reciprocal part once and
+// div_prep() is the three remaining operations.  Used only where the operands are depths,
+// level spacings (metres, > 0) and differences of fp32 field values (or exactly 0):
+// bit-identical to `a / b` there (checked on the device by tests/test_gpu_div.py).
+struct Divisor { double b, y; };
+LT_DEV Divisor prep_div(double b) {
+  Divisor d;
+  d.b = b;
+  double y = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-b, y, 1.0);
+  d.y = __builtin_fma(y, e, y);
+  return d;
+}
+LT_DEV double div_prep(double a, const Divisor& d) {
+  const double q = a * d.y;
+  const double r = __builtin_fma(-d.b, q, a);
+  // a zero numerator: q already is the zero of the right sign, the correction would lose it
+  return (a == 0.0) ? q : __builtin_fma(r, d.y, q);
+}
+
 // SIGS' convexity Newton iteration (tension_module.f90:531-580) gives up after
 // 10000 evaluations (SigErr).  Each iterate is a function of the previous one
 // only, so once an iterate REPEATS the sequence is periodic, none of the states
@@ -294,6 +323,15 @@ LT_DEV double ypc1_end(double SI, double T) {
 }
 LT_DEV double ypc1_mid(double DXIM1, double DXI, double SIM1, double SI) {
   double T = (DXIM1 * SI + DXI * SIM1) / (DXIM1 + DXI);
+  double ASIM1 = fabs(SIM1), ASI = fabs(SI);
+  double SGN = fsign1(SI);
+  if (ASIM1 > ASI) SGN = fsign1(SIM1);
+  return (SGN > 0.0) ? dmin(dmax(0.0, T), 3.0 * dmin(ASIM1, ASI))
+                     : dmax(dmin(0.0, T), -3.0 * dmin(ASIM1, ASI));
+}
+
+LT_DEV double ypc1_mid_d(double DXIM1, double DXI, const Divisor& dsum, double SIM1, double SI) {
+  double T = div_prep(DXIM1 * SI + DXI * SIM1, dsum);
   double ASIM1 = fabs(SIM1), ASI = fabs(SI);
   double SGN = fsign1(SI);
   if (ASIM1 > ASI) SGN = fsign1(SIM1);
