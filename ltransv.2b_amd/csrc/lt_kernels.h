@@ -591,35 +591,35 @@ struct WaveScratch {
 #endif
 };
 
-// pass B: the queued iterations, 64 at a time, all lanes of the wave
+// pass B: the queued iterations, 64 at a time, all lanes of the wave.  Evaluation
+// intervals and check intervals share the batches, so the wave runs ONE Newton loop per
+// batch whatever the mix (a separate loop for the few check intervals cost as much as the
+// one for the evaluation intervals).
 LT_DEV void run_tasks(WaveScratch& ws, int nchk, int nev, int lane) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int total = nev + nchk;
 #pragma unroll 1
-  for (int t = lane; t < nchk; t += 64) {
-    // a non-evaluation interval: only the convergence of its Newton iteration matters
-    const double T = ws.chk[t][0] / ws.chk[t][1];
-    if (T > 2.0) {
-      bool failed;
-      (void)sigs_newton(T, failed);
-      if (failed) {
-        unsigned short o = ws.chk_owner[t];
-        atomicOr(&ws.errmask[o & 63], 1u << (o >> 6));
-      }
+  for (int t = lane; t < total; t += 64) {
+    const bool is_ev = t < nev;
+    const double* e = ws.ev[is_ev ? t : 0];
+    const int tc = is_ev ? 0 : (t - nev);
+    const unsigned short o = is_ev ? ws.ev_owner[t] : ws.chk_owner[tc];
+    double sg = 0.0, T = 0.0;
+    int kind;
+    if (is_ev) {
+      // the evaluation interval: full SIGS decision
+      kind = sigs_classify(e[5], e[3], e[4], sg, T);
+    } else {
+      // a non-evaluation interval: only the convergence of its Newton iteration matters
+      T = ws.chk[tc][0] / ws.chk[tc][1];
+      kind = (T > 2.0) ? SIGK_NEWTON : SIGK_DONE;
     }
-  }
-#pragma unroll 1
-  for (int t = lane; t < nev; t += 64) {
-    // the evaluation interval: full SIGS decision, then HVAL
     bool failed = false;
-    const double* e = ws.ev[t];
-    const unsigned short o = ws.ev_owner[t];
-    double sg, T;
-    const int kind = sigs_classify(e[5], e[3], e[4], sg, T);
     if (kind == SIGK_NEWTON) sg = sigs_newton(T, failed);
     else if (kind == SIGK_SECANT) sg = sigs_secant(e[5], e[3], e[4]);  // rare
-    ws.res[(o >> 6) % 3][o & 63] = hval_interval_s(e[6], e[0], e[1], e[2], e[3], e[4], e[5], sg);
+    if (is_ev) ws.res[(o >> 6) % 3][o & 63] = hval_interval_s(e[6], e[0], e[1], e[2], e[3], e[4], e[5], sg);
     if (failed) atomicOr(&ws.errmask[o & 63], 1u << (o >> 6));
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
