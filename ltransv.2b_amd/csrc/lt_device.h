@@ -117,6 +117,7 @@ struct StepParams {
   int* ws_i;      // [numpar] flags | err << 8
   // ---- counters
   unsigned long long* counters;
+  unsigned int* block_active;  // [blocks] tracked particles per k_pre block
 };
 
 }  // namespace ltd

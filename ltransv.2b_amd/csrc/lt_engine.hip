@@ -61,7 +61,7 @@ struct lt_engine {
   lt_habitat hab{};
   int npoly = 0, nhole = 0;
   // particles
-  DevBuf ws_d, ws_i, orig, ele_ok;
+  DevBuf ws_d, ws_i, orig, ele_ok, block_active, count_slots;
   // internal particle order: slot i of every device array holds the reference's
   // particle perm[i] (0-based); sorted by rho element for memory locality
   std::vector<int> perm;
@@ -228,6 +228,7 @@ void fill_params(lt_engine* e, StepParams& P) {
   P.rank = (const int*)e->rank.p; P.orig = (const int*)e->orig.p;
   P.vt_x = (double*)e->vt_x.p; P.vt_y = (double*)e->vt_y.p; P.vt_yp = (double*)e->vt_yp.p; P.vt_sig = (double*)e->vt_sig.p;
   P.ele_ok = (unsigned char*)e->ele_ok.p;
+  P.block_active = (unsigned int*)e->block_active.p;
   P.ws_d = (double*)e->ws_d.p;
   P.ws_i = (int*)e->ws_i.p;
   P.counters = (unsigned long long*)e->counters.p;
@@ -571,7 +572,7 @@ int lt_destroy(lt_engine* e) {
                     &e->ep_ptr, &e->ep_ids, &e->ph_ptr, &e->ph_ids, &e->par, &e->pr, &e->pu,
                     &e->pv, &e->P_behave, &e->dead, &e->oob, &e->settle, &e->endpoly,
                     &e->hitBottom, &e->hitLand, &e->err_code, &e->P_swim, &e->P_pediage,
-                    &e->P_deadage, &e->settletime, &e->counters, &e->ws_d, &e->ws_i, &e->orig, &e->ele_ok, &e->rng_states, &e->rng_ring, &e->rng_gJ, &e->flag, &e->rank, &e->scan_tmp,
+                    &e->P_deadage, &e->settletime, &e->counters, &e->ws_d, &e->ws_i, &e->orig, &e->ele_ok, &e->block_active, &e->count_slots, &e->rng_states, &e->rng_ring, &e->rng_gJ, &e->flag, &e->rank, &e->scan_tmp,
                     &e->vt_x, &e->vt_y, &e->vt_yp, &e->vt_sig};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
@@ -757,6 +758,7 @@ int lt_set_particles(lt_engine* e, const lt_particles* p) {
   }
   // positions / elements may change: nothing is known to be verified any more
   TRY(dev_alloc(e, e->ele_ok, n));
+  TRY(dev_alloc(e, e->block_active, ((size_t)n + 255) / 256 * 4 + 4));
   HIPCHK(e, hipMemsetAsync(e->ele_ok.p, 0, e->ele_ok.bytes, e->stream));
   TRY(put_field<double>(e, e->par, p->par, 13));
   TRY(put_field<int32_t>(e, e->pr, p->P_r_element, 1));
@@ -939,14 +941,18 @@ int lt_count_active(lt_engine* e, const double* ix3, int64_t* n_active) {
   StepParams P;
   fill_params(e, P);
   P.ix0 = ix3[0]; P.ix1 = ix3[1]; P.ix2 = ix3[2];
-  unsigned long long* slot = (unsigned long long*)e->counters.p + (CNT_COUNT - 1);
-  HIPCHK(e, hipMemsetAsync(slot, 0, 8, e->stream));
+  // 64 partial counters, one 64-byte line each
+  if (e->count_slots.bytes < 64 * 64) TRY(dev_alloc(e, e->count_slots, 64 * 64));
+  unsigned long long* slot = (unsigned long long*)e->count_slots.p;
+  HIPCHK(e, hipMemsetAsync(slot, 0, 64 * 64, e->stream));
   unsigned blocks = (unsigned)((e->cfg.numpar + 255) / 256);
   if (blocks) hipLaunchKernelGGL(k_count_active, dim3(blocks), dim3(256), 0, e->stream, P, slot);
   HIPCHK(e, hipGetLastError());
-  unsigned long long v = 0;
-  HIPCHK(e, hipMemcpyAsync(&v, slot, 8, hipMemcpyDeviceToHost, e->stream));
+  unsigned long long part[64 * 8];
+  HIPCHK(e, hipMemcpyAsync(part, slot, 64 * 64, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
+  unsigned long long v = 0;
+  for (int i = 0; i < 64; i++) v += part[i * 8];
   *n_active = (int64_t)v;
   return LT_OK;
 }

@@ -880,9 +880,6 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
 
 template <typename SlabT>
 __global__ __launch_bounds__(256) void k_pre(const StepParams P) {
-  __shared__ double lev[6 * LT_LEV_STRIDE];
-  for (int i = threadIdx.x; i < 6 * LT_LEV_STRIDE; i += blockDim.x) lev[i] = P.lev[i];
-  __syncthreads();
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned c_active = 0;
   if (n < P.numpar) {
@@ -890,36 +887,43 @@ __global__ __launch_bounds__(256) void k_pre(const StepParams P) {
     double* par = P.par + n;
     double* wsd = P.ws_d + n;
 #define PARV(k) par[(size_t)(k) * N]
+    // Everything the gates may look at is requested at once (the kernel is a chain of
+    // dependent loads, not arithmetic): state, status flags, the stored elements and,
+    // through them, the nodes of the rho element.
     const double X = PARV(pX), Y = PARV(pY);
     double Z = PARV(pZ);
+    const double dob = PARV(pDOB), age0 = PARV(pAge);
+    const int settle_n = P.settlementon ? P.settle[n] : 0;
+    const double deadage_n = P.mortality ? P.P_deadage[n] : 0.0;
+    int dead_n = P.mortality ? P.dead[n] : 0;
+    const int oob_n = P.OpenOceanBoundary ? P.oob[n] : 0;
+    const int ele_ok = P.ele_ok[n];
+    int er = P.P_r_element[n], eu = P.P_u_element[n], ev = P.P_v_element[n];
+    int4 rn = P.RE[er - 1], un, vn;  // stored element ids are always valid ids
     int flags = 0, err = 0;
     // the gates of LTRANS.f90:790-816
-    const bool released = !(P.ix2 <= PARV(pDOB));
+    const bool released = !(P.ix2 <= dob);
     bool track = released;
     if (released) {
-      double age = PARV(pAge) + (double)(float)P.idt;
+      double age = age0 + (double)(float)P.idt;
       PARV(pAge) = age;
       // updateStatus, behavior_module.f90:162-179
-      bool settled = P.settlementon ? (P.settle[n] != 0) : false;
-      if (P.mortality && age >= P.P_deadage[n]) {
-        if (!(P.settlementon && settled)) P.dead[n] = 1;
+      bool settled = P.settlementon ? (settle_n != 0) : false;
+      if (P.mortality && age >= deadage_n) {
+        if (!(P.settlementon && settled)) { P.dead[n] = 1; dead_n = 1; }
       }
       if (P.settlementon && settled) track = false;
-      if (track && P.mortality && P.dead[n] != 0) track = false;
-      if (track && P.OpenOceanBoundary && P.oob[n] != 0) track = false;
+      if (track && P.mortality && dead_n != 0) track = false;
+      if (track && P.OpenOceanBoundary && oob_n != 0) track = false;
       if (!track) flags |= FL_KEEP_PN;
     }
     if (track) {
-      int er = P.P_r_element[n], eu = P.P_u_element[n], ev = P.P_v_element[n];
-      int4 rn, un, vn;
       // setEle :830 (all three grids are searched even after a miss).  When the
       // previous step's closing setEle (:1317) found these very elements for this
       // very position, the first probe of each grid is that element and succeeds
-      // again: the search is skipped and only the rho nodes are fetched.
+      // again: the search is skipped and only the rho nodes are used.
       bool okr = true, oku = true, okv = true;
-      if (P.ele_ok[n]) {
-        rn = P.RE[er - 1];
-      } else {
+      if (!ele_ok) {
         find_elements3(P, X, Y, er, eu, ev, rn, un, vn, okr, oku, okv);
         P.P_r_element[n] = er; P.P_u_element[n] = eu; P.P_v_element[n] = ev;
       }
@@ -969,9 +973,14 @@ __global__ __launch_bounds__(256) void k_pre(const StepParams P) {
     P.ws_i[n] = flags | (err << FL_ERR_SHIFT);
 #undef PARV
   }
+  // tracked particles of this block -> block_active[block]; k_post's block 0 adds them up
+  // (one atomic per wave on a single counter serialised at the L2: 160 us per step)
+  __shared__ unsigned wsum[4];
   unsigned v = c_active;
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  if ((threadIdx.x & 63) == 0 && v) atomicAdd(&P.counters[CNT_ACTIVE], (unsigned long long)v);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) P.block_active[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 template <typename SlabT, int VT, int WAVES_PER_SIMD>
@@ -1827,6 +1836,17 @@ __global__ __launch_bounds__(256) void k_post(const StepParams P) {
   }
   __shared__ unsigned red[3];
   if (threadIdx.x < 3) red[threadIdx.x] = 0;
+  if (blockIdx.x == 0) {  // total of k_pre's per-block counts of tracked particles
+    __shared__ unsigned long long tot;
+    if (threadIdx.x == 0) tot = 0;
+    __syncthreads();
+    unsigned long long s = 0;
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += blockDim.x) s += P.block_active[b];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&tot, s);
+    __syncthreads();
+    if (threadIdx.x == 0) P.counters[CNT_ACTIVE] = tot;
+  }
   __syncthreads();
   unsigned vals[3] = {c_err, c_brute, c_pipslow};
 #pragma unroll
@@ -1917,8 +1937,16 @@ __global__ void k_count_active(const StepParams P, unsigned long long* out) {
       c = ok ? 1u : 0u;
     }
   }
+  // per block partial sums, then few atomics spread over 64 slots (one counter hit by
+  // every wave serialises at the L2); the host adds the slots
+  __shared__ unsigned wsum[4];
   for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned s = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (s) atomicAdd(out + (blockIdx.x & 63) * 8, (unsigned long long)s);
+  }
 }
 
 }  // namespace ltd
