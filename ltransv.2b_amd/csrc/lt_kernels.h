@@ -838,7 +838,8 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
         }
         nev += __popcll(me);
 #ifdef LT_RK_TIMING
-        if (lane == 0) { ws.tim[6] += __popcll(me); ws.tim[7] += __popcll(ma) + __popcll(mb); }
+        { const unsigned long long mk = __ballot(evdone && sigI != 0.0);
+          if (lane == 0) { ws.tim[6] += __popcll(me); ws.tim[7] += __popcll(mk); } }
 #endif
       }
       // HVAL now when the evaluation interval's tension is already known

@@ -571,13 +571,15 @@ LT_DEV double sigs_newton(double T, bool& failed) {
     if (SIG <= .5) {
       double SINHM, COSHM, COSHMM;
       snhcsh(SIG, SINHM, COSHM, COSHMM);
-      T1 = COSHM / SINHM;
-      FP = T1 + SIG * (SIG / SINHM - T1 * T1 + 1.0);
+      const Divisor ds = prep_div(SINHM);  // two quotients over SINHM
+      T1 = div_prep(COSHM, ds);
+      FP = T1 + SIG * (div_prep(SIG, ds) - T1 * T1 + 1.0);
     } else {
       double EMS = exp(-SIG);
       double SSM = 1.0 - EMS * (EMS + SIG + SIG);
-      T1 = (1.0 - EMS) * (1.0 - EMS) / SSM;
-      FP = T1 + SIG * (2.0 * SIG * EMS / SSM - T1 * T1 + 1.0);
+      const Divisor ds = prep_div(SSM);  // two quotients over SSM
+      T1 = div_prep((1.0 - EMS) * (1.0 - EMS), ds);
+      FP = T1 + SIG * (div_prep(2.0 * SIG * EMS, ds) - T1 * T1 + 1.0);
     }
     double F = SIG * T1 - TP1;
     NIT = NIT + 1;
