@@ -50,6 +50,28 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(tag, kernels, n, args):
+    """HBM-side bytes per launch of the timed kernel(s) from the committed rocprofv3 PMC
+    summary of THIS command (profiles/<tag>/pmc.json: FETCH_SIZE x 2 on gfx950 +
+    WRITE_SIZE, separate passes, see profiles/tools/).  Counters cannot be collected
+    inside an ordinary run, so the number is the one measured for the default workload;
+    any other workload reports null."""
+    if n != 1_000_000 or args.grid != "512x256x30" or args.slab != "f32":
+        return None, None
+    p = os.path.join(ROOT, "profiles", tag, "pmc.json")
+    try:
+        d = json.load(open(p))
+    except (OSError, ValueError):
+        return None, None
+    tot = 0.0
+    for kern in kernels:
+        hit = [v for k, v in d.items() if ("::" + kern + "(" in k or "::" + kern + "<" in k)]
+        if not hit or "fetch_bytes_per_launch" not in hit[0] or "write_bytes_per_launch" not in hit[0]:
+            return None, None
+        tot += hit[0]["fetch_bytes_per_launch"] + hit[0]["write_bytes_per_launch"]
+    return tot, "profiles/%s/pmc.json" % tag
+
+
 def build_inputs(vi, uj, us, numpar, seed):
     from ltrans_amd import roms_synth as rs
     g = rs.make_grid(vi, uj, us)
@@ -215,6 +237,8 @@ def main():
         A += (48 if args.slab == "f32" else 96) * ws_ + 124 * 4 * 2
     k_avg_s = (k_ms / max(k_n, 1)) * 1e-3
     achieved = (A * n / k_avg_s) / 1e9 if k_avg_s > 0 else 0.0
+    kernels = ["k_vt_table", "k_vt_sigs", "k_vt_walk"] if args.turb else ["k_rk"]
+    traffic, traffic_src = pmc_traffic("r01_turb" if args.turb else "r01_adv", kernels, n, args)
 
     out = {
         "metric": "particle-steps/s", "value": value, "unit": "particle-steps/s",
@@ -230,8 +254,10 @@ def main():
                    "sigerr_last_step": stats["sigerr"],
                    "slab_rotation_s_excluded": upload_s},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "k_vturb" if args.turb else "k_rk", "kernel_ms_avg": k_avg_s * 1e3,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": traffic_src,
+                     "kernel": "+".join(kernels), "kernel_ms_avg": k_avg_s * 1e3,
+                     "algorithmic_bytes_per_launch": A * n,
                      "algorithmic_bytes_per_particle_step": A},
     }
     if rank == 0 and not args.no_cpu_baseline:
