@@ -154,15 +154,20 @@ def main():
                                             else ltrans_amd.abi.LT_SLAB_F64))
     e, run = make_engine(ltrans_amd, cfg, g, geo, bounds, parts, records)
 
-    send = recv = None
+    # N > 1: the end-of-step all-gather of (x,y,z) runs on its own stream and overlaps the
+    # next step's kernels; the packed positions are double-buffered so a step never
+    # overwrites a buffer RCCL may still be reading.
+    send = recv = gather_stream = None
+    send_done = [None, None]
     if world > 1:
-        send = torch.empty(3 * n, dtype=torch.float64, device=dev)
+        send = [torch.empty(3 * n, dtype=torch.float64, device=dev) for _ in range(2)]
         recv = torch.empty(3 * n * world, dtype=torch.float64, device=dev)
+        gather_stream = torch.cuda.Stream(device=dev)
 
     p = 2                      # second external step: plain (b,c,f) time interpolation
     ex = run.external_times(p)
     stepIT = cfg.dt // cfg.idt
-    state = {"it": 0, "p": p, "ex": ex}
+    state = {"it": 0, "p": p, "ex": ex, "nstep": 0}
 
     def needs_rotation():
         return state["it"] + 1 > stepIT
@@ -186,9 +191,16 @@ def main():
             e.set_rng_window(before, total)
         e.update_particles(state["ex"], ix, state["p"], state["it"])
         if world > 1:
-            e.pack_positions(send.data_ptr())
-            e.sync()
-            dist.all_gather_into_tensor(recv, send)
+            b = state["nstep"] & 1
+            state["nstep"] += 1
+            if send_done[b] is not None:
+                send_done[b].synchronize()      # the all-gather that last read this buffer
+            e.pack_positions(send[b].data_ptr())
+            e.sync()                            # engine stream: step + pack complete
+            with torch.cuda.stream(gather_stream):
+                dist.all_gather_into_tensor(recv, send[b])
+                send_done[b] = torch.cuda.Event()
+                send_done[b].record(gather_stream)
 
     def fence():
         e.sync()
