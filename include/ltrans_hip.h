@@ -198,6 +198,35 @@ typedef struct lt_slab {
   const double *Kh;              /* (rho_nodes,ws)  NULL allowed when VTurbOn = 0   */
 } lt_slab;
 
+/* One ROMS history record as updateHydro holds it right after NF90_GET_VAR
+ * (hydrodynamic_module.f90:1065-1368), BEFORE the mask multiply and the copy into
+ * t_*(t_f,node,level) of :1371-1403, which the engine does on the device:
+ * romZf(vi,uj), romUf(ui,uj,us), romVf(vi,vj,us), romWf(vi,uj,ws), romKHf(vi,uj,ws),
+ * Fortran order.  (i,j) -> node is count = (j-1)*vi + i (rho, v) and (j-1)*ui + i (u),
+ * so the arrays are node-numbered already.  dtype selects how the host read them:
+ * LTRANS allocates DOUBLE PRECISION arrays; a host that lets NetCDF deliver REAL
+ * arrays (the file's own type) halves the PCIe bytes.  window = t_ijruv(12)
+ * (hydrodynamic_module.f90:42, setijruv :2851-2922): only
+ *   rho / w / Kh / zeta  i = w[0]..w[1], j = w[2]..w[3]
+ *   u                    i = w[4]..w[5], j = w[6]..w[7]
+ *   v                    i = w[8]..w[9], j = w[10]..w[11]      (1-based, inclusive)
+ * are valid in the host arrays and are refreshed on the device; the other nodes of
+ * the slot keep what they held, as the reference's t_* arrays do. */
+#define LT_ROM_F64 0
+#define LT_ROM_F32 1
+typedef struct lt_rom_record {
+  int32_t struct_size;           /* = sizeof(lt_rom_record)                          */
+  int32_t dtype;                 /* LT_ROM_F64 | LT_ROM_F32 : type of the five arrays */
+  int32_t vi, uj, ui, vj;        /* grid dimensions (PARAM_MOD)                      */
+  int32_t masked;                /* 0: raw ROMS values, the engine multiplies by the
+                                  *    node masks of lt_grid (m_r, m_u, m_v);
+                                  * 1: already multiplied                            */
+  int32_t has_window;            /* 0: whole grid; 1: window[] applies               */
+  int32_t window[12];            /* t_ijruv                                          */
+  const void *romZ, *romU, *romV, *romW;
+  const void *romKH;             /* NULL allowed when VTurbOn = 0                    */
+} lt_rom_record;
+
 /* Per-step counters (sums over the shard). */
 typedef struct lt_step_stats {
   int64_t active;                /* particles that were tracked this step           */
@@ -223,6 +252,22 @@ int lt_set_particles(lt_engine *e, const lt_particles *p);  /* after setEle_all 
 int lt_set_slab(lt_engine *e, int32_t slot, const lt_slab *s);
 /* rotating indices t_b,t_c,t_f (hydrodynamic_module.f90:42,741-743,1080-1082) */
 int lt_set_time_slots(lt_engine *e, int32_t t_b, int32_t t_c, int32_t t_f);
+
+/* The slab pipeline (the rotation + upload of updateHydro, hydrodynamic_module.f90:
+ * 1052-1410, as an asynchronous double buffer).  The device keeps FOUR physical time
+ * slots per field: the three in use and a spare one.
+ *   lt_slab_prefetch  copies the record into pinned staging (the only part the caller
+ *                     waits for: its arrays may be reused on return), then H2D copy,
+ *                     mask multiply, type conversion and scatter into the SPARE slot run
+ *                     on a copy stream beside the steps of the current external step.
+ *   lt_slab_commit    = the rotation: the prefetched record becomes slot t_f, the slot
+ *                     that held the old back record becomes the spare, the time roles
+ *                     are (t_b, t_c, t_f) as after hydrodynamic_module.f90:1080-1082.
+ *                     Later steps are ordered after the prefetch on the device; the call
+ *                     itself waits for the prefetch only to report LT_ERR_SLAB_NOT_F32.
+ * lt_set_slab + lt_set_time_slots remain the synchronous equivalent. */
+int lt_slab_prefetch(lt_engine *e, const lt_rom_record *r);
+int lt_slab_commit(lt_engine *e, int32_t t_b, int32_t t_c, int32_t t_f);
 
 /* Mersenne Twister state (random_module.f90:98-99): mt(0:623), mti. */
 int lt_set_rng(lt_engine *e, const int32_t *mt624, int32_t mti);

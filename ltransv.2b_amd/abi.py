@@ -13,6 +13,7 @@ LT_ERR = {
     -5: "LT_ERR_DEVICE", -6: "LT_ERR_SLAB_NOT_F32", -7: "LT_ERR_NOMEM",
 }
 LT_SLAB_F32, LT_SLAB_F64 = 0, 1
+LT_ERR_SLAB_NOT_F32 = -6
 
 PERR_NAMES = {0: "none", 4: "not in rho element", 5: "not in u element", 6: "not in v element",
               24: "out after 3rd reflection", 25: "outside main bounds", 26: "inside island",
@@ -135,6 +136,20 @@ class LtSlab(C.Structure):
     _fields_ = [("zeta", c_dp), ("Uvel", c_dp), ("Vvel", c_dp), ("Wvel", c_dp), ("Kh", c_dp)]
 
 
+LT_ROM_F64, LT_ROM_F32 = 0, 1
+
+
+class LtRomRecord(C.Structure):
+    """lt_rom_record: a ROMS record as read from the history file (include/ltrans_hip.h)."""
+    _fields_ = [
+        ("struct_size", C.c_int32), ("dtype", C.c_int32),
+        ("vi", C.c_int32), ("uj", C.c_int32), ("ui", C.c_int32), ("vj", C.c_int32),
+        ("masked", C.c_int32), ("has_window", C.c_int32), ("window", C.c_int32 * 12),
+        ("romZ", C.c_void_p), ("romU", C.c_void_p), ("romV", C.c_void_p), ("romW", C.c_void_p),
+        ("romKH", C.c_void_p),
+    ]
+
+
 class LtStepStats(C.Structure):
     _fields_ = [("active", C.c_int64), ("errors", C.c_int64), ("rng_draws", C.c_int64)]
 
@@ -143,7 +158,7 @@ class LtStepStats(C.Structure):
 # library; the test-side CPU oracle exports the same set as "lto_")
 ENTRY_POINTS = [
     "create", "destroy", "set_grid", "set_bounds", "set_habitat", "set_particles",
-    "set_slab", "set_time_slots", "set_rng", "get_rng", "count_active", "set_rng_window",
+    "set_slab", "set_time_slots", "slab_prefetch", "slab_commit", "set_rng", "get_rng", "count_active", "set_rng_window",
     "step", "sync", "get_stats", "get_particles",
 ]
 HIP_ONLY_ENTRY_POINTS = ["last_error", "abi_version", "pack_positions", "stream",

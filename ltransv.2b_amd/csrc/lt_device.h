@@ -49,6 +49,10 @@ struct PipIndex {
   int nbins;
 };
 
+// Physical time slots of a slab: the three records in use (back / centre / forward) and a
+// spare one that the next record is prefetched into while steps run (lt_slab_prefetch).
+#define LT_SLOTS 4
+
 struct StepParams {
   // ---- particle state (device copies of the reference's arrays)
   double* par;
@@ -72,7 +76,7 @@ struct StepParams {
   double hc, z0;
   // ---- hydrodynamic slabs
   const void *U, *V, *W, *Kh, *zeta;
-  int tb, tc, tf;  // 0-based physical slot of the back / centre / forward record
+  int tb, tc, tf;  // 0-based PHYSICAL slot (0..LT_SLOTS-1) of the back / centre / forward record
   // ---- time
   double ex0, ex1, ex2, ix0, ix1, ix2;
   int p, it, idt;

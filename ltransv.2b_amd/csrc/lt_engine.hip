@@ -13,6 +13,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "../../include/ltrans_hip.h"
@@ -90,6 +92,18 @@ struct lt_engine {
   // optional HIP-event timing of the step kernel (lt_profile_*)
   bool prof_on = false;
   std::vector<hipEvent_t> prof_ev;  // pairs (start, stop)
+  // slab pipeline (lt_slab_prefetch / lt_slab_commit): logical slot 1..3 -> physical slot,
+  // the spare physical slot, a copy stream, pinned staging (double buffer)
+  int phys[4] = {0, 0, 1, 2};
+  int spare = 3;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t prefetch_done = nullptr, compute_mark = nullptr, pin_free[2] = {nullptr, nullptr};
+  bool prefetch_pending = false, mark_valid = false, pin_busy[2] = {false, false};
+  void* pin[2] = {nullptr, nullptr};
+  size_t pin_bytes = 0;
+  int pin_next = 0;
+  DevBuf stage_rom, rmask, umask, vmask;
+  bool have_masks = false;
   hipStream_t rng_stream = nullptr;  // the MT19937 blocks of a step are generated beside k_rk
   hipEvent_t rng_done = nullptr;
   bool rng_pending = false;
@@ -201,7 +215,7 @@ void fill_params(lt_engine* e, StepParams& P) {
   P.hc = (double)c.hc;  // REAL promoted (LTRANS.h:66)
   P.z0 = c.z0;
   P.U = e->U.p; P.V = e->V.p; P.W = e->W.p; P.Kh = e->Kh.p; P.zeta = e->zeta.p;
-  P.tb = e->t_b - 1; P.tc = e->t_c - 1; P.tf = e->t_f - 1;
+  P.tb = e->phys[e->t_b]; P.tc = e->phys[e->t_c]; P.tf = e->phys[e->t_f];
   P.idt = c.idt;
   P.Behavior = c.Behavior; P.OpenOceanBoundary = c.OpenOceanBoundary; P.mortality = c.mortality;
   P.settlementon = c.settlementon; P.holesExist = c.holesExist; P.ErrorFlag = c.ErrorFlag;
@@ -310,7 +324,7 @@ int scatter_field(lt_engine* e, const double* src, DevBuf& dst, int nodes, int L
   HIPCHK(e, hipMemcpyAsync(e->staging.p, src, total * 8, hipMemcpyHostToDevice, e->stream));
   unsigned blocks = (unsigned)((total + 255) / 256);
   hipLaunchKernelGGL((k_slab_scatter<SlabT>), dim3(blocks), dim3(256), 0, e->stream,
-                     (const double*)e->staging.p, (SlabT*)dst.p, nodes, L, slot - 1, (int*)e->flags.p);
+                     (const double*)e->staging.p, (SlabT*)dst.p, nodes, L, e->phys[slot], (int*)e->flags.p);
   HIPCHK(e, hipGetLastError());
   return LT_OK;
 }
@@ -320,7 +334,7 @@ int set_slab_t(lt_engine* e, int slot, const lt_slab* s) {
   const int us = e->cfg.us, ws = e->cfg.ws;
   HIPCHK(e, hipMemcpyAsync(e->staging.p, s->zeta, (size_t)e->rho_nodes * 8, hipMemcpyHostToDevice, e->stream));
   hipLaunchKernelGGL((k_zeta_scatter<SlabT>), dim3((e->rho_nodes + 255) / 256), dim3(256), 0, e->stream,
-                     (const double*)e->staging.p, (SlabT*)e->zeta.p, e->rho_nodes, slot - 1, (int*)e->flags.p);
+                     (const double*)e->staging.p, (SlabT*)e->zeta.p, e->rho_nodes, e->phys[slot], (int*)e->flags.p);
   HIPCHK(e, hipGetLastError());
   TRY(scatter_field<SlabT>(e, s->Uvel, e->U, e->u_nodes, us, slot));
   TRY(scatter_field<SlabT>(e, s->Vvel, e->V, e->v_nodes, us, slot));
@@ -502,6 +516,42 @@ void launch_rk(lt_engine* e, const StepParams& P, unsigned blocks) {
 
 }  // namespace
 
+namespace {
+struct RomField {
+  const void* src; const int* mask; DevBuf* dst;
+  int n1, n2, L;           // array extents (i, j, level)
+  int i1, i2, j1, j2;      // window, 1-based inclusive
+  size_t off;              // element offset of the packed window in the staging buffers
+  size_t count() const { return (size_t)(i2 - i1 + 1) * (j2 - j1 + 1) * L; }
+};
+
+// copy the window of one field into the packed staging layout [level][j][i]
+void pack_field(const RomField& f, size_t es, char* pin, int k_lo, int k_hi) {
+  const size_t wi = (size_t)(f.i2 - f.i1 + 1), wj = (size_t)(f.j2 - f.j1 + 1);
+  const char* src = (const char*)f.src;
+  char* dst = pin + f.off * es;
+  for (int k = k_lo; k < k_hi; k++) {
+    if (wi == (size_t)f.n1) {  // full rows: one contiguous block of rows per level
+      memcpy(dst + (size_t)k * wi * wj * es,
+             src + (((size_t)k * f.n2 + (f.j1 - 1)) * f.n1) * es, wi * wj * es);
+    } else {
+      for (size_t jj = 0; jj < wj; jj++)
+        memcpy(dst + (((size_t)k * wj + jj) * wi) * es,
+               src + (((size_t)k * f.n2 + (f.j1 - 1 + jj)) * f.n1 + (f.i1 - 1)) * es, wi * es);
+    }
+  }
+}
+
+template <typename SlabT, typename HostT>
+void launch_rom_scatter(lt_engine* e, const RomField& f, int pslot) {
+  const size_t total = f.count();
+  if (!total) return;
+  hipLaunchKernelGGL((k_rom_scatter<SlabT, HostT>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     e->copy_stream, (const HostT*)e->stage_rom.p + f.off, (SlabT*)f.dst->p, f.mask, f.n1,
+                     f.i1, f.i2 - f.i1 + 1, f.j1, f.j2 - f.j1 + 1, f.L, pslot, (int*)e->flags.p + 1);
+}
+}  // namespace
+
 extern "C" {
 
 int lt_abi_version(void) { return LT_ABI_VERSION; }
@@ -534,6 +584,11 @@ int lt_create(const lt_config* cfg, lt_engine** out) {
   if (dev >= ndev || hipSetDevice(dev) != hipSuccess ||
       hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&e->rng_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&e->prefetch_done, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e->compute_mark, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e->pin_free[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e->pin_free[1], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&e->rng_done, hipEventDisableTiming) != hipSuccess) {
     delete e;
     return LT_ERR_DEVICE;
@@ -565,7 +620,7 @@ int lt_destroy(lt_engine* e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   DevBuf* bufs[] = {&e->rnode, &e->unode, &e->vnode, &e->RE, &e->UE, &e->VE, &e->rAdj, &e->uAdj,
-                    &e->vAdj, &e->lev, &e->U, &e->V, &e->W, &e->Kh, &e->zeta, &e->staging,
+                    &e->vAdj, &e->lev, &e->U, &e->V, &e->W, &e->Kh, &e->zeta, &e->staging, &e->stage_rom, &e->rmask, &e->umask, &e->vmask,
                     &e->flags, &e->bnd, &e->land, &e->bx, &e->by, &e->hx, &e->hy, &e->hid,
                     &e->seg_ptr, &e->seg_ids, &e->pm_ptr, &e->pm_ids, &e->pi_ptr, &e->pi_ids,
                     &e->polys, &e->holes, &e->polyspecs, &e->holespecs, &e->maxbdis, &e->maxhdis,
@@ -578,6 +633,14 @@ int lt_destroy(lt_engine* e) {
     if (b->p) (void)hipFree(b->p);
   for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
   if (e->h_counters) (void)hipHostFree(e->h_counters);
+  if (e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);
+  for (int i = 0; i < 2; i++) {
+    if (e->pin[i]) (void)hipHostFree(e->pin[i]);
+    if (e->pin_free[i]) (void)hipEventDestroy(e->pin_free[i]);
+  }
+  if (e->prefetch_done) (void)hipEventDestroy(e->prefetch_done);
+  if (e->compute_mark) (void)hipEventDestroy(e->compute_mark);
+  if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
   if (e->rng_done) (void)hipEventDestroy(e->rng_done);
   if (e->rng_stream) (void)hipStreamDestroy(e->rng_stream);
   if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -635,16 +698,24 @@ int lt_set_grid(lt_engine* e, const lt_grid* g) {
   // slabs: ALLOCATE + zero (hydrodynamic_module.f90:682-698)
   const size_t se = slab_elem(e);
   const size_t us = e->cfg.us, ws = e->cfg.ws;
-  TRY(dev_alloc(e, e->U, (size_t)e->u_nodes * us * 3 * se));
-  TRY(dev_alloc(e, e->V, (size_t)e->v_nodes * us * 3 * se));
-  TRY(dev_alloc(e, e->W, (size_t)e->rho_nodes * ws * 3 * se));
-  TRY(dev_alloc(e, e->Kh, (size_t)e->rho_nodes * ws * 3 * se));
+  TRY(dev_alloc(e, e->U, (size_t)e->u_nodes * us * LT_SLOTS * se));
+  TRY(dev_alloc(e, e->V, (size_t)e->v_nodes * us * LT_SLOTS * se));
+  TRY(dev_alloc(e, e->W, (size_t)e->rho_nodes * ws * LT_SLOTS * se));
+  TRY(dev_alloc(e, e->Kh, (size_t)e->rho_nodes * ws * LT_SLOTS * se));
   TRY(dev_alloc(e, e->zeta, (size_t)e->rho_nodes * 4 * se));
   HIPCHK(e, hipMemsetAsync(e->U.p, 0, e->U.bytes, e->stream));
   HIPCHK(e, hipMemsetAsync(e->V.p, 0, e->V.bytes, e->stream));
   HIPCHK(e, hipMemsetAsync(e->W.p, 0, e->W.bytes, e->stream));
   HIPCHK(e, hipMemsetAsync(e->Kh.p, 0, e->Kh.bytes, e->stream));
   HIPCHK(e, hipMemsetAsync(e->zeta.p, 0, e->zeta.bytes, e->stream));
+  e->have_masks = g->rho_mask && g->u_mask && g->v_mask;
+  if (e->have_masks) {  // m_r, m_u, m_v of updateHydro's mask multiply (lt_slab_prefetch, masked = 0)
+    TRY(upload(e, e->rmask, g->rho_mask, (size_t)g->rho_nodes * 4));
+    TRY(upload(e, e->umask, g->u_mask, (size_t)g->u_nodes * 4));
+    TRY(upload(e, e->vmask, g->v_mask, (size_t)g->v_nodes * 4));
+  }
+  e->phys[1] = 0; e->phys[2] = 1; e->phys[3] = 2; e->spare = 3;
+  e->prefetch_pending = false;
   size_t stage = std::max((size_t)e->rho_nodes * ws, (size_t)e->u_nodes * us) * 8;
   TRY(dev_alloc(e, e->staging, stage));
   HIPCHK(e, hipStreamSynchronize(e->stream));  // host vectors go out of scope
@@ -815,6 +886,127 @@ int lt_set_slab(lt_engine* e, int32_t slot, const lt_slab* s) {
                                                 : set_slab_t<double>(e, slot, s);
   if (rc == LT_OK) e->slab_set[slot] = true;
   return rc;
+}
+
+int lt_slab_prefetch(lt_engine* e, const lt_rom_record* r) {
+  if (!e || !r) return LT_ERR_ARG;
+  if (r->struct_size != (int32_t)sizeof(lt_rom_record)) return fail(e, LT_ERR_ABI, "lt_rom_record size mismatch");
+  if (!e->have_grid) return fail(e, LT_ERR_STATE, "lt_slab_prefetch before lt_set_grid");
+  if (e->prefetch_pending) return fail(e, LT_ERR_STATE, "lt_slab_prefetch: the previous record has not been committed");
+  if ((r->dtype != LT_ROM_F64 && r->dtype != LT_ROM_F32) || !r->romZ || !r->romU || !r->romV || !r->romW ||
+      (e->cfg.VTurbOn && !r->romKH))
+    return fail(e, LT_ERR_ARG, "lt_slab_prefetch: bad arguments (romKH is required when VTurbOn)");
+  if ((long long)r->vi * r->uj != e->rho_nodes || (long long)r->ui * r->uj != e->u_nodes ||
+      (long long)r->vi * r->vj != e->v_nodes || r->vi < 1 || r->uj < 1 || r->ui < 1 || r->vj < 1)
+    return fail(e, LT_ERR_ARG, "lt_slab_prefetch: vi,uj,ui,vj do not match the node counts of lt_set_grid");
+  if (!r->masked && !e->have_masks)
+    return fail(e, LT_ERR_ARG, "lt_slab_prefetch: masked = 0 needs rho_mask/u_mask/v_mask in lt_set_grid");
+  const int us = e->cfg.us, ws = e->cfg.ws;
+  int w[12] = {1, r->vi, 1, r->uj, 1, r->ui, 1, r->uj, 1, r->vi, 1, r->vj};
+  if (r->has_window) {
+    const int hi[12] = {r->vi, r->vi, r->uj, r->uj, r->ui, r->ui, r->uj, r->uj, r->vi, r->vi, r->vj, r->vj};
+    for (int i = 0; i < 12; i++) {
+      w[i] = r->window[i];
+      if (w[i] < 1 || w[i] > hi[i] || ((i & 1) && w[i] < w[i - 1]))
+        return fail(e, LT_ERR_ARG, "lt_slab_prefetch: window(%d) = %d is outside the grid", i + 1, w[i]);
+    }
+  }
+  const int* mr = r->masked ? nullptr : (const int*)e->rmask.p;
+  const int* mu = r->masked ? nullptr : (const int*)e->umask.p;
+  const int* mv = r->masked ? nullptr : (const int*)e->vmask.p;
+  RomField f[5] = {
+      {r->romZ, mr, &e->zeta, r->vi, r->uj, 1, w[0], w[1], w[2], w[3], 0},
+      {r->romU, mu, &e->U, r->ui, r->uj, us, w[4], w[5], w[6], w[7], 0},
+      {r->romV, mv, &e->V, r->vi, r->vj, us, w[8], w[9], w[10], w[11], 0},
+      {r->romW, mr, &e->W, r->vi, r->uj, ws, w[0], w[1], w[2], w[3], 0},
+      {r->romKH, mr, &e->Kh, r->vi, r->uj, ws, w[0], w[1], w[2], w[3], 0}};
+  const int nf = r->romKH ? 5 : 4;
+  size_t total = 0;
+  for (int i = 0; i < nf; i++) { f[i].off = total; total += (f[i].count() + 3) & ~(size_t)3; }
+  const size_t es = (r->dtype == LT_ROM_F32) ? 4 : 8;
+  const size_t bytes = total * es;
+  HIPCHK(e, hipSetDevice(e->device));
+  // pinned double buffer and device staging sized for a whole-grid record of doubles
+  const size_t cap = ((size_t)e->rho_nodes * (1 + 2 * (size_t)ws) + ((size_t)e->u_nodes + e->v_nodes) * us + 32) * 8;
+  if (e->pin_bytes < cap) {
+    for (int i = 0; i < 2; i++) {
+      if (e->pin_busy[i]) HIPCHK(e, hipEventSynchronize(e->pin_free[i]));
+      e->pin_busy[i] = false;
+      if (e->pin[i]) (void)hipHostFree(e->pin[i]);
+      e->pin[i] = nullptr;
+      if (hipHostMalloc(&e->pin[i], cap) != hipSuccess) return fail(e, LT_ERR_NOMEM, "pinned staging of %zu bytes", cap);
+    }
+    e->pin_bytes = cap;
+    HIPCHK(e, hipStreamSynchronize(e->copy_stream));
+    TRY(dev_alloc(e, e->stage_rom, cap));
+  }
+  const int b = e->pin_next;
+  e->pin_next ^= 1;
+  if (e->pin_busy[b]) HIPCHK(e, hipEventSynchronize(e->pin_free[b]));  // its last H2D copy
+  // pack: a few host threads share the (field, level) planes
+  {
+    struct Job { int fi, k_lo, k_hi; };
+    std::vector<Job> jobs;
+    for (int i = 0; i < nf; i++) {
+      const int step = std::max(1, f[i].L / 8);
+      for (int k = 0; k < f[i].L; k += step) jobs.push_back({i, k, std::min(f[i].L, k + step)});
+    }
+    const int nt = (int)std::min<size_t>(8, std::max<size_t>(1, bytes >> 22));
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+      for (size_t j; (j = next.fetch_add(1)) < jobs.size();)
+        pack_field(f[jobs[j].fi], es, (char*)e->pin[b], jobs[j].k_lo, jobs[j].k_hi);
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+  }
+  // the spare slot may still be read (as the old back record) by steps enqueued before
+  // the last commit
+  if (e->mark_valid) HIPCHK(e, hipStreamWaitEvent(e->copy_stream, e->compute_mark, 0));
+  HIPCHK(e, hipMemcpyAsync(e->stage_rom.p, e->pin[b], bytes, hipMemcpyHostToDevice, e->copy_stream));
+  HIPCHK(e, hipEventRecord(e->pin_free[b], e->copy_stream));
+  e->pin_busy[b] = true;
+  const bool f32 = e->cfg.slab_storage == LT_SLAB_F32;
+  for (int i = 0; i < nf; i++) {
+    if (f32 && es == 4) launch_rom_scatter<float, float>(e, f[i], e->spare);
+    else if (f32) launch_rom_scatter<float, double>(e, f[i], e->spare);
+    else if (es == 4) launch_rom_scatter<double, float>(e, f[i], e->spare);
+    else launch_rom_scatter<double, double>(e, f[i], e->spare);
+  }
+  HIPCHK(e, hipGetLastError());
+  HIPCHK(e, hipEventRecord(e->prefetch_done, e->copy_stream));
+  e->prefetch_pending = true;
+  return LT_OK;
+}
+
+int lt_slab_commit(lt_engine* e, int32_t t_b, int32_t t_c, int32_t t_f) {
+  if (!e) return LT_ERR_ARG;
+  if (t_b < 1 || t_b > 3 || t_c < 1 || t_c > 3 || t_f < 1 || t_f > 3 || t_b == t_c || t_c == t_f || t_b == t_f)
+    return fail(e, LT_ERR_ARG, "time slots must be a permutation of 1..3");
+  if (!e->prefetch_pending) return fail(e, LT_ERR_STATE, "lt_slab_commit without lt_slab_prefetch");
+  HIPCHK(e, hipSetDevice(e->device));
+  e->prefetch_pending = false;
+  HIPCHK(e, hipEventSynchronize(e->prefetch_done));
+  int flag = 0;
+  HIPCHK(e, hipMemcpy(&flag, (int*)e->flags.p + 1, 4, hipMemcpyDeviceToHost));
+  if (flag) {
+    (void)hipMemset((int*)e->flags.p + 1, 0, 4);
+    return fail(e, LT_ERR_SLAB_NOT_F32,
+                "slab value is not exactly representable in the device storage type; "
+                "use slab_storage = LT_SLAB_F64");
+  }
+  // later steps read the new record: ordered after the prefetch on the device as well
+  HIPCHK(e, hipStreamWaitEvent(e->stream, e->prefetch_done, 0));
+  const int old = e->phys[t_f];
+  e->phys[t_f] = e->spare;
+  e->spare = old;
+  e->t_b = t_b; e->t_c = t_c; e->t_f = t_f;
+  e->slab_set[t_f] = true;
+  HIPCHK(e, hipEventRecord(e->compute_mark, e->stream));
+  e->mark_valid = true;
+  return LT_OK;
 }
 
 int lt_set_time_slots(lt_engine* e, int32_t t_b, int32_t t_c, int32_t t_f) {

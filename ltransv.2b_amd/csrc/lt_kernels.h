@@ -487,7 +487,7 @@ LT_DEV int test_settlement(const StepParams& P, double Px, double Py, int R_ele)
 // ---------------------------------------------------- field access
 template <typename SlabT>
 LT_DEV double fld(const SlabT* F, int node, int L, int k, int ps) {
-  return (double)F[((size_t)(node - 1) * L + (k - 1)) * 3 + ps];
+  return (double)F[((size_t)(node - 1) * L + (k - 1)) * LT_SLOTS + ps];
 }
 
 // the per-particle context that find_currents needs (registers)
@@ -502,7 +502,6 @@ struct Column {
 // s-level depth split into its zeta-independent part (one division per level
 // instead of one per level and slot): the operations and their order are those
 // of getSlevel/getWlevel (hydrodynamic_module.f90:2691-2777).
-template <typename T> struct __attribute__((packed, aligned(4))) Slab3 { T a, b, c; };  // one (node, level): 3 slots
 struct LevCoef { double a, b, c; };
 LT_DEV LevCoef level_coef(const double* tab, int k, double h, double hc, int Vtransform) {
   LevCoef r;
@@ -706,17 +705,17 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
     // just left (they are dead once the horizontal interpolation has produced Y).
     const SlabT *b0 = F, *b1 = F, *b2 = F, *b3 = F;
     if (spl) {
-      b0 = F + ((size_t)(nd.x - 1) * L + (k0 - 1)) * 3;
-      b1 = F + ((size_t)(nd.y - 1) * L + (k0 - 1)) * 3;
-      b2 = F + ((size_t)(nd.z - 1) * L + (k0 - 1)) * 3;
-      b3 = F + ((size_t)(nd.w - 1) * L + (k0 - 1)) * 3;
+      b0 = F + ((size_t)(nd.x - 1) * L + (k0 - 1)) * LT_SLOTS;
+      b1 = F + ((size_t)(nd.y - 1) * L + (k0 - 1)) * LT_SLOTS;
+      b2 = F + ((size_t)(nd.z - 1) * L + (k0 - 1)) * LT_SLOTS;
+      b3 = F + ((size_t)(nd.w - 1) * L + (k0 - 1)) * LT_SLOTS;
     }
     auto request = [&](int s) {
       const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
 #pragma unroll
       for (int l = 0; l < 4; l++) {
-        raw[4 * l + 0] = b0[3 * l + ps]; raw[4 * l + 1] = b1[3 * l + ps];
-        raw[4 * l + 2] = b2[3 * l + ps]; raw[4 * l + 3] = b3[3 * l + ps];
+        raw[4 * l + 0] = b0[LT_SLOTS * l + ps]; raw[4 * l + 1] = b1[LT_SLOTS * l + ps];
+        raw[4 * l + 2] = b2[LT_SLOTS * l + ps]; raw[4 * l + 3] = b3[LT_SLOTS * l + ps];
       }
       zt = wsd[(size_t)(WS_ZETA0 + s) * N];
       pz = wsd[(size_t)(WS_PZ0 + s) * N];
@@ -943,7 +942,7 @@ __global__ __launch_bounds__(256) void k_pre(const StepParams P) {
         const Z4* zt = (const Z4*)P.zeta;
         Z4 z1 = zt[rn.x - 1], z2 = zt[rn.y - 1], z3 = zt[rn.z - 1], z4 = zt[rn.w - 1];
         auto pick = [](const Z4& v, int s) -> double {
-          return (double)((s == 0) ? v.x : (s == 1) ? v.y : v.z);
+          return (double)((s == 0) ? v.x : (s == 1) ? v.y : (s == 2) ? v.z : v.w);
         };
         double zeta[3], Pz[3];
         zeta[0] = apply_getinterp(w0, pick(z1, P.tb), pick(z2, P.tb), pick(z3, P.tb), pick(z4, P.tb));
@@ -1398,7 +1397,7 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
   double slope[3], icpt[3], wzhi[3], khhi[3];
   SlabT rawn[3][4];
   auto RAW = [&](int s, int i) {
-    const size_t o = (size_t)(i - 1) * 3 + pslot[s], L3 = (size_t)ws * 3;
+    const size_t o = (size_t)(i - 1) * LT_SLOTS + pslot[s], L3 = (size_t)ws * LT_SLOTS;
     rawn[s][0] = K[(size_t)(rn.x - 1) * L3 + o]; rawn[s][1] = K[(size_t)(rn.y - 1) * L3 + o];
     rawn[s][2] = K[(size_t)(rn.z - 1) * L3 + o]; rawn[s][3] = K[(size_t)(rn.w - 1) * L3 + o];
   };
@@ -1878,7 +1877,7 @@ __global__ void k_slab_scatter(const double* __restrict__ src, SlabT* __restrict
   double v = src[node + (size_t)nodes * k];
   SlabT c = (SlabT)v;
   if ((double)c != v && !(v != v)) atomicOr(flags, 1);
-  dst[idx * 3 + slot] = c;
+  dst[idx * LT_SLOTS + slot] = c;
 }
 
 template <typename SlabT>
@@ -1890,6 +1889,28 @@ __global__ void k_zeta_scatter(const double* __restrict__ src, SlabT* __restrict
   SlabT c = (SlabT)v;
   if ((double)c != v && !(v != v)) atomicOr(flags, 1);
   dst[idx * 4 + slot] = c;
+}
+
+// One field of a ROMS record (packed window [level][j][i], host type HostT) into a
+// physical slot of the slab: mask multiply in double as hydrodynamic_module.f90:1371-1403,
+// conversion to the storage type (checked lossless), node = (j-1)*n1 + i.
+template <typename SlabT, typename HostT>
+__global__ void k_rom_scatter(const HostT* __restrict__ src, SlabT* __restrict__ dst,
+                              const int* __restrict__ mask, int n1, int i1, int wi, int j1, int wj, int L,
+                              int pslot, int* flags) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t cells = (size_t)wi * wj;
+  if (idx >= cells * L) return;
+  // idx enumerates the destination order (cell-major, level fastest)
+  const size_t cell = idx / L;
+  const int k = (int)(idx - cell * L);
+  const int jj = (int)(cell / wi), ii = (int)(cell - (size_t)jj * wi);
+  const size_t node = (size_t)(j1 - 1 + jj) * n1 + (size_t)(i1 - 1 + ii);
+  double v = (double)src[cell + cells * k];
+  if (mask) v = v * (double)mask[node];
+  const SlabT c = (SlabT)v;
+  if ((double)c != v && !(v != v)) atomicOr(flags, 1);
+  dst[(node * L + k) * LT_SLOTS + pslot] = c;
 }
 
 // xyz(numpar,3) column-major in the REFERENCE particle order <- par(:,1:3)

@@ -11,11 +11,19 @@ import numpy as np
 
 
 class LtransRun:
-    def __init__(self, engine, dt, idt, record_fn):
-        """record_fn(r) -> dict(zeta, Uvel, Vvel, Wvel, Kh) for history record r (0-based)."""
+    def __init__(self, engine, dt, idt, record_fn, rom_fn=None, dims=None, window_fn=None):
+        """record_fn(r) -> dict(zeta, Uvel, Vvel, Wvel, Kh) for history record r (0-based).
+
+        rom_fn(r) -> dict(romZ, romU, romV, romW, romKH) (the record as read from the file,
+        unmasked) switches updateHydro to the slab pipeline: the record of the NEXT external
+        step is handed to ``slab_prefetch`` as soon as the current one has been committed,
+        and ``update_hydro`` is only the rotation + ``slab_commit``.  dims = (vi,uj,ui,vj);
+        window_fn(r) -> t_ijruv(12) or None."""
         self.e = engine
         self.dt, self.idt = int(dt), int(idt)
         self.record_fn = record_fn
+        self.rom_fn, self.dims, self.window_fn = rom_fn, dims, window_fn
+        self._prefetched = None
         self.t_b, self.t_c, self.t_f = 1, 2, 3
         self.stepf = 3
         self.p = 0
@@ -36,9 +44,27 @@ class LtransRun:
         self.t_c = self.t_c % 3 + 1
         self.t_f = self.t_f % 3 + 1
         self.stepf += 1
+        if self.rom_fn is not None:
+            if self._prefetched != self.stepf - 1:
+                self.prefetch(self.stepf - 1)
+            self.e.slab_commit(self.t_b, self.t_c, self.t_f)
+            self._prefetched = None
+            return
         r = self.record_fn(self.stepf - 1)
         self.e.set_slab(self.t_f, r["zeta"], r["Uvel"], r["Vvel"], r["Wvel"], r.get("Kh"))
         self.e.set_time_slots(self.t_b, self.t_c, self.t_f)
+
+    def prefetch(self, r):
+        """hand history record r (0-based) to the engine's spare slot (asynchronous)"""
+        w = self.window_fn(r) if self.window_fn is not None else None
+        self.e.slab_prefetch(self.rom_fn(r), self.dims, masked=False, window=w)
+        self._prefetched = r
+
+    def prefetch_next(self):
+        """the record the NEXT update_hydro will need; call right after update_hydro (or
+        init_hydro) so that the upload runs beside this external step's internal steps"""
+        if self.rom_fn is not None and self._prefetched is None:
+            self.prefetch(self.stepf)
 
     def external_times(self, p):
         return np.array([(p - 2) * self.dt, (p - 1) * self.dt, p * self.dt], dtype=np.float64)
@@ -51,6 +77,8 @@ class LtransRun:
         self.p = p
         if p > 2:
             self.update_hydro()
+        if p >= 2:
+            self.prefetch_next()
         ex = self.external_times(p)
         stepIT = self.dt // self.idt
         if max_internal is not None:

@@ -219,6 +219,40 @@ class Engine:
             s.Kh = _dp(k)
         self._check(self._fn["set_slab"](self._h, int(slot), C.byref(s)), "set_slab")
 
+    def slab_prefetch(self, rom, dims, masked=False, window=None):
+        """lt_slab_prefetch: ``rom`` = dict romZ (vi,uj), romU (ui,uj,us), romV (vi,vj,us),
+        romW / romKH (vi,uj,ws) as the host read them (float64 or float32, all the same
+        type, Fortran order); ``dims`` = (vi, uj, ui, vj); ``window`` = t_ijruv(12)."""
+        vi, uj, ui, vj = (int(d) for d in dims)
+        dt = np.dtype(rom["romZ"].dtype)
+        if dt not in (np.dtype(np.float64), np.dtype(np.float32)):
+            raise ValueError("rom arrays must be float64 or float32")
+        shapes = {"romZ": (vi, uj), "romU": (ui, uj, self.us), "romV": (vi, vj, self.us),
+                  "romW": (vi, uj, self.ws), "romKH": (vi, uj, self.ws)}
+        r = abi.LtRomRecord()
+        r.struct_size = C.sizeof(abi.LtRomRecord)
+        r.dtype = abi.LT_ROM_F32 if dt == np.dtype(np.float32) else abi.LT_ROM_F64
+        r.vi, r.uj, r.ui, r.vj = vi, uj, ui, vj
+        r.masked = 1 if masked else 0
+        r.has_window = 0 if window is None else 1
+        if window is not None:
+            for i, v in enumerate(window):
+                r.window[i] = int(v)
+        keep = []
+        for name, shp in shapes.items():
+            a = rom.get(name)
+            if a is None:
+                continue
+            a = np.asfortranarray(a, dtype=dt)
+            if a.shape != shp:
+                raise ValueError(f"{name} has shape {a.shape}, expected {shp}")
+            keep.append(a)
+            setattr(r, name, a.ctypes.data)
+        self._check(self._fn["slab_prefetch"](self._h, C.byref(r)), "slab_prefetch")
+
+    def slab_commit(self, t_b, t_c, t_f):
+        self._check(self._fn["slab_commit"](self._h, int(t_b), int(t_c), int(t_f)), "slab_commit")
+
     def set_time_slots(self, t_b, t_c, t_f):
         self._check(self._fn["set_time_slots"](self._h, int(t_b), int(t_c), int(t_f)),
                     "set_time_slots")

@@ -246,12 +246,16 @@ def create_bounds(g):
 # --------------------------------------------------------------------------
 # fields
 # --------------------------------------------------------------------------
-def make_record(g, geo, r, dt=3600.0, with_kh=True, drift=(0.0, 0.0)):
+def make_record(g, geo, r, dt=3600.0, with_kh=True, drift=(0.0, 0.0), raw=None):
     """History record r (time r*dt) as ROMS stores it (float32), then masked and
     node-numbered as updateHydro does (hydrodynamic_module.f90:1371-1403).
     ``drift`` adds a uniform (u, v) to push particles into the coast (reflection tests).
     Returns dict zeta (rho_nodes), Uvel (u_nodes,us), Vvel (v_nodes,us),
-    Wvel/Kh (rho_nodes,ws), all float64 holding float32-representable values."""
+    Wvel/Kh (rho_nodes,ws), all float64 holding float32-representable values.
+    ``raw`` = np.float32 / np.float64: instead return the record as NF90_GET_VAR delivers
+    it, BEFORE the mask multiply: dict romZ (vi,uj), romU (ui,uj,us), romV (vi,vj,us),
+    romW, romKH (vi,uj,ws) of that type, Fortran order (land points hold ocean-like
+    values, as a ROMS file's fill-free fields may)."""
     vi, uj, us, ws = g["vi"], g["uj"], g["us"], g["ws"]
     Lx, Ly = (vi - 1) * g["dx"], (uj - 1) * g["dy"]
     t = r * dt
@@ -275,6 +279,13 @@ def make_record(g, geo, r, dt=3600.0, with_kh=True, drift=(0.0, 0.0)):
     U = (u2[:, :, None] + drift[0]) * shear
     V = (v2[:, :, None] + drift[1]) * shear
     W = 1.0e-3 * np.sin(np.pi * sw) * (np.sin(2 * np.pi * xr) * np.cos(np.pi * yr))[:, :, None] * tide
+    if with_kh:
+        K = 1.0e-5 + 1.0e-2 * 4.0 * (-sw) * (1.0 + sw) * \
+            (0.55 + 0.45 * np.sin(2 * np.pi * (xr + 0.25 * t / 44714.0)) * np.cos(2 * np.pi * yr))[:, :, None]
+    if raw is not None:
+        conv = lambda a: np.asfortranarray(a.astype(np.float32).astype(raw))  # noqa: E731
+        return dict(romZ=conv(zeta), romU=conv(U + 0.0 * sr), romV=conv(V + 0.0 * sr), romW=conv(W),
+                    romKH=conv(K) if with_kh else None)
     out = dict(
         zeta=F(f32(zeta) * geo["m_r"]),
         Uvel=F(f32(U) * geo["m_u"][:, :, None]),
@@ -282,8 +293,6 @@ def make_record(g, geo, r, dt=3600.0, with_kh=True, drift=(0.0, 0.0)):
         Wvel=F(f32(W) * geo["m_r"][:, :, None]),
     )
     if with_kh:
-        K = 1.0e-5 + 1.0e-2 * 4.0 * (-sw) * (1.0 + sw) * \
-            (0.55 + 0.45 * np.sin(2 * np.pi * (xr + 0.25 * t / 44714.0)) * np.cos(2 * np.pi * yr))[:, :, None]
         out["Kh"] = F(f32(K) * geo["m_r"][:, :, None])
     else:
         out["Kh"] = None

@@ -40,6 +40,8 @@ int lto_set_habitat(lto_engine *e, const lt_habitat *h);
 int lto_set_particles(lto_engine *e, const lt_particles *p);
 int lto_set_slab(lto_engine *e, int32_t slot, const lt_slab *s);
 int lto_set_time_slots(lto_engine *e, int32_t t_b, int32_t t_c, int32_t t_f);
+int lto_slab_prefetch(lto_engine *e, const lt_rom_record *r);
+int lto_slab_commit(lto_engine *e, int32_t t_b, int32_t t_c, int32_t t_f);
 int lto_set_rng(lto_engine *e, const int32_t *mt624, int32_t mti);
 int lto_get_rng(lto_engine *e, int32_t *mt624, int32_t *mti);
 int lto_count_active(lto_engine *e, const double *ix3, int64_t *n_active);

@@ -70,8 +70,17 @@ def build_case(name, numpar=None, slab_storage=None, **cfg_extra):
             recs[r] = rs.make_record(g, geo, r, with_kh=True, drift=spec.get("drift", (0.0, 0.0)))
         return recs[r]
 
+    roms = {}
+
+    def rom(r, dtype=np.float64):
+        """the same record as the file delivers it (unmasked), for the slab pipeline"""
+        if (r, dtype) not in roms:
+            roms[(r, dtype)] = rs.make_record(g, geo, r, with_kh=True, drift=spec.get("drift", (0.0, 0.0)),
+                                              raw=dtype)
+        return roms[(r, dtype)]
+
     return dict(name=name, g=g, geo=geo, bounds=bounds, cfg=cfg, parts=parts, record=record,
-                habitat=habitat)
+                habitat=habitat, rom=rom, dims=(g["vi"], g["uj"], g["ui"], g["vj"]))
 
 
 def make_engine(case, engine_cls, engine_kw):
@@ -84,9 +93,16 @@ def make_engine(case, engine_cls, engine_kw):
     return e
 
 
-def run_case(case, engine_cls, engine_kw, n_external=2, max_internal=None, trace=None):
+def run_case(case, engine_cls, engine_kw, n_external=2, max_internal=None, trace=None,
+             pipeline=None, window_fn=None):
+    """pipeline = np.float64 / np.float32: updateHydro through slab_prefetch / slab_commit
+    with host arrays of that type instead of set_slab."""
     e = make_engine(case, engine_cls, engine_kw)
-    run = LtransRun(e, case["cfg"].dt, case["cfg"].idt, case["record"])
+    if pipeline is None:
+        run = LtransRun(e, case["cfg"].dt, case["cfg"].idt, case["record"])
+    else:
+        run = LtransRun(e, case["cfg"].dt, case["cfg"].idt, case["record"],
+                        rom_fn=lambda r: case["rom"](r, pipeline), dims=case["dims"], window_fn=window_fn)
     run.init_hydro()
 
     def on_step(p, it, ex, ix):
