@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--turb", action="store_true",
                     help="BASELINE configs[2]: RK4 + HTurb + VTurb (MT19937 stream on device)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hydro-timing", action="store_true",
+                    help="skip the updateHydro cost measurement (set_slab vs slab pipeline)")
     ap.add_argument("--cpu-sample", type=int, default=40000,
                     help="particles of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-steps", type=int, default=30)
@@ -91,6 +93,60 @@ def make_engine(ltrans_amd, cfg, g, geo, bounds, parts, records, **kw):
     run = LtransRun(e, cfg.dt, cfg.idt, lambda r: records(r))
     run.init_hydro()
     return e, run
+
+
+def hydro_update_costs(e, run, rs, g, geo, args, state, one_step, fence):
+    """What one updateHydro costs on this box, outside the throughput measurement
+    (SURVEY.md 8f row 1): the synchronous lt_set_slab path (host waits, GPU idle) against
+    the slab pipeline (lt_slab_prefetch beside the steps, lt_slab_commit at the rotation).
+    ``exposed`` = wall of [prefetch, stepIT steps, commit] - wall of [stepIT steps]."""
+    import numpy as np
+    stepIT = run.dt // run.idt
+    r0 = run.stepf
+    masked = rs.make_record(g, geo, r0, with_kh=bool(args.turb))
+    rom32 = rs.make_record(g, geo, r0 + 1, with_kh=bool(args.turb), raw=np.float32)
+    rom64 = rs.make_record(g, geo, r0 + 2, with_kh=bool(args.turb), raw=np.float64)
+    dims = (g["vi"], g["uj"], g["ui"], g["vj"])
+    mb = lambda d: sum(v.nbytes for v in d.values() if v is not None) / 1e6  # noqa: E731
+
+    def steps():
+        for _ in range(stepIT):
+            state["it"] = state["it"] % stepIT
+            one_step()
+
+    def rotated():
+        return run.t_b % 3 + 1, run.t_c % 3 + 1, run.t_f % 3 + 1
+
+    fence()
+    t0 = time.perf_counter(); steps(); fence(); t_steps = time.perf_counter() - t0
+    # synchronous path
+    run.t_b, run.t_c, run.t_f = rotated()
+    t0 = time.perf_counter()
+    e.set_slab(run.t_f, masked["zeta"], masked["Uvel"], masked["Vvel"], masked["Wvel"], masked.get("Kh"))
+    e.set_time_slots(run.t_b, run.t_c, run.t_f)
+    fence()
+    t_sync = time.perf_counter() - t0
+    out = {"steps_per_external_step": stepIT, "steps_ms": t_steps * 1e3,
+           "set_slab": {"host_mb": mb(masked), "ms": t_sync * 1e3}}
+    # first use allocates the pinned staging buffers: not part of a steady-state update
+    e.slab_prefetch(rom32, dims)
+    run.t_b, run.t_c, run.t_f = rotated()
+    e.slab_commit(run.t_b, run.t_c, run.t_f)
+    for name, rom in (("pipeline_f32_host_arrays", rom32), ("pipeline_f64_host_arrays", rom64)):
+        fence()
+        t0 = time.perf_counter()
+        e.slab_prefetch(rom, dims)
+        t_call = time.perf_counter() - t0
+        steps()
+        run.t_b, run.t_c, run.t_f = rotated()
+        tc = time.perf_counter()
+        e.slab_commit(run.t_b, run.t_c, run.t_f)
+        t_commit = time.perf_counter() - tc
+        fence()
+        t_all = time.perf_counter() - t0
+        out[name] = {"host_mb": mb(rom), "prefetch_call_ms": t_call * 1e3, "commit_call_ms": t_commit * 1e3,
+                     "exposed_ms": (t_all - t_steps) * 1e3}
+    return out
 
 
 def cpu_baseline(ltrans_amd, args, vi, uj, us, g, geo, bounds, records):
@@ -272,6 +328,8 @@ def main():
                      "algorithmic_bytes_per_launch": A * n,
                      "algorithmic_bytes_per_particle_step": A},
     }
+    if world == 1 and not args.no_hydro_timing:
+        out["config"]["hydro_update"] = hydro_update_costs(e, run, rs, g, geo, args, state, one_step, fence)
     if rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ltrans_amd, args, vi, uj, us, g, geo, bounds, records)
     elif rank == 0:

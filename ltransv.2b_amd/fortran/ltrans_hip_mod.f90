@@ -69,6 +69,17 @@ module ltrans_hip
     type(c_ptr) :: zeta, Uvel, Vvel, Wvel, Kh
   end type lt_slab
 
+  ! a ROMS record as updateHydro holds it after NF90_GET_VAR, before the mask multiply
+  ! (hydrodynamic_module.f90:1065-1368): rom*f arrays + t_ijruv
+  integer(c_int32_t), parameter :: LT_ROM_F64 = 0, LT_ROM_F32 = 1
+  type, bind(C) :: lt_rom_record
+    integer(c_int32_t) :: struct_size, dtype
+    integer(c_int32_t) :: vi, uj, ui, vj
+    integer(c_int32_t) :: masked, has_window
+    integer(c_int32_t) :: window(12)
+    type(c_ptr) :: romZ, romU, romV, romW, romKH
+  end type lt_rom_record
+
   type, bind(C) :: lt_step_stats
     integer(c_int64_t) :: active, errors, rng_draws
   end type lt_step_stats
@@ -129,6 +140,18 @@ module ltrans_hip
       type(c_ptr), value :: engine
       integer(c_int32_t), value :: slot
       type(lt_slab), intent(in) :: s
+      integer(c_int) :: rc
+    end function
+    function lt_slab_prefetch(engine, r) bind(C, name="lt_slab_prefetch") result(rc)
+      import :: c_int, c_ptr, lt_rom_record
+      type(c_ptr), value :: engine
+      type(lt_rom_record), intent(in) :: r
+      integer(c_int) :: rc
+    end function
+    function lt_slab_commit(engine, t_b, t_c, t_f) bind(C, name="lt_slab_commit") result(rc)
+      import :: c_int, c_int32_t, c_ptr
+      type(c_ptr), value :: engine
+      integer(c_int32_t), value :: t_b, t_c, t_f
       integer(c_int) :: rc
     end function
     function lt_set_time_slots(engine, t_b, t_c, t_f) bind(C, name="lt_set_time_slots") result(rc)
