@@ -66,11 +66,19 @@ def pmc_traffic(tag, kernels, n, args):
     except (OSError, ValueError):
         return None, None
     tot = 0.0
+    valu = {}
     for kern in kernels:
         hit = [v for k, v in d.items() if ("::" + kern + "(" in k or "::" + kern + "<" in k)]
         if not hit or "fetch_bytes_per_launch" not in hit[0] or "write_bytes_per_launch" not in hit[0]:
             return None, None
         tot += hit[0]["fetch_bytes_per_launch"] + hit[0]["write_bytes_per_launch"]
+        g = lambda c: hit[0].get(c, {}).get("mean_per_launch")  # noqa: E731
+        if g("SQ_WAVES") and g("SQ_WAVE_CYCLES"):
+            # what actually bounds these kernels: the fp64 VALU instruction stream
+            valu[kern] = {"valu_instr_per_particle_step": g("SQ_INSTS_VALU") / g("SQ_WAVES"),
+                          "wave_cycles_valu_active": g("SQ_ACTIVE_INST_VALU") / g("SQ_WAVE_CYCLES"),
+                          "wave_cycles_waiting": g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES")}
+    pmc_traffic.valu = valu
     return tot, "profiles/%s/pmc.json" % tag
 
 
@@ -325,6 +333,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_src,
                      "kernel": "+".join(kernels), "kernel_ms_avg": k_avg_s * 1e3,
+                     "valu_pmc": getattr(pmc_traffic, "valu", None),
                      "algorithmic_bytes_per_launch": A * n,
                      "algorithmic_bytes_per_particle_step": A},
     }

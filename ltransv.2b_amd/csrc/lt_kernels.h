@@ -846,7 +846,9 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
       TICK(3);
     }
     // ---------------- pass B: everything of this variable that iterates
+#ifndef LT_ABL_NOTASKS
     run_tasks(ws, (nchk < LT_CHK_CAP) ? nchk : LT_CHK_CAP, nev, lane);
+#endif
     TICK(4);
     // ---------------- pass C: time interpolation :1534-1598 / hydrodynamic_module.f90:2653-2670
     if (act && !zero) {
