@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define LT_ABI_VERSION 1
+#define LT_ABI_VERSION 2
 
 /* status codes */
 #define LT_OK                 0
@@ -99,10 +99,16 @@ typedef struct lt_config {
                                  serial MT19937 stream is reproduced on the device        */
   double  ConstantHTurb;
   /* $behavparam */
-  int32_t Behavior;           /* 0 passive, 6 constant sink/float; 1-5,7 unsupported   */
+  int32_t Behavior;           /* 0 passive, 1 near-surface, 2 near-bottom, 3 diurnal vertical
+                                 migration, 4 C. virginica, 5 C. ariakensis, 6 constant
+                                 sink/float, 7 tidal stream transport
+                                 (behavior_module.f90:181-551)                            */
   int32_t OpenOceanBoundary;
   int32_t mortality;
   double  deadage, pediage, swimstart, swimslow, swimfast, sink, Swimdepth;
+  double  Sgradient, Hswimspeed;                       /* rest of $behavparam          */
+  /* $dvmparam (behaviour 3) */
+  double  twistart, twiend, daylength, Em, Kd, thresh;
   /* $settleparam */
   int32_t settlementon, holesExist;
   /* $convparam */
@@ -110,7 +116,7 @@ typedef struct lt_config {
   /* $other */
   int32_t seed;               /* init_genrand(seed) (LTRANS.f90:241)                   */
   int32_t ErrorFlag;          /* 0 stop, 1 return to previous, 2 kill, 3 set out       */
-  int32_t SaltTempOn;         /* unsupported (must be 0)                               */
+  int32_t SaltTempOn;         /* P_Salt / P_Temp at the particle (LTRANS.f90:1062-1076) */
   int32_t TrackCollisions;
   int32_t FreeSlip;           /* unsupported (must be 0)                               */
   /* build-specific (not in LTRANS.data) */
@@ -185,6 +191,14 @@ typedef struct lt_particles {
   int32_t *hitBottom;            /* LTRANS.f90:122 (TrackCollisions)                */
   int32_t *hitLand;
   int32_t *err_code;             /* LT_PERR_* of the last step (build addition)     */
+  /* behaviours 4, 5, 7 (behavior_module.f90:61,70-71,80) */
+  double  *timer;                /* C. ariakensis downward-swimming timer           */
+  double  *P_Sprev;              /* salinity at the previous location               */
+  double  *P_zprev;              /* previous depth                                  */
+  int32_t *bottom;               /* LOGICAL: on the bottom (behaviour 7)            */
+  /* SaltTempOn (LTRANS.f90:124,1072-1075): outputs only */
+  double  *P_Salt;
+  double  *P_Temp;
 } lt_particles;
 
 /* One time record of the hydrodynamic fields, as updateHydro scatters it into
@@ -196,6 +210,8 @@ typedef struct lt_slab {
   const double *Vvel;            /* (v_nodes,us)                                    */
   const double *Wvel;            /* (rho_nodes,ws)                                  */
   const double *Kh;              /* (rho_nodes,ws)  NULL allowed when VTurbOn = 0   */
+  const double *salt;            /* (rho_nodes,us)  needed by behaviours 4,5,7 and SaltTempOn */
+  const double *temp;            /* (rho_nodes,us)  needed by SaltTempOn            */
 } lt_slab;
 
 /* One ROMS history record as updateHydro holds it right after NF90_GET_VAR
@@ -225,6 +241,7 @@ typedef struct lt_rom_record {
   int32_t window[12];            /* t_ijruv                                          */
   const void *romZ, *romU, *romV, *romW;
   const void *romKH;             /* NULL allowed when VTurbOn = 0                    */
+  const void *romS, *romT;       /* (vi,uj,us) salinity / temperature, as lt_slab     */
 } lt_rom_record;
 
 /* Per-step counters (sums over the shard). */
@@ -277,6 +294,15 @@ int lt_get_rng(lt_engine *e, int32_t *mt624, int32_t *mti);
  * and the total over all shards.  Defaults: 0 and the shard's own count. */
 int lt_count_active(lt_engine *e, const double *ix3, int64_t *n_active);
 int lt_set_rng_window(lt_engine *e, int64_t active_before, int64_t active_total);
+/* Behaviours 1-5 draw a data-dependent number of deviates per particle
+ * (genrand_real1, behavior_module.f90:256-452), so a shard's place in the stream is a
+ * number of DRAWS: lt_count_draws runs the first part of the step (the gates, the element
+ * search, the salinity cue) and returns the draws this shard will consume; the following
+ * lt_step with the same arguments continues from there.  lt_set_rng_window_draws gives
+ * the draws consumed by lower-ranked shards and by all shards in this step. */
+int lt_count_draws(lt_engine *e, const double *ex3, const double *ix3, int32_t p, int32_t it,
+                   int64_t *n_draws);
+int lt_set_rng_window_draws(lt_engine *e, int64_t draws_before, int64_t draws_total);
 
 /* the hot path ---------------------------------------------------------- */
 /* = update_particles() with main's ex(3), ix(3), p, it (LTRANS.f90:568-571,

@@ -5,7 +5,7 @@ checks sizes/offsets against a C probe compiled from the header.
 """
 import ctypes as C
 
-LT_ABI_VERSION = 1
+LT_ABI_VERSION = 2
 
 LT_OK = 0
 LT_ERR = {
@@ -45,6 +45,9 @@ class LtConfig(C.Structure):
         ("deadage", C.c_double), ("pediage", C.c_double), ("swimstart", C.c_double),
         ("swimslow", C.c_double), ("swimfast", C.c_double), ("sink", C.c_double),
         ("Swimdepth", C.c_double),
+        ("Sgradient", C.c_double), ("Hswimspeed", C.c_double),
+        ("twistart", C.c_double), ("twiend", C.c_double), ("daylength", C.c_double),
+        ("Em", C.c_double), ("Kd", C.c_double), ("thresh", C.c_double),
         ("settlementon", C.c_int32), ("holesExist", C.c_int32),
         ("PI", C.c_double),
         ("seed", C.c_int32), ("ErrorFlag", C.c_int32), ("SaltTempOn", C.c_int32),
@@ -63,6 +66,9 @@ class LtConfig(C.Structure):
         self.deadage, self.pediage = 367200.0, 302400.0
         self.swimslow = self.swimfast = 0.005
         self.sink, self.Swimdepth = -0.0003, 2.0
+        self.Sgradient, self.Hswimspeed = 1.0, 0.9
+        self.twistart, self.twiend, self.daylength = 4.801821, 19.19956, 14.39774
+        self.Em, self.Kd, self.thresh = 1814.328, 1.07, 0.0166
         self.PI = 3.14159265358979
         self.seed = 9
         self.ErrorFlag = 1
@@ -125,6 +131,8 @@ PARTICLE_FIELDS = [
     ("settle", c_ip, "i4", 1), ("settletime", c_dp, "f8", 1),
     ("endpoly", c_ip, "i4", 1), ("hitBottom", c_ip, "i4", 1), ("hitLand", c_ip, "i4", 1),
     ("err_code", c_ip, "i4", 1),
+    ("timer", c_dp, "f8", 1), ("P_Sprev", c_dp, "f8", 1), ("P_zprev", c_dp, "f8", 1),
+    ("bottom", c_ip, "i4", 1), ("P_Salt", c_dp, "f8", 1), ("P_Temp", c_dp, "f8", 1),
 ]
 
 
@@ -133,7 +141,8 @@ class LtParticles(C.Structure):
 
 
 class LtSlab(C.Structure):
-    _fields_ = [("zeta", c_dp), ("Uvel", c_dp), ("Vvel", c_dp), ("Wvel", c_dp), ("Kh", c_dp)]
+    _fields_ = [("zeta", c_dp), ("Uvel", c_dp), ("Vvel", c_dp), ("Wvel", c_dp), ("Kh", c_dp),
+                ("salt", c_dp), ("temp", c_dp)]
 
 
 LT_ROM_F64, LT_ROM_F32 = 0, 1
@@ -146,7 +155,7 @@ class LtRomRecord(C.Structure):
         ("vi", C.c_int32), ("uj", C.c_int32), ("ui", C.c_int32), ("vj", C.c_int32),
         ("masked", C.c_int32), ("has_window", C.c_int32), ("window", C.c_int32 * 12),
         ("romZ", C.c_void_p), ("romU", C.c_void_p), ("romV", C.c_void_p), ("romW", C.c_void_p),
-        ("romKH", C.c_void_p),
+        ("romKH", C.c_void_p), ("romS", C.c_void_p), ("romT", C.c_void_p),
     ]
 
 
@@ -159,6 +168,7 @@ class LtStepStats(C.Structure):
 ENTRY_POINTS = [
     "create", "destroy", "set_grid", "set_bounds", "set_habitat", "set_particles",
     "set_slab", "set_time_slots", "slab_prefetch", "slab_commit", "set_rng", "get_rng", "count_active", "set_rng_window",
+    "count_draws", "set_rng_window_draws",
     "step", "sync", "get_stats", "get_particles",
 ]
 HIP_ONLY_ENTRY_POINTS = ["last_error", "abi_version", "pack_positions", "stream",

@@ -115,18 +115,18 @@ $behavparam
   swimstart = {cfg.swimstart!r}
   swimslow  = {cfg.swimslow!r}
   swimfast  = {cfg.swimfast!r}
-  Sgradient = 1.0
+  Sgradient = {cfg.Sgradient!r}
   sink      = {cfg.sink!r}
-  Hswimspeed = 0.9
+  Hswimspeed = {cfg.Hswimspeed!r}
   Swimdepth  = {cfg.Swimdepth!r}
 $end
 $dvmparam
-  twistart  = 4.801821
-  twiend    = 19.19956
-  daylength = 14.39774
-  Em        = 1814.328
-  Kd        = 1.07
-  thresh    = 0.0166
+  twistart  = {cfg.twistart!r}
+  twiend    = {cfg.twiend!r}
+  daylength = {cfg.daylength!r}
+  Em        = {cfg.Em!r}
+  Kd        = {cfg.Kd!r}
+  thresh    = {cfg.thresh!r}
 $end
 $settleparam
  settlementon = {_l(cfg.settlementon)}

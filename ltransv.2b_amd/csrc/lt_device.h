@@ -87,6 +87,12 @@ struct StepParams {
   // ---- options
   int Behavior, OpenOceanBoundary, mortality, settlementon, holesExist, ErrorFlag, TrackCollisions;
   double swimstart, swimfast, sink;
+  // behaviours 1-5, 7 and SaltTempOn (behavior_module.f90:181-551, LTRANS.f90:1062-1076)
+  int dt, SaltTempOn;
+  double Sgradient, Hswimspeed, Swimdepth, twistart, twiend, daylength, Em, Kd, thresh;
+  const void *S, *T;                 // salinity / temperature slabs [rho node][us][LT_SLOTS]
+  double *timer, *P_Sprev, *P_zprev, *P_Salt, *P_Temp;
+  int* bottom;
   // ---- boundaries
   const double* bnd;   // [nbounds][4] = x1, y1, x2, y2
   const int* land;     // [nbounds]
@@ -110,8 +116,10 @@ struct StepParams {
   const uint32_t* rng_ring;       // raw stream words, ring of rng_mask+1 words
   unsigned long long rng_mask;    // ring size - 1 (power of two)
   unsigned long long rng_base;    // stream index of the first draw of THIS shard's first active particle
-  int rng_draws;                  // draws per active particle (4 HTurb + 2*(idt/2) VTurb)
-  const int* rank;                // [numpar] rank of the particle among the active ones, indexed by reference index
+  int rng_draws;                  // turbulence draws per active particle (4 HTurb + 2*(idt/2) VTurb);
+                                  // the behaviour draws (0..3, data dependent) follow them
+  const int* rank;                // [numpar] offset of the particle's first draw behind rng_base: exclusive
+                                  // sum, in reference order, of the draws of the tracked particles
   const int* orig;                // [numpar] reference index of internal slot i
   double* vt_x; double* vt_y; double* vt_yp; double* vt_sig;  // VTurb spline tables [4*ws][numpar]
   // ---- per-step workspace exchanged between k_pre / k_rk / k_post

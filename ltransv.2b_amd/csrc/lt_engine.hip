@@ -49,7 +49,7 @@ struct lt_engine {
   int rho_nodes = 0, u_nodes = 0, v_nodes = 0, rho_elements = 0, u_elements = 0, v_elements = 0;
   DevBuf rnode, unode, vnode, RE, UE, VE, rAdj, uAdj, vAdj, lev;
   // slabs
-  DevBuf U, V, W, Kh, zeta, staging, flags;
+  DevBuf U, V, W, Kh, zeta, S, T, staging, flags;
   bool slab_set[4] = {false, false, false, false};
   int t_b = 1, t_c = 2, t_f = 3;
   // bounds
@@ -69,7 +69,7 @@ struct lt_engine {
   std::vector<int> perm;
   bool sort_particles = true;
   DevBuf par, pr, pu, pv, P_behave, dead, oob, settle, endpoly, hitBottom, hitLand, err_code,
-      P_swim, P_pediage, P_deadage, settletime;
+      P_swim, P_pediage, P_deadage, settletime, timer, P_Sprev, P_zprev, bottom, P_Salt, P_Temp;
   // rng: the reference's single serial MT19937 stream, materialised on the device
   // in blocks (lt_mt.h).  Stream word k ("virtual stream"): k < 624 -> mt[k] of the
   // state given at start, k >= 624 -> generated; the cursor starts at mti.
@@ -104,6 +104,11 @@ struct lt_engine {
   int pin_next = 0;
   DevBuf stage_rom, rmask, umask, vmask;
   bool have_masks = false;
+  // first part of a step done ahead by lt_count_draws (or by lt_step itself)
+  StepParams pre_P;
+  bool pre_valid = false;
+  int64_t pre_own = 0;
+  double pre_sig[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   hipStream_t rng_stream = nullptr;  // the MT19937 blocks of a step are generated beside k_rk
   hipEvent_t rng_done = nullptr;
   bool rng_pending = false;
@@ -194,6 +199,11 @@ constexpr size_t RNG_S = (size_t)1 << RNG_LOG2_S;  // MT19937 stream words per b
 
 size_t slab_elem(const lt_engine* e) { return e->cfg.slab_storage == LT_SLAB_F32 ? 4 : 8; }
 
+// the salinity field is read by behaviours 4, 5, 7 (behavior_module.f90:233-246) and SaltTempOn
+bool needs_salt(const lt_config& c) {
+  return c.SaltTempOn || c.Behavior == 4 || c.Behavior == 5 || c.Behavior == 7;
+}
+
 void fill_params(lt_engine* e, StepParams& P) {
   memset(&P, 0, sizeof(P));
   const lt_config& c = e->cfg;
@@ -221,6 +231,13 @@ void fill_params(lt_engine* e, StepParams& P) {
   P.settlementon = c.settlementon; P.holesExist = c.holesExist; P.ErrorFlag = c.ErrorFlag;
   P.TrackCollisions = c.TrackCollisions;
   P.swimstart = c.swimstart; P.swimfast = c.swimfast; P.sink = c.sink;
+  P.dt = c.dt; P.SaltTempOn = c.SaltTempOn;
+  P.Sgradient = c.Sgradient; P.Hswimspeed = c.Hswimspeed; P.Swimdepth = c.Swimdepth;
+  P.twistart = c.twistart; P.twiend = c.twiend; P.daylength = c.daylength;
+  P.Em = c.Em; P.Kd = c.Kd; P.thresh = c.thresh;
+  P.S = e->S.p; P.T = e->T.p;
+  P.timer = (double*)e->timer.p; P.P_Sprev = (double*)e->P_Sprev.p; P.P_zprev = (double*)e->P_zprev.p;
+  P.bottom = (int*)e->bottom.p; P.P_Salt = (double*)e->P_Salt.p; P.P_Temp = (double*)e->P_Temp.p;
   P.bnd = (const double*)e->bnd.p; P.land = (const int*)e->land.p; P.nbounds = e->nbounds;
   P.seg = e->seg; P.use_seg_index = e->use_seg_index;
   P.bx = (const double*)e->bx.p; P.by = (const double*)e->by.p; P.maxbound = e->maxbound;
@@ -340,6 +357,8 @@ int set_slab_t(lt_engine* e, int slot, const lt_slab* s) {
   TRY(scatter_field<SlabT>(e, s->Vvel, e->V, e->v_nodes, us, slot));
   TRY(scatter_field<SlabT>(e, s->Wvel, e->W, e->rho_nodes, ws, slot));
   if (s->Kh) TRY(scatter_field<SlabT>(e, s->Kh, e->Kh, e->rho_nodes, ws, slot));
+  if (s->salt && e->S.p) TRY(scatter_field<SlabT>(e, s->salt, e->S, e->rho_nodes, us, slot));
+  if (s->temp && e->T.p) TRY(scatter_field<SlabT>(e, s->temp, e->T, e->rho_nodes, us, slot));
   int flag = 0;
   HIPCHK(e, hipMemcpyAsync(&flag, e->flags.p, 4, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));  // the caller's arrays may change after return
@@ -566,8 +585,8 @@ int lt_create(const lt_config* cfg, lt_engine** out) {
   if (cfg->numpar < 0 || cfg->us < 5 || cfg->ws != cfg->us + 1 || cfg->ws > LT_LEV_STRIDE ||
       cfg->idt <= 0 || cfg->Vtransform < 1 || cfg->Vtransform > 3)
     return LT_ERR_ARG;
-  if (cfg->FreeSlip || cfg->SaltTempOn) return LT_ERR_UNSUPPORTED;
-  if (!(cfg->Behavior == 0 || cfg->Behavior == 6)) return LT_ERR_UNSUPPORTED;
+  if (cfg->FreeSlip) return LT_ERR_UNSUPPORTED;
+  if (cfg->Behavior < 0 || cfg->Behavior > 7) return LT_ERR_UNSUPPORTED;
   if (cfg->slab_storage != LT_SLAB_F32 && cfg->slab_storage != LT_SLAB_F64) return LT_ERR_ARG;
   lt_engine* e = new (std::nothrow) lt_engine();
   if (!e) return LT_ERR_NOMEM;
@@ -627,7 +646,7 @@ int lt_destroy(lt_engine* e) {
                     &e->ep_ptr, &e->ep_ids, &e->ph_ptr, &e->ph_ids, &e->par, &e->pr, &e->pu,
                     &e->pv, &e->P_behave, &e->dead, &e->oob, &e->settle, &e->endpoly,
                     &e->hitBottom, &e->hitLand, &e->err_code, &e->P_swim, &e->P_pediage,
-                    &e->P_deadage, &e->settletime, &e->counters, &e->ws_d, &e->ws_i, &e->orig, &e->ele_ok, &e->block_active, &e->count_slots, &e->rng_states, &e->rng_ring, &e->rng_gJ, &e->flag, &e->rank, &e->scan_tmp,
+                    &e->P_deadage, &e->settletime, &e->timer, &e->P_Sprev, &e->P_zprev, &e->bottom, &e->P_Salt, &e->P_Temp, &e->S, &e->T, &e->counters, &e->ws_d, &e->ws_i, &e->orig, &e->ele_ok, &e->block_active, &e->count_slots, &e->rng_states, &e->rng_ring, &e->rng_gJ, &e->flag, &e->rank, &e->scan_tmp,
                     &e->vt_x, &e->vt_y, &e->vt_yp, &e->vt_sig};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
@@ -703,6 +722,14 @@ int lt_set_grid(lt_engine* e, const lt_grid* g) {
   TRY(dev_alloc(e, e->W, (size_t)e->rho_nodes * ws * LT_SLOTS * se));
   TRY(dev_alloc(e, e->Kh, (size_t)e->rho_nodes * ws * LT_SLOTS * se));
   TRY(dev_alloc(e, e->zeta, (size_t)e->rho_nodes * 4 * se));
+  if (needs_salt(e->cfg)) {
+    TRY(dev_alloc(e, e->S, (size_t)e->rho_nodes * us * LT_SLOTS * se));
+    HIPCHK(e, hipMemsetAsync(e->S.p, 0, e->S.bytes, e->stream));
+  }
+  if (e->cfg.SaltTempOn) {
+    TRY(dev_alloc(e, e->T, (size_t)e->rho_nodes * us * LT_SLOTS * se));
+    HIPCHK(e, hipMemsetAsync(e->T.p, 0, e->T.bytes, e->stream));
+  }
   HIPCHK(e, hipMemsetAsync(e->U.p, 0, e->U.bytes, e->stream));
   HIPCHK(e, hipMemsetAsync(e->V.p, 0, e->V.bytes, e->stream));
   HIPCHK(e, hipMemsetAsync(e->W.p, 0, e->W.bytes, e->stream));
@@ -795,6 +822,7 @@ int lt_set_habitat(lt_engine* e, const lt_habitat* h) {
 
 int lt_set_particles(lt_engine* e, const lt_particles* p) {
   if (!e || !p) return LT_ERR_ARG;
+  if (e->pre_valid) return fail(e, LT_ERR_STATE, "not between lt_count_draws and its lt_step");
   if (!e->have_grid) return fail(e, LT_ERR_STATE, "lt_set_particles before lt_set_grid");
   if (!e->par.p && !p->par) return fail(e, LT_ERR_ARG, "lt_set_particles: par is required");
   HIPCHK(e, hipSetDevice(e->device));
@@ -817,7 +845,7 @@ int lt_set_particles(lt_engine* e, const lt_particles* p) {
     TRY(upload(e, e->orig, e->perm.data(), n * 4));
     TRY(dev_alloc(e, e->ws_d, (size_t)WS_NDOUBLE * n * 8));
     TRY(dev_alloc(e, e->ws_i, n * 4));
-    if (e->cfg.HTurbOn || e->cfg.VTurbOn) {
+    if (e->cfg.HTurbOn || e->cfg.VTurbOn || (e->cfg.Behavior >= 1 && e->cfg.Behavior <= 5)) {
       TRY(dev_alloc(e, e->flag, (n + 1) * 4));
       TRY(dev_alloc(e, e->rank, (n + 1) * 4));
     }
@@ -847,6 +875,19 @@ int lt_set_particles(lt_engine* e, const lt_particles* p) {
   TRY(put_field<int32_t>(e, e->hitBottom, p->hitBottom, 1));
   TRY(put_field<int32_t>(e, e->hitLand, p->hitLand, 1));
   TRY(put_field<int32_t>(e, e->err_code, p->err_code, 1));
+  TRY(put_field<double>(e, e->timer, p->timer, 1));
+  TRY(put_field<double>(e, e->P_Sprev, p->P_Sprev, 1));
+  TRY(put_field<double>(e, e->P_zprev, p->P_zprev, 1));
+  {
+    const bool fresh = !e->bottom.p;
+    TRY(put_field<int32_t>(e, e->bottom, p->bottom, 1));
+    if (fresh && !p->bottom && e->cfg.Behavior == 7) {  // bottom = .TRUE., behavior_module.f90:113
+      std::vector<int32_t> ones((size_t)n, 1);
+      HIPCHK(e, hipMemcpy(e->bottom.p, ones.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    }
+  }
+  TRY(put_field<double>(e, e->P_Salt, p->P_Salt, 1));
+  TRY(put_field<double>(e, e->P_Temp, p->P_Temp, 1));
   HIPCHK(e, hipStreamSynchronize(e->stream));
   e->have_particles = true;
   return LT_OK;
@@ -872,15 +913,23 @@ int lt_get_particles(lt_engine* e, lt_particles* out) {
   TRY(get_field<int32_t>(e, e->hitBottom, out->hitBottom, 1));
   TRY(get_field<int32_t>(e, e->hitLand, out->hitLand, 1));
   TRY(get_field<int32_t>(e, e->err_code, out->err_code, 1));
+  TRY(get_field<double>(e, e->timer, out->timer, 1));
+  TRY(get_field<double>(e, e->P_Sprev, out->P_Sprev, 1));
+  TRY(get_field<double>(e, e->P_zprev, out->P_zprev, 1));
+  TRY(get_field<int32_t>(e, e->bottom, out->bottom, 1));
+  TRY(get_field<double>(e, e->P_Salt, out->P_Salt, 1));
+  TRY(get_field<double>(e, e->P_Temp, out->P_Temp, 1));
   return LT_OK;
 }
 
 int lt_set_slab(lt_engine* e, int32_t slot, const lt_slab* s) {
   if (!e || !s) return LT_ERR_ARG;
+  if (e->pre_valid) return fail(e, LT_ERR_STATE, "not between lt_count_draws and its lt_step");
   if (!e->have_grid) return fail(e, LT_ERR_STATE, "lt_set_slab before lt_set_grid");
   if (slot < 1 || slot > 3 || !s->zeta || !s->Uvel || !s->Vvel || !s->Wvel ||
-      (e->cfg.VTurbOn && !s->Kh))
-    return fail(e, LT_ERR_ARG, "lt_set_slab: bad arguments (Kh is required when VTurbOn)");
+      (e->cfg.VTurbOn && !s->Kh) || (needs_salt(e->cfg) && !s->salt) || (e->cfg.SaltTempOn && !s->temp))
+    return fail(e, LT_ERR_ARG, "lt_set_slab: bad arguments (Kh is required when VTurbOn, salt by behaviours "
+                               "4,5,7 and SaltTempOn, temp by SaltTempOn)");
   HIPCHK(e, hipSetDevice(e->device));
   int rc = (e->cfg.slab_storage == LT_SLAB_F32) ? set_slab_t<float>(e, slot, s)
                                                 : set_slab_t<double>(e, slot, s);
@@ -894,8 +943,9 @@ int lt_slab_prefetch(lt_engine* e, const lt_rom_record* r) {
   if (!e->have_grid) return fail(e, LT_ERR_STATE, "lt_slab_prefetch before lt_set_grid");
   if (e->prefetch_pending) return fail(e, LT_ERR_STATE, "lt_slab_prefetch: the previous record has not been committed");
   if ((r->dtype != LT_ROM_F64 && r->dtype != LT_ROM_F32) || !r->romZ || !r->romU || !r->romV || !r->romW ||
-      (e->cfg.VTurbOn && !r->romKH))
-    return fail(e, LT_ERR_ARG, "lt_slab_prefetch: bad arguments (romKH is required when VTurbOn)");
+      (e->cfg.VTurbOn && !r->romKH) || (needs_salt(e->cfg) && !r->romS) || (e->cfg.SaltTempOn && !r->romT))
+    return fail(e, LT_ERR_ARG, "lt_slab_prefetch: bad arguments (romKH is required when VTurbOn, romS by "
+                               "behaviours 4,5,7 and SaltTempOn, romT by SaltTempOn)");
   if ((long long)r->vi * r->uj != e->rho_nodes || (long long)r->ui * r->uj != e->u_nodes ||
       (long long)r->vi * r->vj != e->v_nodes || r->vi < 1 || r->uj < 1 || r->ui < 1 || r->vj < 1)
     return fail(e, LT_ERR_ARG, "lt_slab_prefetch: vi,uj,ui,vj do not match the node counts of lt_set_grid");
@@ -914,20 +964,22 @@ int lt_slab_prefetch(lt_engine* e, const lt_rom_record* r) {
   const int* mr = r->masked ? nullptr : (const int*)e->rmask.p;
   const int* mu = r->masked ? nullptr : (const int*)e->umask.p;
   const int* mv = r->masked ? nullptr : (const int*)e->vmask.p;
-  RomField f[5] = {
+  RomField f[7] = {
       {r->romZ, mr, &e->zeta, r->vi, r->uj, 1, w[0], w[1], w[2], w[3], 0},
       {r->romU, mu, &e->U, r->ui, r->uj, us, w[4], w[5], w[6], w[7], 0},
       {r->romV, mv, &e->V, r->vi, r->vj, us, w[8], w[9], w[10], w[11], 0},
-      {r->romW, mr, &e->W, r->vi, r->uj, ws, w[0], w[1], w[2], w[3], 0},
-      {r->romKH, mr, &e->Kh, r->vi, r->uj, ws, w[0], w[1], w[2], w[3], 0}};
-  const int nf = r->romKH ? 5 : 4;
+      {r->romW, mr, &e->W, r->vi, r->uj, ws, w[0], w[1], w[2], w[3], 0}};
+  int nf = 4;
+  if (r->romKH) f[nf++] = {r->romKH, mr, &e->Kh, r->vi, r->uj, ws, w[0], w[1], w[2], w[3], 0};
+  if (r->romS && e->S.p) f[nf++] = {r->romS, mr, &e->S, r->vi, r->uj, us, w[0], w[1], w[2], w[3], 0};
+  if (r->romT && e->T.p) f[nf++] = {r->romT, mr, &e->T, r->vi, r->uj, us, w[0], w[1], w[2], w[3], 0};
   size_t total = 0;
   for (int i = 0; i < nf; i++) { f[i].off = total; total += (f[i].count() + 3) & ~(size_t)3; }
   const size_t es = (r->dtype == LT_ROM_F32) ? 4 : 8;
   const size_t bytes = total * es;
   HIPCHK(e, hipSetDevice(e->device));
   // pinned double buffer and device staging sized for a whole-grid record of doubles
-  const size_t cap = ((size_t)e->rho_nodes * (1 + 2 * (size_t)ws) + ((size_t)e->u_nodes + e->v_nodes) * us + 32) * 8;
+  const size_t cap = ((size_t)e->rho_nodes * (1 + 2 * (size_t)ws + 2 * (size_t)us) + ((size_t)e->u_nodes + e->v_nodes) * us + 32) * 8;
   if (e->pin_bytes < cap) {
     for (int i = 0; i < 2; i++) {
       if (e->pin_busy[i]) HIPCHK(e, hipEventSynchronize(e->pin_free[i]));
@@ -983,6 +1035,7 @@ int lt_slab_prefetch(lt_engine* e, const lt_rom_record* r) {
 
 int lt_slab_commit(lt_engine* e, int32_t t_b, int32_t t_c, int32_t t_f) {
   if (!e) return LT_ERR_ARG;
+  if (e->pre_valid) return fail(e, LT_ERR_STATE, "not between lt_count_draws and its lt_step");
   if (t_b < 1 || t_b > 3 || t_c < 1 || t_c > 3 || t_f < 1 || t_f > 3 || t_b == t_c || t_c == t_f || t_b == t_f)
     return fail(e, LT_ERR_ARG, "time slots must be a permutation of 1..3");
   if (!e->prefetch_pending) return fail(e, LT_ERR_STATE, "lt_slab_commit without lt_slab_prefetch");
@@ -1011,6 +1064,7 @@ int lt_slab_commit(lt_engine* e, int32_t t_b, int32_t t_c, int32_t t_f) {
 
 int lt_set_time_slots(lt_engine* e, int32_t t_b, int32_t t_c, int32_t t_f) {
   if (!e) return LT_ERR_ARG;
+  if (e->pre_valid) return fail(e, LT_ERR_STATE, "not between lt_count_draws and its lt_step");
   if (t_b < 1 || t_b > 3 || t_c < 1 || t_c > 3 || t_f < 1 || t_f > 3)
     return fail(e, LT_ERR_ARG, "time slots must be 1..3");
   e->t_b = t_b; e->t_c = t_c; e->t_f = t_f;
@@ -1151,16 +1205,27 @@ int lt_count_active(lt_engine* e, const double* ix3, int64_t* n_active) {
 
 int lt_set_rng_window(lt_engine* e, int64_t active_before, int64_t active_total) {
   if (!e || active_before < 0 || active_total < active_before) return LT_ERR_ARG;
-  e->rng_before = active_before;
-  e->rng_total = active_total;
+  if (e->cfg.Behavior >= 1 && e->cfg.Behavior <= 5)
+    return fail(e, LT_ERR_ARG, "behaviours 1-5 draw a data-dependent number of deviates: use "
+                               "lt_count_draws / lt_set_rng_window_draws");
+  const int64_t D = (e->cfg.HTurbOn ? 4 : 0) + (e->cfg.VTurbOn ? 2 * (e->cfg.idt / 2) : 0);
+  e->rng_before = active_before * D;
+  e->rng_total = active_total * D;
   return LT_OK;
 }
 
-int lt_step(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32_t it) {
-  if (!e || !ex3 || !ix3) return LT_ERR_ARG;
-  TRY(ready_to_step(e));
-  HIPCHK(e, hipSetDevice(e->device));
-  StepParams P;
+int lt_set_rng_window_draws(lt_engine* e, int64_t draws_before, int64_t draws_total) {
+  if (!e || draws_before < 0 || draws_total < draws_before) return LT_ERR_ARG;
+  e->rng_before = draws_before;
+  e->rng_total = draws_total;
+  return LT_OK;
+}
+
+// The first part of a step: parameters, k_pre, the behaviour pre-pass and -- when anything
+// draws -- the prefix sum that places every tracked particle in the serial random stream.
+// Returns with e->stream idle and the shard's number of draws known.
+static int step_prepare(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32_t it) {
+  StepParams& P = e->pre_P;
   fill_params(e, P);
   P.ex0 = ex3[0]; P.ex1 = ex3[1]; P.ex2 = ex3[2];
   {
@@ -1179,20 +1244,25 @@ int lt_step(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32
   P.ix0 = ix3[0]; P.ix1 = ix3[1]; P.ix2 = ix3[2];
   P.p = p; P.it = it;
   HIPCHK(e, hipMemsetAsync(e->counters.p, 0, CNT_COUNT * sizeof(unsigned long long), e->stream));
-  unsigned blocks = (unsigned)((e->cfg.numpar + 255) / 256);
-  const bool turb = e->cfg.HTurbOn || e->cfg.VTurbOn;
-  e->stats.rng_draws = 0;
+  const unsigned blocks = (unsigned)((e->cfg.numpar + 255) / 256);
+  const bool beh_draws = e->cfg.Behavior >= 1 && e->cfg.Behavior <= 5;
+  const bool beh_pre = beh_draws || e->cfg.Behavior == 7 || e->cfg.SaltTempOn;
+  const bool draws = e->cfg.HTurbOn || e->cfg.VTurbOn || beh_draws;
+  e->pre_own = 0;
   if (blocks) {
-    const bool prof = e->prof_on && e->prof_used + 2 <= e->prof_ev.size();
     const bool f32 = e->cfg.slab_storage == LT_SLAB_F32;
     if (f32) hipLaunchKernelGGL((k_pre<float>), dim3(blocks), dim3(256), 0, e->stream, P);
     else hipLaunchKernelGGL((k_pre<double>), dim3(blocks), dim3(256), 0, e->stream, P);
-    if (turb) {
-      // rank of every tracked particle among the tracked ones, in REFERENCE order: the
-      // reference's generator is advanced particle by particle (LTRANS.f90:778,1087,1098)
+    if (beh_pre) {
+      if (f32) hipLaunchKernelGGL((k_beh_pre<float>), dim3(blocks), dim3(256), 0, e->stream, P);
+      else hipLaunchKernelGGL((k_beh_pre<double>), dim3(blocks), dim3(256), 0, e->stream, P);
+    }
+    if (draws) {
+      // offset of every tracked particle's first draw, in REFERENCE order: the reference's
+      // generator is advanced particle by particle (LTRANS.f90:778,1087,1098,1110)
       const int n = e->cfg.numpar;
       hipLaunchKernelGGL(k_flag_scatter, dim3(blocks), dim3(256), 0, e->stream, (const int*)e->ws_i.p,
-                         (const int*)e->orig.p, (int*)e->flag.p, n);
+                         (const int*)e->orig.p, (int*)e->flag.p, n, P.rng_draws);
       size_t need = 0;
       HIPCHK(e, hipcub::DeviceScan::ExclusiveSum(nullptr, need, (int*)e->flag.p, (int*)e->rank.p, n + 1, e->stream));
       if (need > e->scan_tmp_bytes) {
@@ -1202,29 +1272,73 @@ int lt_step(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32
       HIPCHK(e, hipMemsetAsync((int*)e->flag.p + n, 0, 4, e->stream));
       size_t tb = e->scan_tmp_bytes;
       HIPCHK(e, hipcub::DeviceScan::ExclusiveSum(e->scan_tmp.p, tb, (int*)e->flag.p, (int*)e->rank.p, n + 1, e->stream));
-      int own = 0;  // rank[n] = number of tracked particles of this shard
+      int own = 0;  // rank[n] = draws of this shard
       HIPCHK(e, hipMemcpyAsync(&own, (int*)e->rank.p + n, 4, hipMemcpyDeviceToHost, e->stream));
       HIPCHK(e, hipStreamSynchronize(e->stream));
+      e->pre_own = own;
+    }
+  }
+  HIPCHK(e, hipGetLastError());
+  e->pre_valid = true;
+  e->pre_sig[0] = ex3[0]; e->pre_sig[1] = ex3[1]; e->pre_sig[2] = ex3[2];
+  e->pre_sig[3] = ix3[0]; e->pre_sig[4] = ix3[1]; e->pre_sig[5] = ix3[2];
+  e->pre_sig[6] = (double)p; e->pre_sig[7] = (double)it;
+  return LT_OK;
+}
+
+static bool pre_matches(const lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32_t it) {
+  return e->pre_valid && e->pre_sig[0] == ex3[0] && e->pre_sig[1] == ex3[1] && e->pre_sig[2] == ex3[2] &&
+         e->pre_sig[3] == ix3[0] && e->pre_sig[4] == ix3[1] && e->pre_sig[5] == ix3[2] &&
+         e->pre_sig[6] == (double)p && e->pre_sig[7] == (double)it;
+}
+
+int lt_count_draws(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32_t it, int64_t* n_draws) {
+  if (!e || !ex3 || !ix3 || !n_draws) return LT_ERR_ARG;
+  TRY(ready_to_step(e));
+  HIPCHK(e, hipSetDevice(e->device));
+  if (e->pre_valid) return fail(e, LT_ERR_STATE, "lt_count_draws: the step counted before has not been run");
+  TRY(step_prepare(e, ex3, ix3, p, it));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  *n_draws = e->pre_own;
+  return LT_OK;
+}
+
+int lt_step(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32_t it) {
+  if (!e || !ex3 || !ix3) return LT_ERR_ARG;
+  TRY(ready_to_step(e));
+  HIPCHK(e, hipSetDevice(e->device));
+  if (e->pre_valid && !pre_matches(e, ex3, ix3, p, it))
+    return fail(e, LT_ERR_STATE, "lt_step: arguments differ from the preceding lt_count_draws");
+  if (!e->pre_valid) TRY(step_prepare(e, ex3, ix3, p, it));
+  e->pre_valid = false;
+  StepParams& P = e->pre_P;
+  const unsigned blocks = (unsigned)((e->cfg.numpar + 255) / 256);
+  const bool draws = e->cfg.HTurbOn || e->cfg.VTurbOn || (e->cfg.Behavior >= 1 && e->cfg.Behavior <= 5);
+  e->stats.rng_draws = 0;
+  if (blocks) {
+    const bool prof = e->prof_on && e->prof_used + 2 <= e->prof_ev.size();
+    const bool f32 = e->cfg.slab_storage == LT_SLAB_F32;
+    if (draws) {
+      const int64_t own = e->pre_own;
       const int64_t before = (e->rng_total >= 0) ? e->rng_before : 0;
       const int64_t total = (e->rng_total >= 0) ? e->rng_total : own;
-      if (before + own > total) return fail(e, LT_ERR_ARG, "lt_set_rng_window: window smaller than the shard's active count");
-      const uint64_t D = (uint64_t)P.rng_draws;
+      if (before + own > total) return fail(e, LT_ERR_ARG, "lt_set_rng_window: window smaller than the shard's draws");
       if (!e->rng_ready) TRY(rng_init_device(e));
-      const uint64_t base = e->rng_cur + D * (uint64_t)before;
+      const uint64_t base = e->rng_cur + (uint64_t)before;
       if (own > 0) {
-        // everything earlier on e->stream has completed (the synchronize above), so the
+        // everything earlier on e->stream has completed (step_prepare synchronised), so the
         // generators may overwrite old ring blocks while k_rk runs on the main stream
-        TRY(rng_ensure(e, base, base + D * (uint64_t)own, e->rng_stream));
+        TRY(rng_ensure(e, base, base + (uint64_t)own, e->rng_stream));
         HIPCHK(e, hipEventRecord(e->rng_done, e->rng_stream));
         e->rng_pending = true;
       }
       P.rng_ring = (const uint32_t*)e->rng_ring.p;
       P.rng_mask = (unsigned long long)e->rng_R * RNG_S - 1ull;
       P.rng_base = base;
-      e->rng_cur += D * (uint64_t)total;
+      e->rng_cur += (uint64_t)total;
       e->rng_total = -1;
       e->rng_before = 0;
-      e->stats.rng_draws = (int64_t)(D * (uint64_t)own);
+      e->stats.rng_draws = own;
     }
     // lt_profile_* times the dominant kernel of the configuration: k_vturb when
     // vertical turbulence is on, k_rk otherwise

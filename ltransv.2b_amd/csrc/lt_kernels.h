@@ -43,8 +43,13 @@ enum { pX = 0, pY, pZ, pnX, pnY, pnZ, ppX, ppY, ppZ, pStatus, pDOB, pAge, pLifes
 
 // per-step workspace columns (doubles, SoA stride numpar) and the flag word
 enum { WS_PDEPTH = 0, WS_COSA, WS_SINA, WS_ZETA0, WS_ZETA1, WS_ZETA2, WS_PZ0, WS_PZ1, WS_PZ2,
-       WS_ZPAR, WS_SUMU, WS_SUMV, WS_SUMW, WS_TURBV, WS_NDOUBLE };
-enum { FL_ACT = 1, FL_KEEP_PN = 2, FL_SLOW = 4, FL_VT_YPCFAIL = 16, FL_VT_SIGERR = 32, FL_ERR_SHIFT = 8 };
+       WS_ZPAR, WS_SUMU, WS_SUMV, WS_SUMW, WS_TURBV,
+       WS_PS, WS_BTHR1, WS_BTHR2,  // behaviour: salinity at the particle, thresholds of the two draws
+       WS_NDOUBLE };
+// FL_BEH_DIRECTED / FL_BEH_RANDOM: what k_beh_pre decided the behaviour will draw (one deviate
+// compared with WS_BTHR1; then two deviates, the first compared with WS_BTHR2)
+enum { FL_ACT = 1, FL_KEEP_PN = 2, FL_SLOW = 4, FL_VT_YPCFAIL = 16, FL_VT_SIGERR = 32,
+       FL_BEH_DIRECTED = 64, FL_BEH_RANDOM = 128, FL_ERR_SHIFT = 8 };
 
 template <typename SlabT> struct SlabTraits;
 template <> struct SlabTraits<float> { using zeta4 = float4; };
@@ -985,6 +990,174 @@ __global__ __launch_bounds__(256) void k_pre(const StepParams P) {
   if (threadIdx.x == 0) P.block_active[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
+// WCTS_ITPI (hydrodynamic_module.f90:2577-2688) of a rho-grid field with us levels (salinity,
+// temperature) at the start-of-step position, version 4 = (vb + 4 vc + vf)/6: straight
+// transcription (used once or twice per particle-step, only with behaviours 4,5,7 / SaltTempOn)
+template <typename SlabT>
+LT_DEV double wcts_itpi_rho(const StepParams& P, const double* lev, const Column& C, int4 rn,
+                            const QuadWeights& w, const SlabT* F, int deplvl) {
+  double Pv[3];
+#pragma unroll 1
+  for (int s = 0; s < 3; s++) {
+    const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
+    double az[4], av[4];
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+      az[l] = level_z(lev, deplvl + l, C.zeta[s], C.h, P.hc, P.Vtransform);
+      av[l] = apply_interp(w, fld(F, rn.x, P.us, deplvl + l, ps), fld(F, rn.y, P.us, deplvl + l, ps),
+                           fld(F, rn.z, P.us, deplvl + l, ps), fld(F, rn.w, P.us, deplvl + l, ps));
+    }
+    int dummy = 0;
+    Pv[s] = spline4_eval(az, av, C.Pz[s], dummy);
+  }
+  double e1 = Pv[0], e2 = Pv[1], e3 = Pv[2];
+  if (P.p == 1) { e2 = Pv[0]; e3 = Pv[1]; }
+  const double vb = polintd3(P.ex0, P.ex1, P.ex2, e1, e2, e3, P.ix0);
+  const double vc = polintd3(P.ex0, P.ex1, P.ex2, e1, e2, e3, P.ix1);
+  const double vf = polintd3(P.ex0, P.ex1, P.ex2, e1, e2, e3, P.ix2);
+  return (vb + vc * 4 + vf) / 6.0;
+}
+
+// Everything of behave() (behavior_module.f90:181-551) and of the SaltTempOn block
+// (LTRANS.f90:1062-1076) that does not depend on the random deviates or on the RK4 result:
+// swimming speed, stage changes, the C. ariakensis timer, the salinity at the particle, the
+// salinity-gradient cue, and with them WHAT the behaviour will draw (none / one directed
+// deviate / two random-swimming deviates / both), which the draw offsets of all later
+// particles depend on.  k_post consumes the deviates and finishes the behaviour.
+template <typename SlabT>
+__global__ __launch_bounds__(256) void k_beh_pre(const StepParams P) {
+  __shared__ double lev[6 * LT_LEV_STRIDE];
+  for (int i = threadIdx.x; i < 6 * LT_LEV_STRIDE; i += blockDim.x) lev[i] = P.lev[i];
+  __syncthreads();
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= P.numpar) return;
+  int fl = P.ws_i[n];
+  if (!(fl & FL_ACT)) return;
+  const size_t N = (size_t)P.numpar;
+  double* wsd = P.ws_d + n;
+  const double X = P.par[(size_t)pX * N + n], Y = P.par[(size_t)pY * N + n];
+  const double P_age = P.par[(size_t)pAge * N + n];
+  const double Zpar = wsd[(size_t)WS_ZPAR * N];
+  Column C;
+  C.h = -1.0 * wsd[(size_t)WS_PDEPTH * N];
+#pragma unroll
+  for (int s = 0; s < 3; s++) {
+    C.zeta[s] = wsd[(size_t)(WS_ZETA0 + s) * N];
+    C.Pz[s] = wsd[(size_t)(WS_PZ0 + s) * N];
+  }
+  const double P_depth = -C.h, P_zc = C.Pz[1], P_zetac = C.zeta[1];
+  int beh = (P.Behavior != 0) ? P.P_behave[n] : 0;
+  double tim = 0.0;
+  if (P.Behavior != 0) {
+    // :214-215 swimming speed at the current age
+    double sw3 = P.P_swim[n + 2 * N];
+    bool dirty = false;
+    if (P_age >= P.swimstart) { sw3 = P.P_swim[n] * P_age + P.P_swim[n + N]; dirty = true; }
+    if (P_age >= P.P_pediage[n]) { sw3 = P.swimfast; dirty = true; }
+    if (dirty) P.P_swim[n + 2 * N] = sw3;
+    // :220-229 oyster larvae: pediveliger stage, timer
+    if (beh == 4 || beh == 5) {
+      if (P_age >= P.P_pediage[n] && P_age < P.P_deadage[n]) { beh = 2; P.P_behave[n] = 2; }
+      tim = P.timer[n];
+      tim = (0.0 > tim - (double)P.dt) ? 0.0 : tim - (double)P.dt;
+      P.timer[n] = tim;
+    }
+  }
+  // salinity (and temperature) at the particle :233-246, LTRANS.f90:1062-1076
+  const bool want_S = (beh == 4) || (beh == 5 && tim == 0.0) || (beh == 7);
+  double P_S = 0.0;
+  if (want_S || P.SaltTempOn) {
+    const int4 rn = P.RE[P.P_r_element[n] - 1];
+    const Quad q = load_quad_rho(P.rnode, rn);
+    const QuadWeights w = quad_weights(X, Y, q.x, q.y);
+    const int deplvl = level_window(lev, P.us, Zpar, C.zeta[0], C.zeta[1], C.zeta[2], C.h, P.hc, P.Vtransform);
+    P_S = wcts_itpi_rho<SlabT>(P, lev, C, rn, w, (const SlabT*)P.S, deplvl);
+    if (P.SaltTempOn) {
+      P.P_Salt[n] = P_S;
+      P.P_Temp[n] = wcts_itpi_rho<SlabT>(P, lev, C, rn, w, (const SlabT*)P.T, deplvl);
+    }
+  }
+  bool directed = false, random = false;
+  double thr1 = 0.0, thr2 = 0.0;
+  // TYPE 1 :256-283
+  if (beh == 1) {
+    random = true;
+    thr2 = (P_zc < (P_zetac - 1.0)) ? (double)0.80f : 0.5;
+  }
+  // TYPE 2 :287-313 (also C. ariakensis while its timer runs)
+  if (beh == 2 || (beh == 5 && tim > 0.0)) {
+    random = true;
+    thr2 = (P_zc > (P_depth + 1.0)) ? (double)0.20f : 0.5;
+  }
+  // TYPE 3 :316-353
+  if (beh == 3) {
+    const double daytime = P.ix2 / 86400.0;
+    const double dtime = (daytime - trunc(daytime)) * 24.0;
+    double E0 = 0.0;
+    if (dtime > P.twistart && dtime < P.twiend) {
+      const double tst = (dtime - P.twistart) * 3600.0;
+      E0 = P.Em * sin(P.PI * tst / (P.daylength * 3600.0)) * sin(P.PI * tst / (P.daylength * 3600.0));
+    }
+    const double P_light = E0 * exp(P.Kd * P_zc);
+    if (P_light < P.thresh) { random = true; thr2 = 0.5; }
+    if (P_light > P.thresh) { random = true; thr2 = (double)0.20f; }
+  }
+  // TYPES 4 and 5 :357-461: the salinity-gradient cue
+  if (beh == 4 || (beh == 5 && tim == 0.0)) {
+    double Sprev = P.P_Sprev[n], zprev = P.P_zprev[n];
+    if (P.it == 1) { Sprev = P_S; zprev = P_zc; }
+    double Sslope = 0.0;
+    const double deltaS = Sprev - P_S, deltaz = zprev - P_zc;
+    if (P.it > 1) Sslope = deltaS / deltaz;
+    bool btest = false;
+    if (fabs(Sslope) > P.Sgradient) {
+      directed = true;
+      btest = true;
+      if (beh == 4) {
+        thr1 = (double)0.80f;
+      } else {
+        thr1 = (double)0.20f;
+        tim = 2.0 * 3600.0;
+        if (P_age < (double)(3.5f * 24.f * 3600.f)) { btest = false; tim = 0.; }
+        P.timer[n] = tim;
+      }
+    }
+    if (!btest) {
+      random = true;
+      double sw;
+      if (beh == 4) {
+        if (P_age < (double)(1.5f * 24.f * 3600.f)) sw = (double)0.1f;
+        else if (P_age < (double)(5.f * 24.f * 3600.f)) sw = (double)0.49f;
+        else if (P_age < (double)(8.f * 24.f * 3600.f)) sw = (double)0.50f;
+        else {
+          const double switchslope = ((double)0.50f - (double)0.517f) / (8.0 * 24.0 * 3600.0 - P.P_pediage[n]);
+          sw = switchslope * P_age + (double)0.50f - switchslope * 8.0 * 24.0 * 3600.0;
+          if (P_zc < P_depth + 1.) sw = 0.5;
+        }
+        thr2 = 1 - sw;  // :393 dev1 .GT. (1-switch)
+      } else {
+        sw = (double)0.495f;
+        if (P_age < (double)(1.5f * 24.f * 3600.f)) sw = (double)0.9f;
+        if (P_age > (double)(2.0f * 24.f * 3600.f) && P_age < (double)(3.5f * 24.f * 3600.f)) {
+          const double switchslope =
+              ((double)0.3f - (double)0.495f) / (2.0 * 24.0 * 3600.0 - (double)3.5f * 24.0 * 3600.0);
+          sw = switchslope * P_age + (double)0.3f - switchslope * 2.0 * 24.0 * 3600.0;
+        }
+        thr2 = sw;
+      }
+    }
+    P.P_Sprev[n] = P_S;  // :404-405, :461-462
+    P.P_zprev[n] = P_zc;
+  }
+  // TYPE 7 :497-500 first iteration (the rest needs the RK4 currents: k_post)
+  if (beh == 7 && P.it == 1) P.P_Sprev[n] = P_S;
+  wsd[(size_t)WS_PS * N] = P_S;
+  wsd[(size_t)WS_BTHR1 * N] = thr1;
+  wsd[(size_t)WS_BTHR2 * N] = thr2;
+  fl |= (directed ? FL_BEH_DIRECTED : 0) | (random ? FL_BEH_RANDOM : 0);
+  P.ws_i[n] = fl;
+}
+
 template <typename SlabT, int VT, int WAVES_PER_SIMD>
 __global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_rk(const StepParams P) {
   __shared__ double lev[6 * LT_LEV_STRIDE];
@@ -1206,6 +1379,11 @@ LT_DEV double draw_real3(const StepParams& P, unsigned long long idx) {
   return ((double)y + 0.5) / 4294967296.0;
 }
 // norm(), norm_module.f90:25-39: two uniforms per deviate, cos branch only
+// genrand_real1 (random_module.f90:213-219): [0,1]
+LT_DEV double draw_real1(const StepParams& P, unsigned long long idx) {
+  const uint32_t y = ltmt_temper(P.rng_ring[idx & P.rng_mask]);
+  return (double)y / 4294967295.0;
+}
 LT_DEV double draw_norm(const StepParams& P, unsigned long long idx) {
   const double dev1 = draw_real3(P, idx), dev2 = draw_real3(P, idx + 1);
   return sqrt(-2.0 * log(dev1)) * cos(2.0 * P.PI * dev2);
@@ -1600,7 +1778,7 @@ __global__ __launch_bounds__(256) void k_vt_walk(const StepParams P) {
   const double background = (double)1.0E-6f, deltat = 2.0;
   const int loop = P.idt / (int)deltat;
   // this particle's window of the serial stream: HTurb's 4 draws come first (:1087,1098)
-  unsigned long long di = P.rng_base + (unsigned long long)P.rng_draws * (unsigned long long)P.rank[P.orig[n]] +
+  unsigned long long di = P.rng_base + (unsigned long long)(unsigned)P.rank[P.orig[n]] +
                           (P.HTurbOn ? 4ull : 0ull);
   double ParZc = P_zc;
   int il = 1;
@@ -1695,15 +1873,16 @@ __global__ __launch_bounds__(256) void k_post(const StepParams P) {
       // HTurb, hor_turb_module.f90:29-50: X deviate before Y; VTurb's TurbV from k_vturb
       double TurbHx = 0.0, TurbHy = 0.0, TurbV = 0.0;
       if (P.HTurbOn) {
-        const unsigned long long di = P.rng_base + (unsigned long long)P.rng_draws * (unsigned long long)P.rank[P.orig[n]];
+        const unsigned long long di = P.rng_base + (unsigned long long)(unsigned)P.rank[P.orig[n]];
         const double devX = draw_norm(P, di), devY = draw_norm(P, di + 2);
         const double amp = sqrt(2.0 / 1.0 * P.ConstantHTurb * P.idt);  // (2/r*KM*idt)**0.5
         TurbHx = devX * amp;
         TurbHy = devY * amp;
       }
       if (P.VTurbOn) TurbV = wsd[(size_t)WS_TURBV * N];
-      // behave (types 0 and 6), behavior_module.f90:181-551
-      double ZBehav = 0.0;
+      // behave, behavior_module.f90:181-551 (the part that needs the deviates and the currents)
+      double ZBehav = 0.0, XBehav = 0.0, YBehav = 0.0;
+      bool bott = false;
       if (P.Behavior != 0) {
         const size_t np = (size_t)P.numpar;
         double sw3 = P.P_swim[n + 2 * np];
@@ -1712,8 +1891,55 @@ __global__ __launch_bounds__(256) void k_post(const StepParams P) {
         if (age >= P.P_pediage[n]) { sw3 = P.swimfast; sw_dirty = true; }
         if (sw_dirty) P.P_swim[n + 2 * np] = sw3;
         double parBehav = 0.0;
-        if (P.P_behave[n] == 6) parBehav = (age >= P.swimstart) ? P.sink : sw3;
+        const int beh = P.P_behave[n];
+        // types 1-5: the deviates k_beh_pre announced, after this particle's turbulence draws
+        if (fl & (FL_BEH_DIRECTED | FL_BEH_RANDOM)) {
+          unsigned long long db = P.rng_base + (unsigned long long)(unsigned)P.rank[P.orig[n]] +
+                                  (unsigned long long)P.rng_draws;
+          if (fl & FL_BEH_DIRECTED) {  // :371-377, :425-437
+            const double dev1 = draw_real1(P, db);
+            db += 1;
+            const double negpos = (dev1 > wsd[(size_t)WS_BTHR1 * N]) ? -1.0 : 1.0;
+            parBehav = negpos * sw3;
+          }
+          if (fl & FL_BEH_RANDOM) {
+            const double dev1 = draw_real1(P, db), devB = draw_real1(P, db + 1);
+            const double negpos = (dev1 > wsd[(size_t)WS_BTHR2 * N]) ? -1.0 : 1.0;
+            parBehav = negpos * devB * sw3;
+          }
+        }
+        if (beh == 6) parBehav = (age >= P.swimstart) ? P.sink : sw3;
         ZBehav = parBehav * P.idt;
+        // TYPE 7 :495-547 tidal stream transport
+        if (beh == 7) {
+          const double P_S = wsd[(size_t)WS_PS * N];
+          const double cu = P_U * cosA - P_V * sinA, cv = P_U * sinA + P_V * cosA;
+          const double currentspeed = sqrt(cu * cu + cv * cv);
+          int onb = P.bottom[n];
+          if (onb) {
+            if (P.P_Sprev[n] < P_S) {
+              onb = 0;
+              ZBehav = P_depth + P.Swimdepth;
+            } else {
+              ZBehav = -9999;
+            }
+          } else {
+            if (currentspeed > (double)0.05f) {
+              const double Hdistance = P.Hswimspeed * P.idt;
+              const double theta = atan(cv / cu);
+              if (cu > 0.0) { XBehav = Hdistance * cos(theta); YBehav = Hdistance * sin(theta); }
+              if (cu < 0.0) { XBehav = -1.0 * Hdistance * cos(theta); YBehav = -1.0 * Hdistance * sin(theta); }
+              if (cu == 0 && cv >= 0.0) { XBehav = 0.0; YBehav = Hdistance; }
+              if (cu == 0 && cv <= 0.0) { XBehav = 0.0; YBehav = -1.0 * Hdistance; }
+              ZBehav = P_depth + P.Swimdepth;
+            } else {
+              ZBehav = -9999;
+              onb = 1;
+            }
+          }
+          P.bottom[n] = onb;
+          bott = onb != 0;
+        }
       }
       // new position, vertical reflection :1128-1176
       double newXpos = X + AdvectX + TurbHx;
@@ -1729,6 +1955,13 @@ __global__ __launch_bounds__(256) void k_post(const StepParams P) {
         if (P.TrackCollisions) P.hitBottom[n] += 1;
       }
       newZpos = newZpos + ZBehav;
+      if (P.Behavior == 7) {  // :1148-1164
+        if (bott) {
+          newXpos = X; newYpos = Y; newZpos = P_depth;
+        } else {
+          newXpos = newXpos + XBehav; newYpos = newYpos + YBehav; newZpos = P_depth + P.Swimdepth;
+        }
+      }
       if (newZpos > P_zetac) newZpos = P_zetac - (double)0.000001f;
       if (newZpos < P_depth) {
         newZpos = P_depth + (double)0.000001f;
@@ -1928,10 +2161,14 @@ __global__ void k_pack_positions(const double* __restrict__ par, const int* __re
 }
 
 // act flag of every particle in REFERENCE order (input of the rank scan)
+// (the value scanned is the number of deviates the particle will draw: the turbulence draws
+// plus what k_beh_pre decided for the behaviour)
 __global__ void k_flag_scatter(const int* __restrict__ ws_i, const int* __restrict__ orig,
-                               int* __restrict__ flag, int numpar) {
+                               int* __restrict__ flag, int numpar, int turb_draws) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < numpar) flag[orig[i]] = (ws_i[i] & FL_ACT) ? 1 : 0;
+  if (i >= numpar) return;
+  const int f = ws_i[i];
+  flag[orig[i]] = (f & FL_ACT) ? turb_draws + ((f & FL_BEH_DIRECTED) ? 1 : 0) + ((f & FL_BEH_RANDOM) ? 2 : 0) : 0;
 }
 
 // number of particles that pass the gates and the first setEle (= draw RNG)

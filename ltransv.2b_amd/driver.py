@@ -33,7 +33,8 @@ class LtransRun:
         """initHydro (hydrodynamic_module.f90:661-1049): first three records."""
         for slot in (1, 2, 3):
             r = self.record_fn(slot - 1)
-            self.e.set_slab(slot, r["zeta"], r["Uvel"], r["Vvel"], r["Wvel"], r.get("Kh"))
+            self.e.set_slab(slot, r["zeta"], r["Uvel"], r["Vvel"], r["Wvel"], r.get("Kh"),
+                            r.get("salt"), r.get("temp"))
         self.t_b, self.t_c, self.t_f = 1, 2, 3
         self.stepf = 3
         self.e.set_time_slots(1, 2, 3)
@@ -51,7 +52,8 @@ class LtransRun:
             self._prefetched = None
             return
         r = self.record_fn(self.stepf - 1)
-        self.e.set_slab(self.t_f, r["zeta"], r["Uvel"], r["Vvel"], r["Wvel"], r.get("Kh"))
+        self.e.set_slab(self.t_f, r["zeta"], r["Uvel"], r["Vvel"], r["Wvel"], r.get("Kh"),
+                        r.get("salt"), r.get("temp"))
         self.e.set_time_slots(self.t_b, self.t_c, self.t_f)
 
     def prefetch(self, r):

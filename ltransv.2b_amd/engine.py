@@ -197,7 +197,7 @@ class Engine:
             raise KeyError(f"unknown particle arrays {sorted(unknown)}")
         self._check(self._fn["set_particles"](self._h, C.byref(s)), "set_particles")
 
-    def set_slab(self, slot, zeta, Uvel, Vvel, Wvel, Kh=None):
+    def set_slab(self, slot, zeta, Uvel, Vvel, Wvel, Kh=None, salt=None, temp=None):
         """One masked time record into slot 1..3 (updateHydro, hydrodynamic_module.f90:1371)."""
         g = self._grid
         if g is None:
@@ -217,6 +217,14 @@ class Engine:
             if k.size != g["rho_nodes"] * self.ws:
                 raise ValueError("Kh extent does not match the grid")
             s.Kh = _dp(k)
+        st = []
+        for name, a in (("salt", salt), ("temp", temp)):
+            if a is not None:
+                a = _fcol(a, np.float64)
+                if a.size != g["rho_nodes"] * self.us:
+                    raise ValueError(f"{name} extent does not match the grid")
+                st.append(a)
+                setattr(s, name, _dp(a))
         self._check(self._fn["set_slab"](self._h, int(slot), C.byref(s)), "set_slab")
 
     def slab_prefetch(self, rom, dims, masked=False, window=None):
@@ -228,7 +236,8 @@ class Engine:
         if dt not in (np.dtype(np.float64), np.dtype(np.float32)):
             raise ValueError("rom arrays must be float64 or float32")
         shapes = {"romZ": (vi, uj), "romU": (ui, uj, self.us), "romV": (vi, vj, self.us),
-                  "romW": (vi, uj, self.ws), "romKH": (vi, uj, self.ws)}
+                  "romW": (vi, uj, self.ws), "romKH": (vi, uj, self.ws),
+                  "romS": (vi, uj, self.us), "romT": (vi, uj, self.us)}
         r = abi.LtRomRecord()
         r.struct_size = C.sizeof(abi.LtRomRecord)
         r.dtype = abi.LT_ROM_F32 if dt == np.dtype(np.float32) else abi.LT_ROM_F64
@@ -272,6 +281,20 @@ class Engine:
         n = C.c_int64()
         self._check(self._fn["count_active"](self._h, _dp(ix), C.byref(n)), "count_active")
         return n.value
+
+    def count_draws(self, ex, ix, p, it):
+        """lt_count_draws: runs the first part of the step; the next update_particles with
+        the same arguments continues from there."""
+        ex = np.ascontiguousarray(ex, dtype=np.float64)
+        ix = np.ascontiguousarray(ix, dtype=np.float64)
+        n = C.c_int64(0)
+        self._check(self._fn["count_draws"](self._h, _dp(ex), _dp(ix), int(p), int(it), C.byref(n)),
+                    "count_draws")
+        return int(n.value)
+
+    def set_rng_window_draws(self, draws_before, draws_total):
+        self._check(self._fn["set_rng_window_draws"](self._h, C.c_int64(int(draws_before)),
+                                                     C.c_int64(int(draws_total))), "set_rng_window_draws")
 
     def set_rng_window(self, active_before, active_total):
         self._check(self._fn["set_rng_window"](self._h, C.c_int64(int(active_before)),

@@ -170,6 +170,9 @@ program ltrans_hip_driver
   cfg%OpenOceanBoundary = merge(1, 0, OpenOceanBoundary); cfg%mortality = merge(1, 0, mortality)
   cfg%deadage = deadage; cfg%pediage = pediage; cfg%swimstart = swimstart
   cfg%swimslow = swimslow; cfg%swimfast = swimfast; cfg%sink = sink; cfg%Swimdepth = Swimdepth
+  cfg%Sgradient = Sgradient; cfg%Hswimspeed = Hswimspeed
+  cfg%twistart = twistart; cfg%twiend = twiend; cfg%daylength = daylength
+  cfg%Em = Em; cfg%Kd = Kd; cfg%thresh = thresh
   cfg%settlementon = merge(1, 0, settlementon); cfg%holesExist = merge(1, 0, holesExist)
   cfg%PI = PI; cfg%seed = seed; cfg%ErrorFlag = ErrorFlag
   cfg%SaltTempOn = merge(1, 0, SaltTempOn); cfg%TrackCollisions = merge(1, 0, TrackCollisions)
@@ -199,11 +202,15 @@ program ltrans_hip_driver
   pp%settle = c_loc(settle); pp%settletime = c_loc(settletime)
   pp%endpoly = c_loc(endpoly); pp%hitBottom = c_loc(hitBottom); pp%hitLand = c_loc(hitLand)
   pp%err_code = c_loc(err_code)
+  ! the case file carries behaviours 0 and 6 only: no salinity-cue state
+  pp%timer = c_null_ptr; pp%P_Sprev = c_null_ptr; pp%P_zprev = c_null_ptr; pp%bottom = c_null_ptr
+  pp%P_Salt = c_null_ptr; pp%P_Temp = c_null_ptr
   call lt_check(lt_set_particles(eng, pp), eng, 'lt_set_particles')
 
   ! ---- initHydro: first three records into slots 1,2,3 (hydrodynamic_module.f90:741-743)
   slab%zeta = c_loc(zeta); slab%Uvel = c_loc(Uvel); slab%Vvel = c_loc(Vvel)
   slab%Wvel = c_loc(Wvel); slab%Kh = c_loc(Kh)
+  slab%salt = c_null_ptr; slab%temp = c_null_ptr
   do n = 1, 3
     read(2) zeta, Uvel, Vvel, Wvel, Kh
     call lt_check(lt_set_slab(eng, n, slab), eng, 'lt_set_slab')

@@ -13,7 +13,7 @@ module ltrans_hip
   implicit none
   public
 
-  integer(c_int), parameter :: LT_ABI_EXPECTED = 1
+  integer(c_int), parameter :: LT_ABI_EXPECTED = 2
   integer(c_int), parameter :: LT_OK = 0
   integer(c_int), parameter :: LT_SLAB_F32 = 0, LT_SLAB_F64 = 1
 
@@ -29,6 +29,8 @@ module ltrans_hip
     real(c_double)     :: ConstantHTurb
     integer(c_int32_t) :: Behavior, OpenOceanBoundary, mortality
     real(c_double)     :: deadage, pediage, swimstart, swimslow, swimfast, sink, Swimdepth
+    real(c_double)     :: Sgradient, Hswimspeed
+    real(c_double)     :: twistart, twiend, daylength, Em, Kd, thresh
     integer(c_int32_t) :: settlementon, holesExist
     real(c_double)     :: PI
     integer(c_int32_t) :: seed, ErrorFlag, SaltTempOn, TrackCollisions, FreeSlip
@@ -63,10 +65,12 @@ module ltrans_hip
     type(c_ptr) :: P_swim, P_pediage, P_deadage
     type(c_ptr) :: settle, settletime
     type(c_ptr) :: endpoly, hitBottom, hitLand, err_code
+    type(c_ptr) :: timer, P_Sprev, P_zprev, bottom
+    type(c_ptr) :: P_Salt, P_Temp
   end type lt_particles
 
   type, bind(C) :: lt_slab
-    type(c_ptr) :: zeta, Uvel, Vvel, Wvel, Kh
+    type(c_ptr) :: zeta, Uvel, Vvel, Wvel, Kh, salt, temp
   end type lt_slab
 
   ! a ROMS record as updateHydro holds it after NF90_GET_VAR, before the mask multiply
@@ -77,7 +81,7 @@ module ltrans_hip
     integer(c_int32_t) :: vi, uj, ui, vj
     integer(c_int32_t) :: masked, has_window
     integer(c_int32_t) :: window(12)
-    type(c_ptr) :: romZ, romU, romV, romW, romKH
+    type(c_ptr) :: romZ, romU, romV, romW, romKH, romS, romT
   end type lt_rom_record
 
   type, bind(C) :: lt_step_stats
@@ -181,6 +185,20 @@ module ltrans_hip
       integer(c_int64_t), intent(out) :: n_active
       integer(c_int) :: rc
     end function
+    function lt_count_draws(engine, ex, ix, p, it, n_draws) bind(C, name="lt_count_draws") result(rc)
+      import :: c_int, c_int32_t, c_int64_t, c_double, c_ptr
+      type(c_ptr), value :: engine
+      real(c_double), intent(in) :: ex(3), ix(3)
+      integer(c_int32_t), value :: p, it
+      integer(c_int64_t), intent(out) :: n_draws
+      integer(c_int) :: rc
+    end function
+    function lt_set_rng_window_draws(engine, draws_before, draws_total) bind(C, name="lt_set_rng_window_draws") result(rc)
+      import :: c_int, c_int64_t, c_ptr
+      type(c_ptr), value :: engine
+      integer(c_int64_t), value :: draws_before, draws_total
+      integer(c_int) :: rc
+    end function
     function lt_set_rng_window(engine, active_before, active_total) &
         bind(C, name="lt_set_rng_window") result(rc)
       import :: c_int, c_int64_t, c_ptr
@@ -227,6 +245,9 @@ contains
     cfg%Behavior = 0; cfg%OpenOceanBoundary = 0; cfg%mortality = 0
     cfg%deadage = 367200.d0; cfg%pediage = 302400.d0; cfg%swimstart = 0.d0
     cfg%swimslow = 0.005d0; cfg%swimfast = 0.005d0; cfg%sink = -0.0003d0; cfg%Swimdepth = 2.d0
+    cfg%Sgradient = 1.0d0; cfg%Hswimspeed = 0.9d0
+    cfg%twistart = 4.801821d0; cfg%twiend = 19.19956d0; cfg%daylength = 14.39774d0
+    cfg%Em = 1814.328d0; cfg%Kd = 1.07d0; cfg%thresh = 0.0166d0
     cfg%settlementon = 0; cfg%holesExist = 0
     cfg%PI = 3.14159265358979d0
     cfg%seed = 9; cfg%ErrorFlag = 1; cfg%SaltTempOn = 0; cfg%TrackCollisions = 0; cfg%FreeSlip = 0

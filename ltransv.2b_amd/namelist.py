@@ -79,7 +79,8 @@ _MAP = {
     "hydroparam": ["us", "ws", "hc", "z0", "Vtransform"],
     "turbparam": ["HTurbOn", "VTurbOn", "ConstantHTurb"],
     "behavparam": ["Behavior", "OpenOceanBoundary", "mortality", "deadage", "pediage",
-                   "swimstart", "swimslow", "swimfast", "sink", "Swimdepth"],
+                   "swimstart", "swimslow", "swimfast", "sink", "Swimdepth", "Sgradient", "Hswimspeed"],
+    "dvmparam": ["twistart", "twiend", "daylength", "Em", "Kd", "thresh"],
     "settleparam": ["settlementon", "holesExist"],
     "convparam": ["PI"],
     "other": ["seed", "ErrorFlag", "SaltTempOn", "TrackCollisions", "FreeSlip"],

@@ -282,15 +282,23 @@ def make_record(g, geo, r, dt=3600.0, with_kh=True, drift=(0.0, 0.0), raw=None):
     if with_kh:
         K = 1.0e-5 + 1.0e-2 * 4.0 * (-sw) * (1.0 + sw) * \
             (0.55 + 0.45 * np.sin(2 * np.pi * (xr + 0.25 * t / 44714.0)) * np.cos(2 * np.pi * yr))[:, :, None]
+    # salinity with a halocline near -6 m that moves with the tide (up to ~2 psu/m: above the
+    # Sgradient cue of behaviours 4/5 in places, below it elsewhere); temperature
+    zr = (g["h"][:, :, None] * sr)                       # approximate depth of the rho levels
+    hal = -6.0 + 2.0 * np.sin(2 * np.pi * (xr + t / 44714.0))[:, :, None]
+    S = 30.0 + 4.0 * np.tanh((hal - zr) / 2.0) + 1.5 * (np.sin(2 * np.pi * xr) * np.cos(np.pi * yr))[:, :, None]
+    T = 12.0 + 8.0 * np.exp(zr / 15.0) + 0.5 * np.cos(2 * np.pi * (yr - t / 44714.0))[:, :, None]
     if raw is not None:
         conv = lambda a: np.asfortranarray(a.astype(np.float32).astype(raw))  # noqa: E731
         return dict(romZ=conv(zeta), romU=conv(U + 0.0 * sr), romV=conv(V + 0.0 * sr), romW=conv(W),
-                    romKH=conv(K) if with_kh else None)
+                    romKH=conv(K) if with_kh else None, romS=conv(S), romT=conv(T))
     out = dict(
         zeta=F(f32(zeta) * geo["m_r"]),
         Uvel=F(f32(U) * geo["m_u"][:, :, None]),
         Vvel=F(f32(V) * geo["m_v"][:, :, None]),
         Wvel=F(f32(W) * geo["m_r"][:, :, None]),
+        salt=F(f32(S) * geo["m_r"][:, :, None]),
+        temp=F(f32(T) * geo["m_r"][:, :, None]),
     )
     if with_kh:
         out["Kh"] = F(f32(K) * geo["m_r"][:, :, None])
@@ -414,7 +422,10 @@ def behaviour_state(cfg, numpar):
                 P_swim=swim, P_pediage=ped, P_deadage=np.full(numpar, cfg.deadage),
                 settle=np.zeros(numpar, dtype=np.int32), settletime=ped.copy(),
                 endpoly=np.zeros(numpar, dtype=np.int32),
-                hitBottom=np.zeros(numpar, dtype=np.int32), hitLand=np.zeros(numpar, dtype=np.int32))
+                hitBottom=np.zeros(numpar, dtype=np.int32), hitLand=np.zeros(numpar, dtype=np.int32),
+                # behaviours 4, 5, 7: timer = 0, P_Sprev = P_zprev = 0, bottom = .TRUE. (:113,139-144)
+                timer=np.zeros(numpar), P_Sprev=np.zeros(numpar), P_zprev=np.zeros(numpar),
+                bottom=np.ones(numpar, dtype=np.int32))
 
 
 # --------------------------------------------------------------------------

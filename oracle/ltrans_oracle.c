@@ -33,9 +33,11 @@ void lto_init_genrand(lto_mt *s, uint32_t seed) {
 }
 
 /* genrand_int32, random_module.f90:166-197 */
+uint64_t lto_draw_counter = 0; /* raw words drawn so far by anyone (bookkeeping of the engine) */
 uint32_t lto_genrand_int32(lto_mt *s) {
   static const uint32_t mag01[2] = {0u, 0x9908b0dfu};
   uint32_t y;
+  lto_draw_counter++;
   if (s->mti >= 624) {
     int kk;
     for (kk = 0; kk < 624 - 397; kk++) {

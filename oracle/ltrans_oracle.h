@@ -46,6 +46,9 @@ int lto_set_rng(lto_engine *e, const int32_t *mt624, int32_t mti);
 int lto_get_rng(lto_engine *e, int32_t *mt624, int32_t *mti);
 int lto_count_active(lto_engine *e, const double *ix3, int64_t *n_active);
 int lto_set_rng_window(lto_engine *e, int64_t active_before, int64_t active_total);
+int lto_count_draws(lto_engine *e, const double *ex3, const double *ix3, int32_t p, int32_t it,
+                    int64_t *n_draws);
+int lto_set_rng_window_draws(lto_engine *e, int64_t draws_before, int64_t draws_total);
 int lto_step(lto_engine *e, const double *ex3, const double *ix3, int32_t p, int32_t it);
 int lto_sync(lto_engine *e);
 int lto_get_stats(lto_engine *e, lt_step_stats *out);
@@ -54,6 +57,7 @@ int lto_get_particles(lto_engine *e, lt_particles *out);
 /* ---- leaf numerics, exported for pinning against oracle/_ref ------------ */
 typedef struct lto_mt { uint32_t mt[624]; int32_t mti; } lto_mt;
 void     lto_init_genrand(lto_mt *s, uint32_t seed);      /* random_module.f90:108 */
+extern uint64_t lto_draw_counter;                         /* raw words drawn so far */
 uint32_t lto_genrand_int32(lto_mt *s);                    /* :166 */
 void     lto_genrand_fill(lto_mt *s, uint64_t skip, int n, uint32_t *out);
 double   lto_genrand_real1(lto_mt *s);                    /* :213 */

@@ -29,6 +29,36 @@ CASES = {
                        cfg=dict(Behavior=6, sink=-0.001, HTurbOn=0, VTurbOn=1)),
     "small_turb": dict(grid=(100, 100, 20), islands=[(40, 44, 50, 53), (70, 71, 20, 30)],
                        numpar=608, near_land=0.2, cfg=dict(Behavior=0, HTurbOn=1, VTurbOn=1)),
+    # biological behaviours 1-5 and 7 (behavior_module.f90:181-551): genrand_real1 draws in
+    # particle order (a data-dependent number for 4 and 5), salinity cue through WCTS_ITPI
+    "tiny_beh1": dict(grid=(24, 16, 8), islands=[(10, 12, 6, 8)], numpar=512, near_land=0.3,
+                      cfg=dict(Behavior=1, swimstart=0.0, swimslow=0.002, swimfast=0.004, pediage=7200.0)),
+    "tiny_beh2": dict(grid=(24, 16, 8), islands=[(10, 12, 6, 8)], numpar=512, near_land=0.3,
+                      cfg=dict(Behavior=2, swimstart=0.0, swimslow=0.002, swimfast=0.004, pediage=7200.0,
+                               HTurbOn=1, ConstantHTurb=1.0)),
+    "tiny_beh3": dict(grid=(24, 16, 8), islands=[(10, 12, 6, 8)], numpar=512, near_land=0.3,
+                      cfg=dict(Behavior=3, swimstart=0.0, swimslow=0.002, swimfast=0.004, pediage=7200.0,
+                               twistart=0.5, twiend=3.0, daylength=2.5, Kd=0.2)),
+    "tiny_beh4": dict(grid=(24, 16, 8), islands=[(10, 12, 6, 8)], numpar=512, near_land=0.3,
+                      cfg=dict(Behavior=4, swimstart=0.0, swimslow=0.003, swimfast=0.006, pediage=9000.0,
+                               deadage=20000.0, Sgradient=0.3, VTurbOn=1)),
+    "tiny_beh5": dict(grid=(24, 16, 8), islands=[(10, 12, 6, 8)], numpar=512, near_land=0.3,
+                      cfg=dict(Behavior=5, swimstart=0.0, swimslow=0.003, swimfast=0.006, pediage=9000.0,
+                               deadage=20000.0, Sgradient=0.3)),
+    # C. virginica / C. ariakensis late stages: age-dependent switch, the 2-h bottom timer,
+    # the change to pediveliger behaviour (P_behave 4/5 -> 2) at pediage
+    "tiny_beh4_old": dict(grid=(24, 16, 8), islands=[(10, 12, 6, 8)], numpar=512, near_land=0.3,
+                          age0=(100000.0, 800000.0),
+                          cfg=dict(Behavior=4, swimstart=0.0, swimslow=0.003, swimfast=0.006, pediage=760000.0,
+                                   deadage=900000.0, Sgradient=0.3)),
+    "tiny_beh5_old": dict(grid=(24, 16, 8), islands=[(10, 12, 6, 8)], numpar=512, near_land=0.3,
+                          age0=(100000.0, 420000.0),
+                          cfg=dict(Behavior=5, swimstart=0.0, swimslow=0.003, swimfast=0.006, pediage=400000.0,
+                                   deadage=900000.0, Sgradient=0.3, HTurbOn=1)),
+    "tiny_beh7": dict(grid=(24, 16, 8), islands=[(10, 12, 6, 8)], numpar=512, near_land=0.3,
+                      cfg=dict(Behavior=7, Hswimspeed=0.3, Swimdepth=2.0)),
+    "tiny_salt": dict(grid=(24, 16, 8), islands=[(10, 12, 6, 8)], numpar=512, near_land=0.3,
+                      cfg=dict(Behavior=0, SaltTempOn=1)),
     # uniform drift into the west/south coast and the island: many reflections
     "tiny_reflect": dict(grid=(24, 16, 8), islands=[(10, 12, 6, 8)], numpar=768, near_land=0.6,
                          drift=(-0.35, -0.25), cfg=dict(Behavior=0)),
@@ -60,6 +90,10 @@ def build_case(name, numpar=None, slab_storage=None, **cfg_extra):
     cfg = ltrans_amd.LtConfig(**kw)
     parts = rs.make_particles(g, geo, bounds, n, seed=12345, near_land=spec["near_land"])
     parts.update(rs.behaviour_state(cfg, n))
+    if "age0" in spec:       # particles that are already old: late-stage behaviour branches
+        lo, hi = spec["age0"]
+        parts["par"][:, 11] = np.linspace(lo, hi, n)          # par(:,pAge)
+        parts["par"][:, 10] = -parts["par"][:, 11] - 1.0       # par(:,pDOB): released before t = 0
     habitat = None
     if cfg.settlementon:
         habitat = rs.make_habitat(g, geo, spec["polygons"], spec.get("holes", ()))
