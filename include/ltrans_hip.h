@@ -113,6 +113,9 @@ typedef struct lt_config {
   int32_t settlementon, holesExist;
   /* $convparam */
   double  PI;                 /* namelist value 3.14159265358979 (norm_module.f90:37)  */
+  double  Earth_Radius;       /* x2lon / y2lat of the output path                      */
+  int32_t SphericalProjection;
+  double  lonmin, latmin;
   /* $other */
   int32_t seed;               /* init_genrand(seed) (LTRANS.f90:241)                   */
   int32_t ErrorFlag;          /* 0 stop, 1 return to previous, 2 kill, 3 set out       */
@@ -244,6 +247,17 @@ typedef struct lt_rom_record {
   const void *romS, *romT;       /* (vi,uj,us) salinity / temperature, as lt_slab     */
 } lt_rom_record;
 
+/* What printOutput / writeOutput hand to the CSV and NetCDF writers (LTRANS.f90:1617-1779):
+ * longitude / latitude of the particle (x2lon, y2lat, conversion_module.f90:322-378), depth,
+ * age, getStatus (behavior_module.f90:554-574: behaviour id, -1 dead, -2 settled, -3 out of
+ * bounds; a DOUBLE PRECISION array there), and the optional columns.  Host arrays of numpar
+ * values in the host's particle order; NULL = not wanted. */
+typedef struct lt_output {
+  double  *lon, *lat, *z, *age, *status;
+  double  *salt, *temp;          /* SaltTempOn                                       */
+  int32_t *hitBottom, *hitLand;  /* TrackCollisions                                  */
+} lt_output;
+
 /* Per-step counters (sums over the shard). */
 typedef struct lt_step_stats {
   int64_t active;                /* particles that were tracked this step           */
@@ -315,6 +329,10 @@ int lt_get_stats(lt_engine *e, lt_step_stats *out);
 
 /* downloads ------------------------------------------------------------- */
 int lt_get_particles(lt_engine *e, lt_particles *out);
+/* The conversion loop of writeOutput (LTRANS.f90:1719-1723) on the device and the download
+ * of only what the writers need.  reset_hits != 0 also clears hitBottom / hitLand as
+ * printOutput does after LandHits.csv / BottomHits.csv (:1665-1666). */
+int lt_get_output(lt_engine *e, lt_output *out, int32_t reset_hits);
 /* Pack (x,y,z) of the shard as xyz(numpar,3) column-major into DEVICE memory
  * dst (e.g. the send buffer of an RCCL all-gather); asynchronous. */
 int lt_pack_positions(lt_engine *e, void *dst_device);

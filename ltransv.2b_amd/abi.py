@@ -49,7 +49,8 @@ class LtConfig(C.Structure):
         ("twistart", C.c_double), ("twiend", C.c_double), ("daylength", C.c_double),
         ("Em", C.c_double), ("Kd", C.c_double), ("thresh", C.c_double),
         ("settlementon", C.c_int32), ("holesExist", C.c_int32),
-        ("PI", C.c_double),
+        ("PI", C.c_double), ("Earth_Radius", C.c_double), ("SphericalProjection", C.c_int32),
+        ("lonmin", C.c_double), ("latmin", C.c_double),
         ("seed", C.c_int32), ("ErrorFlag", C.c_int32), ("SaltTempOn", C.c_int32),
         ("TrackCollisions", C.c_int32), ("FreeSlip", C.c_int32),
         ("slab_storage", C.c_int32), ("device", C.c_int32), ("reserved0", C.c_int32),
@@ -70,6 +71,8 @@ class LtConfig(C.Structure):
         self.twistart, self.twiend, self.daylength = 4.801821, 19.19956, 14.39774
         self.Em, self.Kd, self.thresh = 1814.328, 1.07, 0.0166
         self.PI = 3.14159265358979
+        self.Earth_Radius, self.SphericalProjection = 6378000.0, 0
+        self.lonmin, self.latmin = -77.0, 36.0
         self.seed = 9
         self.ErrorFlag = 1
         self.slab_storage = LT_SLAB_F32
@@ -159,6 +162,11 @@ class LtRomRecord(C.Structure):
     ]
 
 
+class LtOutput(C.Structure):
+    _fields_ = [("lon", c_dp), ("lat", c_dp), ("z", c_dp), ("age", c_dp), ("status", c_dp),
+                ("salt", c_dp), ("temp", c_dp), ("hitBottom", c_ip), ("hitLand", c_ip)]
+
+
 class LtStepStats(C.Structure):
     _fields_ = [("active", C.c_int64), ("errors", C.c_int64), ("rng_draws", C.c_int64)]
 
@@ -169,7 +177,7 @@ ENTRY_POINTS = [
     "create", "destroy", "set_grid", "set_bounds", "set_habitat", "set_particles",
     "set_slab", "set_time_slots", "slab_prefetch", "slab_commit", "set_rng", "get_rng", "count_active", "set_rng_window",
     "count_draws", "set_rng_window_draws",
-    "step", "sync", "get_stats", "get_particles",
+    "step", "sync", "get_stats", "get_particles", "get_output",
 ]
 HIP_ONLY_ENTRY_POINTS = ["last_error", "abi_version", "pack_positions", "stream",
                          "profile_begin", "profile_end", "get_counters"]

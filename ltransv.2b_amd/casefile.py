@@ -140,10 +140,10 @@ $settleparam
 $end
 $convparam
   PI = {cfg.PI!r}
-  Earth_Radius = 6378000
-  SphericalProjection = .TRUE.
-  latmin = 0
-  lonmin = 0
+  Earth_Radius = {cfg.Earth_Radius!r}
+  SphericalProjection = {_l(cfg.SphericalProjection)}
+  latmin = {cfg.latmin!r}
+  lonmin = {cfg.lonmin!r}
 $end
 $other
   seed         = {cfg.seed}

@@ -63,7 +63,7 @@ struct lt_engine {
   lt_habitat hab{};
   int npoly = 0, nhole = 0;
   // particles
-  DevBuf ws_d, ws_i, orig, ele_ok, block_active, count_slots;
+  DevBuf ws_d, ws_i, orig, ele_ok, block_active, count_slots, out_cols, out_hits;
   // internal particle order: slot i of every device array holds the reference's
   // particle perm[i] (0-based); sorted by rho element for memory locality
   std::vector<int> perm;
@@ -646,7 +646,7 @@ int lt_destroy(lt_engine* e) {
                     &e->ep_ptr, &e->ep_ids, &e->ph_ptr, &e->ph_ids, &e->par, &e->pr, &e->pu,
                     &e->pv, &e->P_behave, &e->dead, &e->oob, &e->settle, &e->endpoly,
                     &e->hitBottom, &e->hitLand, &e->err_code, &e->P_swim, &e->P_pediage,
-                    &e->P_deadage, &e->settletime, &e->timer, &e->P_Sprev, &e->P_zprev, &e->bottom, &e->P_Salt, &e->P_Temp, &e->S, &e->T, &e->counters, &e->ws_d, &e->ws_i, &e->orig, &e->ele_ok, &e->block_active, &e->count_slots, &e->rng_states, &e->rng_ring, &e->rng_gJ, &e->flag, &e->rank, &e->scan_tmp,
+                    &e->P_deadage, &e->settletime, &e->timer, &e->P_Sprev, &e->P_zprev, &e->bottom, &e->P_Salt, &e->P_Temp, &e->S, &e->T, &e->counters, &e->ws_d, &e->ws_i, &e->orig, &e->ele_ok, &e->block_active, &e->count_slots, &e->out_cols, &e->out_hits, &e->rng_states, &e->rng_ring, &e->rng_gJ, &e->flag, &e->rank, &e->scan_tmp,
                     &e->vt_x, &e->vt_y, &e->vt_yp, &e->vt_sig};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
@@ -919,6 +919,32 @@ int lt_get_particles(lt_engine* e, lt_particles* out) {
   TRY(get_field<int32_t>(e, e->bottom, out->bottom, 1));
   TRY(get_field<double>(e, e->P_Salt, out->P_Salt, 1));
   TRY(get_field<double>(e, e->P_Temp, out->P_Temp, 1));
+  return LT_OK;
+}
+
+int lt_get_output(lt_engine* e, lt_output* out, int32_t reset_hits) {
+  if (!e || !out) return LT_ERR_ARG;
+  if (!e->have_particles) return fail(e, LT_ERR_STATE, "no particles uploaded");
+  if (e->pre_valid) return fail(e, LT_ERR_STATE, "not between lt_count_draws and its lt_step");
+  HIPCHK(e, hipSetDevice(e->device));
+  const size_t n = (size_t)e->cfg.numpar;
+  if (!n) return LT_OK;
+  TRY(dev_alloc(e, e->out_cols, 5 * n * 8));
+  TRY(dev_alloc(e, e->out_hits, 2 * n * 4));
+  StepParams P;
+  fill_params(e, P);
+  hipLaunchKernelGGL(k_output, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, P, e->cfg.Earth_Radius,
+                     e->cfg.SphericalProjection, e->cfg.lonmin, e->cfg.latmin, (double*)e->out_cols.p,
+                     (int*)e->out_hits.p, (int)reset_hits);
+  HIPCHK(e, hipGetLastError());
+  double* dst[5] = {out->lon, out->lat, out->z, out->age, out->status};
+  for (int c = 0; c < 5; c++)
+    if (dst[c]) HIPCHK(e, hipMemcpyAsync(dst[c], (double*)e->out_cols.p + c * n, n * 8, hipMemcpyDeviceToHost, e->stream));
+  if (out->hitBottom) HIPCHK(e, hipMemcpyAsync(out->hitBottom, (int*)e->out_hits.p, n * 4, hipMemcpyDeviceToHost, e->stream));
+  if (out->hitLand) HIPCHK(e, hipMemcpyAsync(out->hitLand, (int*)e->out_hits.p + n, n * 4, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (out->salt) TRY(get_field<double>(e, e->P_Salt, out->salt, 1));
+  if (out->temp) TRY(get_field<double>(e, e->P_Temp, out->temp, 1));
   return LT_OK;
 }
 

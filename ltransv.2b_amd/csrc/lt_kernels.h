@@ -2161,6 +2161,41 @@ __global__ void k_pack_positions(const double* __restrict__ par, const int* __re
 }
 
 // act flag of every particle in REFERENCE order (input of the rank scan)
+// The conversion loop of writeOutput (LTRANS.f90:1719-1723): dx2lon / dy2lat
+// (conversion_module.f90:322-378), getStatus (behavior_module.f90:554-574), and the columns
+// the writers take, in the REFERENCE particle order.  cols: lon, lat, z, age, status
+// (doubles, stride numpar); hits: hitBottom, hitLand (ints, stride numpar).
+__global__ void k_output(const StepParams P, double Earth_Radius, int Spherical, double lonmin, double latmin,
+                         double* __restrict__ cols, int* __restrict__ hits, int reset_hits) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.numpar) return;
+  const size_t N = (size_t)P.numpar;
+  const int o = P.orig[i];
+  const double x = P.par[(size_t)pX * N + i], y = P.par[(size_t)pY * N + i];
+  const double RCF = 180.0 / P.PI;
+  double lon, lat;
+  if (Spherical) {
+    const double la = y * 180.0 / (Earth_Radius * P.PI) + latmin;
+    lon = x * 180.0 / (Earth_Radius * P.PI * cos(la / RCF)) + lonmin;
+    lat = y * RCF / Earth_Radius + latmin;
+  } else {
+    lon = x / Earth_Radius * RCF;
+    lat = 2.0 * RCF * (atan(exp(y / Earth_Radius)) - P.PI / 4.0);
+  }
+  int status = P.P_behave[i];
+  if (P.dead[i]) status = -1;
+  if (P.settlementon && P.settle[i]) status = -2;
+  if (P.OpenOceanBoundary && P.oob[i]) status = -3;
+  cols[o] = lon;
+  cols[N + o] = lat;
+  cols[2 * N + o] = P.par[(size_t)pZ * N + i];
+  cols[3 * N + o] = P.par[(size_t)pAge * N + i];
+  cols[4 * N + o] = (double)status;
+  hits[o] = P.hitBottom[i];
+  hits[N + o] = P.hitLand[i];
+  if (reset_hits) { P.hitBottom[i] = 0; P.hitLand[i] = 0; }
+}
+
 // (the value scanned is the number of deviates the particle will draw: the turbulence draws
 // plus what k_beh_pre decided for the behaviour)
 __global__ void k_flag_scatter(const int* __restrict__ ws_i, const int* __restrict__ orig,

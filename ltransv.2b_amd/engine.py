@@ -197,6 +197,20 @@ class Engine:
             raise KeyError(f"unknown particle arrays {sorted(unknown)}")
         self._check(self._fn["set_particles"](self._h, C.byref(s)), "set_particles")
 
+    def get_output(self, reset_hits=False, salt_temp=False):
+        """lt_get_output: dict lon, lat, z, age, status (+ salt, temp), hitBottom, hitLand."""
+        n = self.numpar
+        o = abi.LtOutput()
+        res = {}
+        for k in ("lon", "lat", "z", "age", "status") + (("salt", "temp") if salt_temp else ()):
+            res[k] = np.zeros(n, dtype=np.float64)
+            setattr(o, k, _dp(res[k]))
+        for k in ("hitBottom", "hitLand"):
+            res[k] = np.zeros(n, dtype=np.int32)
+            setattr(o, k, _ip(res[k]))
+        self._check(self._fn["get_output"](self._h, C.byref(o), int(bool(reset_hits))), "get_output")
+        return res
+
     def set_slab(self, slot, zeta, Uvel, Vvel, Wvel, Kh=None, salt=None, temp=None):
         """One masked time record into slot 1..3 (updateHydro, hydrodynamic_module.f90:1371)."""
         g = self._grid

@@ -175,6 +175,8 @@ program ltrans_hip_driver
   cfg%Em = Em; cfg%Kd = Kd; cfg%thresh = thresh
   cfg%settlementon = merge(1, 0, settlementon); cfg%holesExist = merge(1, 0, holesExist)
   cfg%PI = PI; cfg%seed = seed; cfg%ErrorFlag = ErrorFlag
+  cfg%Earth_Radius = Earth_Radius; cfg%SphericalProjection = merge(1, 0, SphericalProjection)
+  cfg%lonmin = lonmin; cfg%latmin = latmin
   cfg%SaltTempOn = merge(1, 0, SaltTempOn); cfg%TrackCollisions = merge(1, 0, TrackCollisions)
   cfg%FreeSlip = merge(1, 0, FreeSlip)
   eng = c_null_ptr

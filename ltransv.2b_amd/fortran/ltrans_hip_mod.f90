@@ -32,7 +32,9 @@ module ltrans_hip
     real(c_double)     :: Sgradient, Hswimspeed
     real(c_double)     :: twistart, twiend, daylength, Em, Kd, thresh
     integer(c_int32_t) :: settlementon, holesExist
-    real(c_double)     :: PI
+    real(c_double)     :: PI, Earth_Radius
+    integer(c_int32_t) :: SphericalProjection
+    real(c_double)     :: lonmin, latmin
     integer(c_int32_t) :: seed, ErrorFlag, SaltTempOn, TrackCollisions, FreeSlip
     integer(c_int32_t) :: slab_storage, device, reserved0
   end type lt_config
@@ -68,6 +70,13 @@ module ltrans_hip
     type(c_ptr) :: timer, P_Sprev, P_zprev, bottom
     type(c_ptr) :: P_Salt, P_Temp
   end type lt_particles
+
+  ! what writeOutput hands to the CSV / NetCDF writers (LTRANS.f90:1700-1779)
+  type, bind(C) :: lt_output
+    type(c_ptr) :: lon, lat, z, age, status
+    type(c_ptr) :: salt, temp
+    type(c_ptr) :: hitBottom, hitLand
+  end type lt_output
 
   type, bind(C) :: lt_slab
     type(c_ptr) :: zeta, Uvel, Vvel, Wvel, Kh, salt, temp
@@ -137,6 +146,13 @@ module ltrans_hip
       import :: c_int, c_ptr, lt_particles
       type(c_ptr), value :: engine
       type(lt_particles), intent(in) :: p     ! pointers to the caller's arrays: filled in place
+      integer(c_int) :: rc
+    end function
+    function lt_get_output(engine, o, reset_hits) bind(C, name="lt_get_output") result(rc)
+      import :: c_int, c_int32_t, c_ptr, lt_output
+      type(c_ptr), value :: engine
+      type(lt_output), intent(in) :: o
+      integer(c_int32_t), value :: reset_hits
       integer(c_int) :: rc
     end function
     function lt_set_slab(engine, slot, s) bind(C, name="lt_set_slab") result(rc)
@@ -250,6 +266,7 @@ contains
     cfg%Em = 1814.328d0; cfg%Kd = 1.07d0; cfg%thresh = 0.0166d0
     cfg%settlementon = 0; cfg%holesExist = 0
     cfg%PI = 3.14159265358979d0
+    cfg%Earth_Radius = 6378000.d0; cfg%SphericalProjection = 0; cfg%lonmin = -77.d0; cfg%latmin = 36.d0
     cfg%seed = 9; cfg%ErrorFlag = 1; cfg%SaltTempOn = 0; cfg%TrackCollisions = 0; cfg%FreeSlip = 0
     cfg%slab_storage = LT_SLAB_F32; cfg%device = -1; cfg%reserved0 = 0
   end function

@@ -82,7 +82,7 @@ _MAP = {
                    "swimstart", "swimslow", "swimfast", "sink", "Swimdepth", "Sgradient", "Hswimspeed"],
     "dvmparam": ["twistart", "twiend", "daylength", "Em", "Kd", "thresh"],
     "settleparam": ["settlementon", "holesExist"],
-    "convparam": ["PI"],
+    "convparam": ["PI", "Earth_Radius", "SphericalProjection", "lonmin", "latmin"],
     "other": ["seed", "ErrorFlag", "SaltTempOn", "TrackCollisions", "FreeSlip"],
 }
 

@@ -53,6 +53,7 @@ int lto_step(lto_engine *e, const double *ex3, const double *ix3, int32_t p, int
 int lto_sync(lto_engine *e);
 int lto_get_stats(lto_engine *e, lt_step_stats *out);
 int lto_get_particles(lto_engine *e, lt_particles *out);
+int lto_get_output(lto_engine *e, lt_output *out, int32_t reset_hits);
 
 /* ---- leaf numerics, exported for pinning against oracle/_ref ------------ */
 typedef struct lto_mt { uint32_t mt[624]; int32_t mti; } lto_mt;

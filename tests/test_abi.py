@@ -48,7 +48,8 @@ def test_oracle_exports_same_engine_api(oracle):
 
 STRUCTS = {"lt_config": abi.LtConfig, "lt_grid": abi.LtGrid, "lt_bounds": abi.LtBounds,
            "lt_habitat": abi.LtHabitat, "lt_particles": abi.LtParticles, "lt_slab": abi.LtSlab,
-           "lt_step_stats": abi.LtStepStats, "lt_rom_record": abi.LtRomRecord}
+           "lt_step_stats": abi.LtStepStats, "lt_rom_record": abi.LtRomRecord,
+           "lt_output": abi.LtOutput}
 
 
 def test_struct_layout_matches_header(tmp_path):
