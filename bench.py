@@ -339,6 +339,13 @@ def main():
     }
     if world == 1 and not args.no_hydro_timing:
         out["config"]["hydro_update"] = hydro_update_costs(e, run, rs, g, geo, args, state, one_step, fence)
+        # the print step: lon/lat/status on the device + download of the
+        # writers' columns, against downloading the whole particle state
+        fence()
+        e.get_output()
+        t0 = time.perf_counter(); e.get_output(); t_out = time.perf_counter() - t0
+        t0 = time.perf_counter(); e.get_particles(); t_all = time.perf_counter() - t0
+        out["config"]["print_step"] = {"lt_get_output_ms": t_out * 1e3, "lt_get_particles_ms": t_all * 1e3}
     if rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ltrans_amd, args, vi, uj, us, g, geo, bounds, records)
     elif rank == 0:
