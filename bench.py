@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--slab", choices=["f32", "f64"], default="f32")
     ap.add_argument("--turb", action="store_true",
                     help="BASELINE configs[2]: RK4 + HTurb + VTurb (MT19937 stream on device)")
+    ap.add_argument("--behavior", type=int, default=0,
+                    help="behaviour type 0-7 (BASELINE configs[4] uses 6 = sinking, with --settle)")
+    ap.add_argument("--settle", action="store_true", help="settlement on habitat polygons + mortality")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hydro-timing", action="store_true",
                     help="skip the updateHydro cost measurement (set_slab vs slab pipeline)")
@@ -91,12 +94,27 @@ def build_inputs(vi, uj, us, numpar, seed):
     return g, geo, bounds, parts
 
 
+def behaviour_cfg(args):
+    """extra lt_config fields of the optional behaviour / settlement workload"""
+    kw = dict(Behavior=args.behavior)
+    if args.behavior:
+        kw.update(swimstart=0.0, swimslow=0.002, swimfast=0.004, sink=-0.002, pediage=7200.0, deadage=90000.0,
+                  Sgradient=0.3, Hswimspeed=0.3)
+    if args.settle:
+        kw.update(settlementon=1, holesExist=1, mortality=1, pediage=3600.0, deadage=36000.0)
+    return kw
+
+
 def make_engine(ltrans_amd, cfg, g, geo, bounds, parts, records, **kw):
     from ltrans_amd import roms_synth as rs
     from ltrans_amd.driver import LtransRun
     e = ltrans_amd.Engine(cfg, **kw)
     e.set_grid(geo)
     e.set_bounds(bounds)
+    if cfg.settlementon:
+        Lx, Ly = (g["vi"] - 1) * g["dx"], (g["uj"] - 1) * g["dy"]
+        polys = [(Lx * fx, Ly * fy, 0.03 * Lx, 14) for fx in (0.2, 0.4, 0.6, 0.8) for fy in (0.25, 0.5, 0.75)]
+        e.set_habitat(rs.make_habitat(g, geo, polys, [(0, Lx * 0.2, Ly * 0.25, 0.008 * Lx, 8)]))
     e.set_particles(**parts, **rs.behaviour_state(cfg, cfg.numpar))
     run = LtransRun(e, cfg.dt, cfg.idt, lambda r: records(r))
     run.init_hydro()
@@ -130,7 +148,8 @@ def hydro_update_costs(e, run, rs, g, geo, args, state, one_step, fence):
     # synchronous path
     run.t_b, run.t_c, run.t_f = rotated()
     t0 = time.perf_counter()
-    e.set_slab(run.t_f, masked["zeta"], masked["Uvel"], masked["Vvel"], masked["Wvel"], masked.get("Kh"))
+    e.set_slab(run.t_f, masked["zeta"], masked["Uvel"], masked["Vvel"], masked["Wvel"], masked.get("Kh"),
+               masked.get("salt"), masked.get("temp"))
     e.set_time_slots(run.t_b, run.t_c, run.t_f)
     fence()
     t_sync = time.perf_counter() - t0
@@ -166,8 +185,8 @@ def cpu_baseline(ltrans_amd, args, vi, uj, us, g, geo, bounds, records):
     n = args.cpu_sample
     parts = rs.make_particles(g, geo, bounds, n, seed=777)
     turb = 1 if args.turb else 0
-    cfg = ltrans_amd.LtConfig(numpar=n, us=us, ws=us + 1, dt=3600, idt=120, Behavior=0,
-                              ErrorFlag=1, HTurbOn=turb, VTurbOn=turb)
+    cfg = ltrans_amd.LtConfig(numpar=n, us=us, ws=us + 1, dt=3600, idt=120,
+                              ErrorFlag=1, HTurbOn=turb, VTurbOn=turb, **behaviour_cfg(args))
     e, run = make_engine(ltrans_amd, cfg, g, geo, bounds, parts, records,
                          lib=oracle_lib.load_oracle(), prefix="lto_")
     ex = run.external_times(2)
@@ -212,8 +231,8 @@ def main():
         return rec_cache[r]
 
     turb = 1 if args.turb else 0
-    cfg = ltrans_amd.LtConfig(numpar=n, us=us, ws=us + 1, dt=3600, idt=120, Behavior=0,
-                              ErrorFlag=1, device=dev.index, HTurbOn=turb, VTurbOn=turb,
+    cfg = ltrans_amd.LtConfig(numpar=n, us=us, ws=us + 1, dt=3600, idt=120,
+                              ErrorFlag=1, device=dev.index, HTurbOn=turb, VTurbOn=turb, **behaviour_cfg(args),
                               slab_storage=(ltrans_amd.abi.LT_SLAB_F32 if args.slab == "f32"
                                             else ltrans_amd.abi.LT_SLAB_F64))
     e, run = make_engine(ltrans_amd, cfg, g, geo, bounds, parts, records)
@@ -248,11 +267,16 @@ def main():
     def one_step():
         state["it"] += 1
         ix = run.internal_times(state["ex"], state["it"])
-        if world > 1 and args.turb:
+        if world > 1 and (args.turb or 1 <= args.behavior <= 5):
             # every rank's place in the single serial random stream of this step
             from ltrans_amd import sharding
-            before, total = sharding.rng_window(dist, torch, e.count_active(ix), world, rank, device=dev)
-            e.set_rng_window(before, total)
+            if 1 <= args.behavior <= 5:   # data-dependent number of deviates: count draws
+                mine = e.count_draws(state["ex"], ix, state["p"], state["it"])
+                before, total = sharding.rng_window(dist, torch, mine, world, rank, device=dev)
+                e.set_rng_window_draws(before, total)
+            else:
+                before, total = sharding.rng_window(dist, torch, e.count_active(ix), world, rank, device=dev)
+                e.set_rng_window(before, total)
         e.update_particles(state["ex"], ix, state["p"], state["it"])
         if world > 1:
             b = state["nstep"] & 1
@@ -323,7 +347,9 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{n} particles per GPU, synthetic {vi}x{uj}x{us} ROMS grid, "
                                + ("RK4 + HTurb + VTurb (MT19937 stream on device), idt=120 s" if args.turb
-                                  else "RK4 advection only (HTurb/VTurb/behavior off), idt=120 s")
+                                  else "RK4 advection only (HTurb/VTurb off), idt=120 s")
+                               + (f", behaviour {args.behavior}" if args.behavior else ", behavior off")
+                               + (", settlement + mortality" if args.settle else "")
                                + (", RCCL all-gather of (x,y,z) per step" if world > 1 else ""),
                    "particles_per_gpu": n, "grid": args.grid, "slab_storage": args.slab,
                    "active_last_step": active, "errors_last_step": stats["errors"],
