@@ -543,19 +543,6 @@ LT_DEV double level_at(const LevCoef& q, double zeta, double h, int Vtransform) 
   return zeta * q.b + q.a + q.c;
 }
 
-LT_DEV int level_window2(const double* tab, int n, double Z, const Column& C, double hc,
-                         int Vtransform) {
-  int lo = 3, hi = n - 1;
-  while (lo < hi) {
-    int mid = (lo + hi) >> 1;
-    LevCoef q = level_coef(tab, mid, C.h, hc, Vtransform);
-    bool below = (Z < level_at(q, C.zeta[0], C.h, Vtransform)) ||
-                 (Z < level_at(q, C.zeta[1], C.h, Vtransform)) ||
-                 (Z < level_at(q, C.zeta[2], C.h, Vtransform));
-    if (below) hi = mid; else lo = mid + 1;
-  }
-  return lo - 2;
-}
 
 // per-wave LDS scratch of the batched passes.  Two task kinds:
 //   check: a non-evaluation interval that may need the convexity Newton
@@ -851,9 +838,7 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
       TICK(3);
     }
     // ---------------- pass B: everything of this variable that iterates
-#ifndef LT_ABL_NOTASKS
     run_tasks(ws, (nchk < LT_CHK_CAP) ? nchk : LT_CHK_CAP, nev, lane);
-#endif
     TICK(4);
     // ---------------- pass C: time interpolation :1534-1598 / hydrodynamic_module.f90:2653-2670
     if (act && !zero) {
@@ -1536,14 +1521,13 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
   double* wsd = P.ws_d + na;
   const double* wtab = lev + 3 * LT_LEV_STRIDE;
   const int ws = P.ws, p2 = 4 * P.ws;
-  double P_depth = -1.0, h = 1.0, P_zc = 0.0, P_zetac = 0.0;
+  double P_depth = -1.0, h = 1.0;
   double zeta[3] = {0.0, 0.0, 0.0};
   int4 rn = make_int4(1, 1, 1, 1);
   QuadWeights w0;
   w0.regime = 1; w0.node_hit = 0; w0.t = w0.u = w0.W1 = w0.W2 = w0.W3 = w0.W4 = 0.0;
   if (act) {
     P_depth = wsd[(size_t)WS_PDEPTH * N]; h = -1.0 * P_depth;
-    P_zc = wsd[(size_t)WS_PZ1 * N]; P_zetac = wsd[(size_t)WS_ZETA1 * N];
     zeta[0] = wsd[(size_t)WS_ZETA0 * N]; zeta[1] = wsd[(size_t)WS_ZETA1 * N]; zeta[2] = wsd[(size_t)WS_ZETA2 * N];
     // getInterp weights of the start position in the rho element (setInterp :882)
     const double X = P.par[(size_t)pX * N + n], Y = P.par[(size_t)pY * N + n];
@@ -1614,7 +1598,7 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
   }
   // table layout: [wave][k][lane], a wave streams one contiguous 4*ws*512 B block per array
   const size_t TS = 64, toff = (size_t)(na >> 6) * (size_t)p2 * 64 + (size_t)(na & 63);
-  double* tx = P.vt_x + toff; double* ty = P.vt_y + toff; double* typ = P.vt_yp + toff; double* tsg = P.vt_sig + toff;
+  double* tx = P.vt_x + toff; double* ty = P.vt_y + toff; double* typ = P.vt_yp + toff;
   // streaming YPC1 / SIGS state: previous point, previous interval, YP(k-2)
   double xm1 = 0.0, ym1 = 0.0, Sp = 0.0, DXp = 0.0, YPp = 0.0;
   bool ypc_fail = false;
