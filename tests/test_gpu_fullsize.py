@@ -1,0 +1,120 @@
+"""BASELINE.json's full size (1M particles, 512x256x30) checked through properties that do
+not need the oracle (it would take hours): the particles are independent, so
+  * two engines holding half of the particles each reproduce the single engine bit for bit
+    (also with turbulence, with the draw windows of the serial random stream),
+  * the internal particle order (sorted by element, or the host's order with LT_NO_SORT=1)
+    does not change any result,
+  * the engine is deterministic;
+and a 20k-particle sample of the same run is compared with the oracle."""
+import numpy as np
+import pytest
+
+import ltrans_amd
+import oracle_lib
+from ltrans_amd import roms_synth as rs
+from ltrans_amd.driver import LtransRun
+
+pytestmark = pytest.mark.gpu
+
+N = 1_000_000
+GRID = (512, 256, 30)
+
+
+def build_world():
+    vi, uj, us = GRID
+    g = rs.make_grid(vi, uj, us)
+    geo = rs.build_geometry(g)
+    bounds = rs.create_bounds(g)
+    parts = rs.make_particles(g, geo, bounds, N, seed=4242)
+    recs = {}
+
+    def record(r):
+        if r not in recs:
+            recs[r] = rs.make_record(g, geo, r, with_kh=True)
+        return recs[r]
+
+    return dict(g=g, geo=geo, bounds=bounds, parts=parts, record=record, us=us)
+
+
+@pytest.fixture(scope="module")
+def world():
+    return build_world()
+
+
+def _engine(world, lo, hi, kw=None, **cfgkw):
+    n = hi - lo
+    cfg = ltrans_amd.LtConfig(numpar=n, us=world["us"], ws=world["us"] + 1, dt=3600, idt=120, ErrorFlag=1, **cfgkw)
+    e = ltrans_amd.Engine(cfg, **(kw or {}))
+    e.set_grid(world["geo"])
+    e.set_bounds(world["bounds"])
+    parts = {k: (v[lo:hi] if v.ndim == 1 else np.asfortranarray(v[lo:hi])) for k, v in world["parts"].items()}
+    e.set_particles(**parts, **rs.behaviour_state(cfg, n))
+    run = LtransRun(e, cfg.dt, cfg.idt, world["record"])
+    run.init_hydro()
+    return e, run
+
+
+def _steps(pairs, nsteps, draws=False):
+    """advance all (engine, run) pairs together through the first nsteps internal steps of p = 2"""
+    p = 2
+    ex = pairs[0][1].external_times(p)
+    for it in range(1, nsteps + 1):
+        ix = pairs[0][1].internal_times(ex, it)
+        if draws and len(pairs) > 1:
+            counts = [e.count_active(ix) for e, _ in pairs]
+            for r, (e, _) in enumerate(pairs):
+                e.set_rng_window(sum(counts[:r]), sum(counts))
+        for e, _ in pairs:
+            e.update_particles(ex, ix, p, it)
+    return np.vstack([e.get_particles(fields=("par",))["par"] for e, _ in pairs])
+
+
+def test_shards_equal_single_engine_advection(world):
+    one = [_engine(world, 0, N)]
+    ref = _steps(one, 4)
+    one[0][0].close()
+    two = [_engine(world, 0, N // 2), _engine(world, N // 2, N)]
+    got = _steps(two, 4)
+    for e, _ in two:
+        e.close()
+    assert np.array_equal(got, ref)
+    assert np.isfinite(ref).all() and np.abs(ref[:, 6:9] - ref[:, 0:3]).max() > 0.0   # (ppX.. = last step's start)
+
+
+def test_shards_equal_single_engine_turbulence(world):
+    kw = dict(HTurbOn=1, VTurbOn=1, ConstantHTurb=1.0)
+    one = [_engine(world, 0, N, **kw)]
+    ref = _steps(one, 2, draws=True)
+    one[0][0].close()
+    two = [_engine(world, 0, N // 2, **kw), _engine(world, N // 2, N, **kw)]
+    got = _steps(two, 2, draws=True)
+    for e, _ in two:
+        e.close()
+    assert np.array_equal(got, ref)
+
+
+def test_internal_order_and_determinism(world, monkeypatch):
+    a = [_engine(world, 0, N)]
+    ra = _steps(a, 3)
+    a[0][0].close()
+    b = [_engine(world, 0, N)]
+    rb = _steps(b, 3)
+    b[0][0].close()
+    assert np.array_equal(ra, rb)
+    monkeypatch.setenv("LT_NO_SORT", "1")
+    c = [_engine(world, 0, N)]
+    rc = _steps(c, 3)
+    c[0][0].close()
+    assert np.array_equal(ra, rc)
+
+
+def test_sample_of_the_full_run_against_the_oracle(world):
+    lo, hi = 400_000, 420_000
+    hip = [_engine(world, lo, hi)]
+    rh = _steps(hip, 6)
+    hip[0][0].close()
+    orc = [_engine(world, lo, hi, kw=dict(lib=oracle_lib.load_oracle(), prefix="lto_"))]
+    ro = _steps(orc, 6)
+    orc[0][0].close()
+    rel = np.max(np.abs(rh[:, :3] - ro[:, :3]) / np.maximum(np.abs(ro[:, :3]), 1.0))
+    assert rel <= 1e-6, rel      # BASELINE.json's tolerance; typically 1e-15
