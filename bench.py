@@ -212,13 +212,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # LT_BENCH_BACKEND=gloo (rehearsal on a box with fewer GPUs than ranks: ranks share the
+    # cards, the all-gather goes through host memory) -- the driver's runs use RCCL
+    backend = os.environ.get("LT_BENCH_BACKEND", "nccl")
+    ndev = max(torch.cuda.device_count(), 1)
+    dev_index = (local_rank % ndev) if (world > 1 and backend != "nccl") else (local_rank if world > 1 else 0)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend)
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", dev_index)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     vi, uj, us = (int(v) for v in args.grid.split("x"))
     n = args.numpar
@@ -272,10 +281,10 @@ def main():
             from ltrans_amd import sharding
             if 1 <= args.behavior <= 5:   # data-dependent number of deviates: count draws
                 mine = e.count_draws(state["ex"], ix, state["p"], state["it"])
-                before, total = sharding.rng_window(dist, torch, mine, world, rank, device=dev)
+                before, total = sharding.rng_window(dist, torch, mine, world, rank, device=coll_dev)
                 e.set_rng_window_draws(before, total)
             else:
-                before, total = sharding.rng_window(dist, torch, e.count_active(ix), world, rank, device=dev)
+                before, total = sharding.rng_window(dist, torch, e.count_active(ix), world, rank, device=coll_dev)
                 e.set_rng_window(before, total)
         e.update_particles(state["ex"], ix, state["p"], state["it"])
         if world > 1:
@@ -286,7 +295,12 @@ def main():
             e.pack_positions(send[b].data_ptr())
             e.sync()                            # engine stream: step + pack complete
             with torch.cuda.stream(gather_stream):
-                dist.all_gather_into_tensor(recv, send[b])
+                if backend == "nccl":
+                    dist.all_gather_into_tensor(recv, send[b])
+                else:
+                    parts_ = [torch.empty(3 * n, dtype=torch.float64) for _ in range(world)]
+                    dist.all_gather(parts_, send[b].cpu())
+                    recv.copy_(torch.cat(parts_))
                 send_done[b] = torch.cuda.Event()
                 send_done[b].record(gather_stream)
 
@@ -321,7 +335,7 @@ def main():
     k_ms, k_n = e.profile_end()
     stats = e.counters()
 
-    wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    wall_t = torch.tensor([wall], dtype=torch.float64, device=coll_dev)
     if world > 1:
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
     wall = float(wall_t.item())
@@ -372,7 +386,7 @@ def main():
         t0 = time.perf_counter(); e.get_output(); t_out = time.perf_counter() - t0
         t0 = time.perf_counter(); e.get_particles(); t_all = time.perf_counter() - t0
         out["config"]["print_step"] = {"lt_get_output_ms": t_out * 1e3, "lt_get_particles_ms": t_all * 1e3}
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ltrans_amd, args, vi, uj, us, g, geo, bounds, records)
     elif rank == 0:
         out["cpu_baseline"] = None
