@@ -27,6 +27,9 @@
 #include "lt_math.h"
 
 namespace ltd {
+#if defined(LT_POST_TIMING) && !defined(LT_RK_TIMING)
+__device__ unsigned long long g_tim[8];  // development aid
+#endif
 
 LT_DEV uint32_t ltmt_temper(uint32_t y) {  // random_module.f90:190-193
   y ^= (y >> 11);
@@ -137,6 +140,45 @@ LT_DEV bool find_element(const void* nodes, const int4* EL, const int* Adj, doub
   return false;
 }
 
+// The neighbour part of the same walk (entries 2..10 of the adjacency row) with the probes
+// of three neighbours in flight at a time: the row, then per chunk the three node-id
+// records, then their twelve corner records, tested in the row's order -- the result is
+// the reference's (first listed element that contains the point; a zero entry ends the
+// list), in at most 1 + 3x2 dependent loads instead of up to 9x3.
+template <bool RHO>
+LT_DEV bool find_element_neighbours(const void* nodes, const int4* EL, const int* Adj, double X, double Y,
+                                    int& ele, int4& nd) {
+  const int* row = Adj + (size_t)(ele - 1) * 10;
+  int cand[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) cand[i] = row[i + 1];
+#pragma unroll 1
+  for (int c = 0; c < 9; c += 3) {
+    int4 n[3];
+    Quad q[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int cj = (c == 0) ? cand[j] : (c == 3) ? cand[3 + j] : cand[6 + j];
+      n[j] = EL[(cj > 0 ? cj : ele) - 1];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+      q[j] = RHO ? load_quad_rho((const RhoNode*)nodes, n[j]) : load_quad_xy((const XYNode*)nodes, n[j]);
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int cj = (c == 0) ? cand[j] : (c == 3) ? cand[3 + j] : cand[6 + j];
+      if (cj == 0) { nd = EL[ele - 1]; return false; }  // zero-filled tail: nothing further to probe
+      if (gridcell_one(q[j].x, q[j].y, X, Y)) {
+        ele = cj;
+        nd = n[j];
+        return true;
+      }
+    }
+  }
+  nd = EL[ele - 1];
+  return false;
+}
+
 // setEle for the three grids (hydrodynamic_module.f90:1462-1510) with the FIRST
 // probe of each grid (the particle's current element, almost always the hit)
 // issued together: the three dependent load chains element -> node ids -> node
@@ -153,9 +195,105 @@ LT_DEV void find_elements3(const StepParams& P, double X, double Y, int& er, int
   okr = gridcell_one(qr.x, qr.y, X, Y);
   oku = gridcell_one(qu.x, qu.y, X, Y);
   okv = gridcell_one(qv.x, qv.y, X, Y);
-  if (!okr) okr = find_element<true>(P.rnode, P.RE, P.rAdj, X, Y, er, rn, 1);
-  if (!oku) oku = find_element<false>(P.unode, P.UE, P.uAdj, X, Y, eu, un, 1);
-  if (!okv) okv = find_element<false>(P.vnode, P.VE, P.vAdj, X, Y, ev, vn, 1);
+#ifdef LT_POST_TIMING
+  {
+    const unsigned long long m1 = __ballot(!okr), m2 = __ballot(!oku), m3 = __ballot(!okv);
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(&g_tim[5], (unsigned long long)(__popcll(m1) + __popcll(m2) + __popcll(m3)));
+      atomicAdd(&g_tim[6], (unsigned long long)((m1 != 0) + (m2 != 0) + (m3 != 0)));
+      atomicAdd(&g_tim[7], 1ull);
+    }
+  }
+#endif
+  if (!okr) okr = find_element_neighbours<true>(P.rnode, P.RE, P.rAdj, X, Y, er, rn);
+  if (!oku) oku = find_element_neighbours<false>(P.unode, P.UE, P.uAdj, X, Y, eu, un);
+  if (!okv) okv = find_element_neighbours<false>(P.vnode, P.VE, P.vAdj, X, Y, ev, vn);
+}
+
+// setEle for the three grids, executed by the WHOLE wave.  The first probe of each grid
+// (the stored element) is per lane as in find_elements3.  Few lanes need the neighbour
+// walk (a particle that changed cell: ~3 % of the lane-grids per step), but almost every
+// wave has some, and a per-lane walk makes the wave sit through up to nine dependent
+// probes per grid for two or three busy lanes.  Here the walks are TASKS (lane, grid) in
+// the wave's LDS scratch and each of 63 lanes takes ONE probe of one task (7 tasks x the
+// 9 neighbour entries of the adjacency row per round): three dependent loads and one
+// gridcell test for all of them; the first hit in row order wins and a zero entry ends
+// the row, as hydrodynamic_module.f90:1462-1475.
+struct EleScratch {
+  double X[192], Y[192];
+  int ele[192];
+  unsigned char owner[192], grid[192];
+  int found[3][64];
+};
+
+LT_DEV void wave_set_ele(const StepParams& P, EleScratch& S, bool want, double X, double Y, int& er,
+                         int& eu, int& ev, bool& okr, bool& oku, bool& okv) {
+  const int lane = threadIdx.x & 63;
+  okr = oku = okv = true;
+  if (want) {
+    const int4 rn = P.RE[er - 1], un = P.UE[eu - 1], vn = P.VE[ev - 1];
+    const Quad qr = load_quad_rho(P.rnode, rn);
+    const Quad qu = load_quad_xy(P.unode, un);
+    const Quad qv = load_quad_xy(P.vnode, vn);
+    okr = gridcell_one(qr.x, qr.y, X, Y);
+    oku = gridcell_one(qu.x, qu.y, X, Y);
+    okv = gridcell_one(qv.x, qv.y, X, Y);
+  }
+  int T = 0;  // wave-uniform
+  const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int g = 0; g < 3; g++) {
+    const bool need = !((g == 0) ? okr : (g == 1) ? oku : okv);
+    const unsigned long long m = __ballot(need);
+    if (need) {
+      const int idx = T + __popcll(m & below);
+      S.X[idx] = X; S.Y[idx] = Y;
+      S.ele[idx] = (g == 0) ? er : (g == 1) ? eu : ev;
+      S.owner[idx] = (unsigned char)lane; S.grid[idx] = (unsigned char)g;
+      S.found[g][lane] = 0;
+    }
+    T += __popcll(m);
+  }
+  if (T == 0) return;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+  for (int base = 0; base < T; base += 7) {
+    const int grp = lane / 9, pr = lane - grp * 9;  // probe = entry pr+2 of the row (1-based)
+    const int t = base + grp;
+    const bool valid = lane < 63 && t < T;
+    bool hit = false;
+    int cand = 0;
+    if (valid) {
+      const int g = S.grid[t];
+      const int* Adj = (g == 0) ? P.rAdj : (g == 1) ? P.uAdj : P.vAdj;
+      cand = Adj[(size_t)(S.ele[t] - 1) * 10 + pr + 1];
+      if (cand != 0) {
+        const int4* EL = (g == 0) ? P.RE : (g == 1) ? P.UE : P.VE;
+        const int4 nn = EL[cand - 1];
+        const char* nb = (g == 0) ? (const char*)P.rnode : (g == 1) ? (const char*)P.unode : (const char*)P.vnode;
+        const size_t st = (g == 0) ? sizeof(RhoNode) : sizeof(XYNode);
+        const XYNode a = *(const XYNode*)(nb + (size_t)(nn.x - 1) * st), b = *(const XYNode*)(nb + (size_t)(nn.y - 1) * st),
+                     c = *(const XYNode*)(nb + (size_t)(nn.z - 1) * st), d = *(const XYNode*)(nb + (size_t)(nn.w - 1) * st);
+        const double qx[4] = {a.x, b.x, c.x, d.x}, qy[4] = {a.y, b.y, c.y, d.y};
+        hit = gridcell_one(qx, qy, S.X[t], S.Y[t]);
+      }
+    }
+    const unsigned long long mh = __ballot(hit), mz = __ballot(valid && cand == 0);
+    if (valid && hit) {
+      const unsigned gh = (unsigned)(mh >> (9 * grp)) & 0x1ffu, gz = (unsigned)(mz >> (9 * grp)) & 0x1ffu;
+      const unsigned before = (1u << pr) - 1u;
+      // the first hit of the row, and no zero entry (= end of the list) before it
+      if ((gh & before) == 0 && (gz & before) == 0) S.found[S.grid[t]][S.owner[t]] = cand;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (!okr) { const int c = S.found[0][lane]; if (c) { er = c; okr = true; } }
+  if (!oku) { const int c = S.found[1][lane]; if (c) { eu = c; oku = true; } }
+  if (!okv) { const int c = S.found[2][lane]; if (c) { ev = c; okv = true; } }
 }
 
 // --------------------------------------------------- point in polygon
@@ -1830,24 +1968,36 @@ __global__ __launch_bounds__(256) void k_vt_walk(const StepParams P) {
 }
 
 __global__ __launch_bounds__(256) void k_post(const StepParams P) {
+#ifdef LT_POST_TIMING
+  __shared__ unsigned long long ptim[32];
+  if (threadIdx.x < 32) ptim[threadIdx.x] = 0;
+  __syncthreads();
+  unsigned long long tprev_ = __builtin_readcyclecounter();
+#endif
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned c_err = 0, c_brute = 0, c_pipslow = 0;
-  if (n < P.numpar) {
-    const size_t N = (size_t)P.numpar;
-    double* par = P.par + n;
-    const double* wsd = P.ws_d + n;
+  __shared__ EleScratch esc[4];
+  // Part 1 (per lane): behaviour, new position, boundaries.  Part 2 (whole wave): setEle on
+  // the new position.  Part 3 (per lane): settlement, error handling, commit.
+  const bool inrange = n < P.numpar;
+  const size_t N = (size_t)P.numpar;
+  double* par = P.par + (inrange ? n : 0);
+  const double* wsd = P.ws_d + (inrange ? n : 0);
 #define PARV(k) par[(size_t)(k) * N]
-    const int fl = P.ws_i[n];
-    const bool act = (fl & FL_ACT) != 0;
-    bool keep_pn = (fl & FL_KEEP_PN) != 0;
-    int err = fl >> FL_ERR_SHIFT;
-    const double X = PARV(pX), Y = PARV(pY);
-    double Z = act ? wsd[(size_t)WS_ZPAR * N] : PARV(pZ);
-    double nX = X, nY = Y, nZ = Z, lifespan = 0.0;
-    bool set_lifespan = false, verified = false;
+  const int fl = inrange ? P.ws_i[n] : 0;
+  const bool act = (fl & FL_ACT) != 0;
+  bool keep_pn = (fl & FL_KEEP_PN) != 0;
+  int err = fl >> FL_ERR_SHIFT;
+  double X = 0.0, Y = 0.0, Z = 0.0;
+  if (inrange) { X = PARV(pX); Y = PARV(pY); Z = act ? wsd[(size_t)WS_ZPAR * N] : PARV(pZ); }
+  double nX = X, nY = Y, nZ = Z, lifespan = 0.0, age = 0.0, P_depth = 0.0;
+  bool set_lifespan = false, verified = false, want_ele = false;
+  double eX = 0.0, eY = 0.0;
+  {
     if (act) {
-      const double age = PARV(pAge);
-      const double P_depth = wsd[(size_t)WS_PDEPTH * N], P_zetac = wsd[(size_t)WS_ZETA1 * N];
+      age = PARV(pAge);
+      P_depth = wsd[(size_t)WS_PDEPTH * N];
+      const double P_zetac = wsd[(size_t)WS_ZETA1 * N];
       const double cosA = wsd[(size_t)WS_COSA * N], sinA = wsd[(size_t)WS_SINA * N];
       const double P_U = wsd[(size_t)WS_SUMU * N] / 6.0, P_V = wsd[(size_t)WS_SUMV * N] / 6.0,
                    P_W = wsd[(size_t)WS_SUMW * N] / 6.0;
@@ -1951,6 +2101,9 @@ __global__ __launch_bounds__(256) void k_post(const StepParams P) {
         newZpos = P_depth + (double)0.000001f;
         if (P.TrackCollisions) P.hitBottom[n] += 1;
       }
+#ifdef LT_POST_TIMING
+      { const unsigned long long t_=__builtin_readcyclecounter(); if ((threadIdx.x&63)==0) ptim[(threadIdx.x>>6)*8+0] += t_-tprev_; tprev_=__builtin_readcyclecounter(); }
+#endif
       // horizontal boundaries :1180-1232
       double Xpos = X, Ypos = Y, nXpos = newXpos, nYpos = newYpos;
       int skipbound = -1, reflects = 0;
@@ -1975,6 +2128,9 @@ __global__ __launch_bounds__(256) void k_post(const StepParams P) {
         }
         Xpos = H.fix; Ypos = H.fiy; nXpos = H.frx; nYpos = H.fry;
       }
+#ifdef LT_POST_TIMING
+      { const unsigned long long t_=__builtin_readcyclecounter(); if ((threadIdx.x&63)==0) ptim[(threadIdx.x>>6)*8+1] += t_-tprev_; tprev_=__builtin_readcyclecounter(); }
+#endif
       if (!done) {
         newXpos = nXpos;
         newYpos = nYpos;
@@ -2007,27 +2163,34 @@ __global__ __launch_bounds__(256) void k_post(const StepParams P) {
             err = 26;
           } else {
             nX = newXpos; nY = newYpos; nZ = newZpos;  // :1312-1314
-            // setEle on the new position :1317
-            int er = P.P_r_element[n], eu = P.P_u_element[n], ev = P.P_v_element[n];
-            int4 nr, nu, nv;
-            bool okr2, oku2, okv2;
-            find_elements3(P, nXpos, nYpos, er, eu, ev, nr, nu, nv, okr2, oku2, okv2);
-            P.P_r_element[n] = er; P.P_u_element[n] = eu; P.P_v_element[n] = ev;
-            if (!okv2) err = 29; else if (!oku2) err = 28; else if (!okr2) err = 27;
-            verified = (err == 0);  // the committed position lies in the stored elements
-            if (err == 0 && P.settlementon) {
-              // testSettlement with the OLD position and the NEW element :1375
-              if (age >= P.settletime[n]) {
-                int inpoly = test_settlement(P, X, Y, er);
-                if (inpoly > 0) {
-                  P.settle[n] = 1;
-                  nZ = P_depth;
-                  P.endpoly[n] = inpoly;
-                  lifespan = age;
-                  set_lifespan = true;
-                }
-              }
-            }
+            want_ele = true;  // setEle on the new position :1317, by the whole wave below
+            eX = nXpos; eY = nYpos;
+          }
+        }
+      }
+    }
+  }
+  // Part 2: setEle :1317
+  int er = 1, eu = 1, ev = 1;
+  if (want_ele) { er = P.P_r_element[n]; eu = P.P_u_element[n]; ev = P.P_v_element[n]; }
+  bool okr2, oku2, okv2;
+  wave_set_ele(P, esc[threadIdx.x >> 6], want_ele, eX, eY, er, eu, ev, okr2, oku2, okv2);
+  // Part 3
+  if (inrange) {
+    if (want_ele) {
+      P.P_r_element[n] = er; P.P_u_element[n] = eu; P.P_v_element[n] = ev;
+      if (!okv2) err = 29; else if (!oku2) err = 28; else if (!okr2) err = 27;
+      verified = (err == 0);  // the committed position lies in the stored elements
+      if (err == 0 && P.settlementon) {
+        // testSettlement with the OLD position and the NEW element :1375
+        if (age >= P.settletime[n]) {
+          int inpoly = test_settlement(P, X, Y, er);
+          if (inpoly > 0) {
+            P.settle[n] = 1;
+            nZ = P_depth;
+            P.endpoly[n] = inpoly;
+            lifespan = age;
+            set_lifespan = true;
           }
         }
       }
@@ -2053,6 +2216,11 @@ __global__ __launch_bounds__(256) void k_post(const StepParams P) {
     if (set_lifespan) PARV(pLifespan) = lifespan;
 #undef PARV
   }
+#ifdef LT_POST_TIMING
+  { const unsigned long long t_=__builtin_readcyclecounter(); if ((threadIdx.x&63)==0) ptim[(threadIdx.x>>6)*8+4] += t_-tprev_; }
+  __syncthreads();
+  if (threadIdx.x < 8) atomicAdd(&g_tim[threadIdx.x], ptim[threadIdx.x] + ptim[8+threadIdx.x] + ptim[16+threadIdx.x] + ptim[24+threadIdx.x]);
+#endif
   __shared__ unsigned red[3];
   if (threadIdx.x < 3) red[threadIdx.x] = 0;
   if (blockIdx.x == 0) {  // total of k_pre's per-block counts of tracked particles
