@@ -227,11 +227,10 @@ struct EleScratch {
 };
 
 LT_DEV void wave_set_ele(const StepParams& P, EleScratch& S, bool want, double X, double Y, int& er,
-                         int& eu, int& ev, bool& okr, bool& oku, bool& okv) {
+                         int& eu, int& ev, int4 rn, int4 un, int4 vn, bool& okr, bool& oku, bool& okv) {
   const int lane = threadIdx.x & 63;
   okr = oku = okv = true;
   if (want) {
-    const int4 rn = P.RE[er - 1], un = P.UE[eu - 1], vn = P.VE[ev - 1];
     const Quad qr = load_quad_rho(P.rnode, rn);
     const Quad qu = load_quad_xy(P.unode, un);
     const Quad qv = load_quad_xy(P.vnode, vn);
@@ -1993,6 +1992,14 @@ __global__ __launch_bounds__(256) void k_post(const StepParams P) {
   double nX = X, nY = Y, nZ = Z, lifespan = 0.0, age = 0.0, P_depth = 0.0;
   bool set_lifespan = false, verified = false, want_ele = false;
   double eX = 0.0, eY = 0.0;
+  // the stored elements and their node ids are what the closing setEle probes first: asked
+  // for now, they arrive while part 1 runs
+  int er = 1, eu = 1, ev = 1;
+  int4 rn0 = make_int4(1, 1, 1, 1), un0 = rn0, vn0 = rn0;
+  if (act) {
+    er = P.P_r_element[n]; eu = P.P_u_element[n]; ev = P.P_v_element[n];
+    rn0 = P.RE[er - 1]; un0 = P.UE[eu - 1]; vn0 = P.VE[ev - 1];
+  }
   {
     if (act) {
       age = PARV(pAge);
@@ -2171,10 +2178,8 @@ __global__ __launch_bounds__(256) void k_post(const StepParams P) {
     }
   }
   // Part 2: setEle :1317
-  int er = 1, eu = 1, ev = 1;
-  if (want_ele) { er = P.P_r_element[n]; eu = P.P_u_element[n]; ev = P.P_v_element[n]; }
   bool okr2, oku2, okv2;
-  wave_set_ele(P, esc[threadIdx.x >> 6], want_ele, eX, eY, er, eu, ev, okr2, oku2, okv2);
+  wave_set_ele(P, esc[threadIdx.x >> 6], want_ele, eX, eY, er, eu, ev, rn0, un0, vn0, okr2, oku2, okv2);
   // Part 3
   if (inrange) {
     if (want_ele) {
