@@ -84,6 +84,7 @@ struct StepParams {
   // ex(2)-ex(3), ex(1)-ex(2), ex(1)-ex(3), 4*ws, 6; fastdiv = 0 falls back to '/'
   double r_d23, r_d12, r_d13, r_p2, r_6;
   int fastdiv;
+  int pns0, pns1, pns2;  // polintd's closest time node (1..3) for ix(1), ix(2), ix(3)
   // ---- options
   int Behavior, OpenOceanBoundary, mortality, settlementon, holesExist, ErrorFlag, TrackCollisions;
   double swimstart, swimfast, sink;

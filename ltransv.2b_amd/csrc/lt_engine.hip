@@ -1269,6 +1269,20 @@ static int step_prepare(lt_engine* e, const double* ex3, const double* ix3, int3
   }
   P.ix0 = ix3[0]; P.ix1 = ix3[1]; P.ix2 = ix3[2];
   P.p = p; P.it = it;
+  {
+    // polintd's choice of the closest node (interpolation_module.f90:85-92) depends on the
+    // times only
+    int ns[3];
+    for (int i = 0; i < 3; i++) {
+      const double x = ix3[i];
+      ns[i] = 1;
+      double dif = std::fabs(x - ex3[0]), dift = std::fabs(x - ex3[1]);
+      if (dift < dif) { ns[i] = 2; dif = dift; }
+      dift = std::fabs(x - ex3[2]);
+      if (dift < dif) { ns[i] = 3; dif = dift; }
+    }
+    P.pns0 = ns[0]; P.pns1 = ns[1]; P.pns2 = ns[2];
+  }
   HIPCHK(e, hipMemsetAsync(e->counters.p, 0, CNT_COUNT * sizeof(unsigned long long), e->stream));
   const unsigned blocks = (unsigned)((e->cfg.numpar + 255) / 256);
   const bool beh_draws = e->cfg.Behavior >= 1 && e->cfg.Behavior <= 5;

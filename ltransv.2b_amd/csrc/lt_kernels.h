@@ -1543,13 +1543,10 @@ LT_DEV double hval_table(double T, int n, const double* x, const double* y, cons
 // polintd at the three internal times ix(1..3) of one (ex, ey) triple
 // (ver_turb_module.f90:236-238,258-260): the two inner quotients of polintd do
 // not depend on x, so they are formed once (same values, 5 divisions instead of 9).
+// (ns, the node of the time axis closest to x, is the same for every particle: the host
+// finds it once per step with polintd's own comparisons, StepParams::pns)
 LT_DEV double polintd_shared(double xa1, double xa2, double xa3, double ya1, double ya2, double ya3,
-                             double q32, double q21, double r13, bool fd, double x) {
-  int ns = 1;
-  double dif = fabs(x - xa1), dift = fabs(x - xa2);
-  if (dift < dif) { ns = 2; dif = dift; }
-  dift = fabs(x - xa3);
-  if (dift < dif) { ns = 3; dif = dift; }
+                             double q32, double q21, double r13, bool fd, double x, int ns) {
   double c = (xa2 - x) * q32;
   c = c - (xa2 - x) * q21;
   c = div_by(c, xa1 - xa3, r13, fd);
@@ -1567,9 +1564,9 @@ LT_DEV void polintd3x3(const StepParams& P, double ya1, double ya2, double ya3,
   const bool fd = P.fastdiv != 0;
   const double q32 = div_by(ya3 - ya2, xa2 - xa3, P.r_d23, fd);
   const double q21 = div_by(ya2 - ya1, xa1 - xa2, P.r_d12, fd);
-  rb = polintd_shared(xa1, xa2, xa3, ya1, ya2, ya3, q32, q21, P.r_d13, fd, P.ix0);
-  rc = polintd_shared(xa1, xa2, xa3, ya1, ya2, ya3, q32, q21, P.r_d13, fd, P.ix1);
-  rf = polintd_shared(xa1, xa2, xa3, ya1, ya2, ya3, q32, q21, P.r_d13, fd, P.ix2);
+  rb = polintd_shared(xa1, xa2, xa3, ya1, ya2, ya3, q32, q21, P.r_d13, fd, P.ix0, P.pns0);
+  rc = polintd_shared(xa1, xa2, xa3, ya1, ya2, ya3, q32, q21, P.r_d13, fd, P.ix1, P.pns1);
+  rf = polintd_shared(xa1, xa2, xa3, ya1, ya2, ya3, q32, q21, P.r_d13, fd, P.ix2, P.pns2);
 }
 
 // The interval of the VTurb spline table a walk is in, kept in registers: HVAL and
