@@ -85,6 +85,19 @@ def pmc_traffic(tag, kernels, n, args):
     return tot, "profiles/%s/pmc.json" % tag
 
 
+def valu_issue(valu, kernels, n, k_avg_s):
+    """The bound that actually applies: VALU instruction issue.  PMC
+    instruction count per particle-step (committed profile) x particles / live kernel time,
+    against the MI355X vector rate of 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3e12
+    lane-operations/s (the 78.6 TFLOP/s fp64 vector peak counts an FMA as two)."""
+    if not valu or k_avg_s <= 0 or any(k not in valu for k in kernels):
+        return None
+    per = sum(valu[k]["valu_instr_per_particle_step"] for k in kernels)
+    ach = per * n / k_avg_s / 1e12
+    return {"achieved": ach, "peak": 39.3, "unit": "T lane-ops/s", "frac": ach / 39.3,
+            "valu_instr_per_particle_step": per}
+
+
 def build_inputs(vi, uj, us, numpar, seed):
     from ltrans_amd import roms_synth as rs
     g = rs.make_grid(vi, uj, us)
@@ -374,6 +387,7 @@ def main():
                      "traffic_source": traffic_src,
                      "kernel": "+".join(kernels), "kernel_ms_avg": k_avg_s * 1e3,
                      "valu_pmc": getattr(pmc_traffic, "valu", None),
+                     "valu_issue": valu_issue(getattr(pmc_traffic, "valu", None), kernels, n, k_avg_s),
                      "algorithmic_bytes_per_launch": A * n,
                      "algorithmic_bytes_per_particle_step": A},
     }
