@@ -60,3 +60,18 @@ def test_set_rng_mid_batch(oracle):
     oracle.lto_genrand_fill(C.byref(st), C.c_uint64(0), C.c_int(3000), exp.ctypes.data_as(C.c_void_p))
     assert np.array_equal(out, exp)
     e.close()
+
+
+def test_ring_far_into_the_stream(oracle):
+    """3e9 words in (past 2^31: 64-bit stream positions, ~2900 blocks, every generator
+    state jumped ~22 times), as a long turbulence run gets after a few dozen steps"""
+    seed = 9
+    cfg = ltrans_amd.LtConfig(numpar=4, us=8, ws=9, seed=seed)
+    e = ltrans_amd.Engine(cfg)
+    f = e.lib.lt_test_mt_ring
+    f.restype = C.c_int
+    off = 3_000_000_123
+    out = np.zeros(2000, dtype=np.uint32)
+    assert f(e._h, C.c_uint64(off), C.c_int32(out.size), out.ctypes.data_as(C.c_void_p)) == 0
+    assert np.array_equal(out, _oracle_stream(oracle, seed, off, out.size))
+    e.close()
