@@ -1428,7 +1428,7 @@ int lt_get_stats(lt_engine* e, lt_step_stats* out) {
 
 /* diagnostics of the last step: [0] active [1] errors [2] SigErr fallbacks
  * [3] brute-force boundary scans [4] full point-in-polygon evaluations */
-#if defined(LT_RK_TIMING) || defined(LT_POST_TIMING)
+#ifdef LT_RK_TIMING
 int lt_diag(unsigned long long* out) {
   hipDeviceSynchronize();
   hipMemcpyFromSymbol(out, HIP_SYMBOL(ltd::g_tim), 64);

@@ -1,0 +1,871 @@
+// lt_rk.h -- field access, the wave-cooperative find_currents (pass A / B / C) and the kernels
+// k_pre, k_beh_pre, k_rk, k_rk_slow.
+// Part of lt_kernels.h (included inside namespace ltd); see the notes there.
+#pragma once
+
+// ---------------------------------------------------- field access
+template <typename SlabT>
+LT_DEV double fld(const SlabT* F, int node, int L, int k, int ps) {
+  return (double)F[((size_t)(node - 1) * L + (k - 1)) * LT_SLOTS + ps];
+}
+
+// the per-particle context that find_currents needs (registers)
+struct Column {
+  double zeta[3];   // zetab, zetac, zetaf at the particle (roles b,c,f)
+  double h;         // -P_depth
+  double Pz[3];     // P_zb, P_zc, P_zf
+  double wz1[3];    // Pwc_wz{b,c,f}(1)
+  double z1[3];     // Pwc_z{b,c,f}(1)
+};
+
+// s-level depth split into its zeta-independent part (one division per level
+// instead of one per level and slot): the operations and their order are those
+// of getSlevel/getWlevel (hydrodynamic_module.f90:2691-2777).
+struct LevCoef { double a, b, c; };
+LT_DEV LevCoef level_coef(const double* tab, int k, double h, double hc, int Vtransform) {
+  LevCoef r;
+  double A = tab[k - 1];
+  double B = tab[LT_LEV_STRIDE + k - 1];
+  if (Vtransform == 1) {
+    double S = A + (h - hc) * B;
+    r.a = S; r.b = 1.0 + S / h; r.c = 0.0;
+  } else if (Vtransform == 2) {
+    r.a = (A + h * B) / (hc + h); r.b = 0.0; r.c = 0.0;
+  } else {
+    r.a = A; r.b = 1.0 + tab[2 * LT_LEV_STRIDE + k - 1]; r.c = (h - hc) * B;
+  }
+  return r;
+}
+// the same with the per-particle divisor prepared once: dv = h (Vtransform 1) or hc + h (2)
+LT_DEV LevCoef level_coef_d(const double* tab, int k, double h, double hc, int Vtransform, const Divisor& dv) {
+  LevCoef r;
+  double A = tab[k - 1];
+  double B = tab[LT_LEV_STRIDE + k - 1];
+  if (Vtransform == 1) {
+    double S = A + (h - hc) * B;
+    r.a = S; r.b = 1.0 + div_prep(S, dv); r.c = 0.0;
+  } else if (Vtransform == 2) {
+    r.a = div_prep(A + h * B, dv); r.b = 0.0; r.c = 0.0;
+  } else {
+    r.a = A; r.b = 1.0 + tab[2 * LT_LEV_STRIDE + k - 1]; r.c = (h - hc) * B;
+  }
+  return r;
+}
+LT_DEV double level_at(const LevCoef& q, double zeta, double h, int Vtransform) {
+  if (Vtransform == 1) return q.a + zeta * q.b;
+  if (Vtransform == 2) return zeta + (zeta + h) * q.a;
+  return zeta * q.b + q.a + q.c;
+}
+
+
+// per-wave LDS scratch of the batched passes.  Two task kinds:
+//   check: a non-evaluation interval that may need the convexity Newton
+//          iteration; only its convergence matters (SigErr): (num, den) of T;
+//   eval:  the evaluation interval's tension is not known without iterating:
+//          the task carries the interval, the lane that iterates evaluates HVAL.
+// Results of all 9 (variable, slot) fits of a stage are collected in res[][lane].
+#ifdef LT_RK_TIMING
+// development aid: wave time per section, accumulated in the wave's LDS scratch and
+// added to g_tim once at the end of the kernel
+__device__ unsigned long long g_tim[8];
+#define TICK(slot) do { const unsigned long long t_ = __builtin_readcyclecounter(); if ((threadIdx.x & 63) == 0) ws.tim[slot] += t_ - tprev_; tprev_ = __builtin_readcyclecounter(); } while (0)
+#define TICK_INIT unsigned long long tprev_ = __builtin_readcyclecounter()
+#else
+#ifdef LT_RK_MARK
+#define TICK(slot) asm volatile("; MARK " #slot)
+#else
+#define TICK(slot) do { } while (0)
+#endif
+#define TICK_INIT do { } while (0)
+#endif
+// One variable's three time slots are queued, then iterated (pass B), then combined in
+// time (pass C): at most 3 x 64 evaluation intervals and 6 x 64 check intervals.  The
+// evaluation queue holds the worst case; a check interval that finds the queue full
+// (never seen: ~1 % of them are candidates) sends its particle-step to k_rk_slow.
+#define LT_CHK_CAP 256
+#define LT_EV_CAP 192
+struct WaveScratch {
+  double chk[LT_CHK_CAP][2];         // num, den of T = MAX(D1/D2, D2/D1)
+  unsigned short chk_owner[LT_CHK_CAP];  // lane | slot9 << 6
+  double ev[LT_EV_CAP][7];           // x1,x2,y1,p1,p2,S,Pz
+  unsigned short ev_owner[LT_EV_CAP];
+  double res[3][64];                 // H(P_z) per (slot, lane) of the current variable
+  unsigned int errmask[64];          // bit (variable*3+slot): SigErr / degenerate window
+#ifdef LT_RK_TIMING
+  unsigned long long tim[8];
+#endif
+};
+
+// pass B: the queued iterations, 64 at a time, all lanes of the wave.  Evaluation
+// intervals and check intervals share the batches, so the wave runs ONE Newton loop per
+// batch whatever the mix (a separate loop for the few check intervals cost as much as the
+// one for the evaluation intervals).
+LT_DEV void run_tasks(WaveScratch& ws, int nchk, int nev, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int total = nev + nchk;
+#pragma unroll 1
+  for (int t = lane; t < total; t += 64) {
+    const bool is_ev = t < nev;
+    const double* e = ws.ev[is_ev ? t : 0];
+    const int tc = is_ev ? 0 : (t - nev);
+    const unsigned short o = is_ev ? ws.ev_owner[t] : ws.chk_owner[tc];
+    double sg = 0.0, T = 0.0;
+    int kind;
+    if (is_ev) {
+      // the evaluation interval: full SIGS decision
+      kind = sigs_classify(e[5], e[3], e[4], sg, T);
+    } else {
+      // a non-evaluation interval: only the convergence of its Newton iteration matters
+      T = ws.chk[tc][0] / ws.chk[tc][1];
+      kind = (T > 2.0) ? SIGK_NEWTON : SIGK_DONE;
+    }
+    bool failed = false;
+    if (kind == SIGK_NEWTON) sg = sigs_newton(T, failed);
+    else if (kind == SIGK_SECANT) sg = sigs_secant(e[5], e[3], e[4]);  // rare
+    if (is_ev) ws.res[(o >> 6) % 3][o & 63] = hval_interval_s(e[6], e[0], e[1], e[2], e[3], e[4], e[5], sg);
+    if (failed) atomicOr(&ws.errmask[o & 63], 1u << (o >> 6));
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// find_currents, LTRANS.f90:1422-1614, executed by the WHOLE wave: lanes whose
+// particle is not tracked (act = false) only take part in the cooperative pass.
+// Per-particle constants of the water column are read from the step workspace
+// (coalesced, L2-resident) where needed instead of living in registers.
+template <typename SlabT, int VT>
+LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& ws, bool act, int n,
+                          int er, int eu, int ev_, double h, const Divisor& dv, double Xs, double Ys, double Zs, int version,
+                          double& Uad, double& Vad, double& Wad, int& sigerr_count, bool& slow) {
+  const double* rtab = lev;
+  const double* wtab = lev + 3 * LT_LEV_STRIDE;
+  const int lane = threadIdx.x & 63;
+  const size_t N = (size_t)P.numpar;
+  const double* wsd = P.ws_d + (act ? n : 0);
+  TICK_INIT;
+  Uad = 0.0; Vad = 0.0; Wad = 0.0;
+  // regime tests :1481-1491
+  bool zero = false, loglayer = false;
+  int ii = 1, iii = 1;
+  double wzb1 = 0.0;
+  if (act) {
+    const double zb = wsd[(size_t)WS_ZETA0 * N], zc = wsd[(size_t)WS_ZETA1 * N], zf = wsd[(size_t)WS_ZETA2 * N];
+    const LevCoef w1 = level_coef_d(wtab, 1, h, P.hc, VT, dv);
+    const LevCoef r1 = level_coef_d(rtab, 1, h, P.hc, VT, dv);
+    wzb1 = level_at(w1, zb, h, VT);
+    const double wzc1 = level_at(w1, zc, h, VT), wzf1 = level_at(w1, zf, h, VT);
+    zero = (Zs < wzb1 + P.z0) || (Zs < wzc1 + P.z0) || (Zs < wzf1 + P.z0);
+    loglayer = !zero && ((Zs < level_at(r1, zb, h, VT)) || (Zs < level_at(r1, zc, h, VT)) ||
+                         (Zs < level_at(r1, zf, h, VT)));
+    if (!zero && !loglayer) {
+      // lowest 4-level windows :1451-1467 by bisection on the monotone level depths
+      int lo = 3, hi = P.us - 1;
+      while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        LevCoef q = level_coef_d(rtab, mid, h, P.hc, VT, dv);
+        bool below = (Zs < level_at(q, zb, h, VT)) || (Zs < level_at(q, zc, h, VT)) ||
+                     (Zs < level_at(q, zf, h, VT));
+        if (below) hi = mid; else lo = mid + 1;
+      }
+      ii = lo - 2;
+      lo = 3; hi = P.ws - 1;
+      while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        LevCoef q = level_coef_d(wtab, mid, h, P.hc, VT, dv);
+        bool below = (Zs < level_at(q, zb, h, VT)) || (Zs < level_at(q, zc, h, VT)) ||
+                     (Zs < level_at(q, zf, h, VT));
+        if (below) hi = mid; else lo = mid + 1;
+      }
+      iii = lo - 2;
+    }
+  }
+  const bool spl = act && !zero && !loglayer;  // this lane fits splines
+  unsigned degenerate = 0;
+  const double ixv = (version == 1) ? P.ix0 : (version == 2) ? P.ix1 : P.ix2;
+  ws.errmask[lane] = 0;
+  TICK(0);
+  // ---------------- pass A: fit without iterating, queue what must iterate.
+  // Memory latency is taken off the critical path by asking early: the node ids of the
+  // NEXT variable's element, and the 4x4 field values + zeta + depth of the NEXT time
+  // slot, are requested before the arithmetic of the current one (same registers: the
+  // raw values are dead once the horizontal interpolation has produced Y).
+  int4 nd_next = make_int4(1, 1, 1, 1);
+  if (act && !zero) nd_next = P.UE[eu - 1];
+  double zt = 0.0, pz = 0.0;
+  SlabT raw[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) raw[i] = (SlabT)0;
+#pragma unroll 1
+  for (int var = 0; var < 3; var++) {
+    const int4 nd = nd_next;
+    const SlabT* F = (const SlabT*)((var == 0) ? P.U : (var == 1) ? P.V : P.W);
+    const int L = (var == 2) ? P.ws : P.us;
+    const double* tab = (var == 2) ? wtab : rtab;
+    const int k0 = (var == 2) ? iii : ii;
+    int nchk = 0, nev = 0;  // wave-uniform task counts of this variable
+    // The 16 field values (4 nodes x 4 levels) of a time slot, its zeta and its depth are
+    // requested one slot ahead of their use, into the registers the previous slot's values
+    // just left (they are dead once the horizontal interpolation has produced Y).
+    const SlabT *b0 = F, *b1 = F, *b2 = F, *b3 = F;
+    if (spl) {
+      b0 = F + ((size_t)(nd.x - 1) * L + (k0 - 1)) * LT_SLOTS;
+      b1 = F + ((size_t)(nd.y - 1) * L + (k0 - 1)) * LT_SLOTS;
+      b2 = F + ((size_t)(nd.z - 1) * L + (k0 - 1)) * LT_SLOTS;
+      b3 = F + ((size_t)(nd.w - 1) * L + (k0 - 1)) * LT_SLOTS;
+    }
+    auto request = [&](int s) {
+      const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
+#pragma unroll
+      for (int l = 0; l < 4; l++) {
+        raw[4 * l + 0] = b0[LT_SLOTS * l + ps]; raw[4 * l + 1] = b1[LT_SLOTS * l + ps];
+        raw[4 * l + 2] = b2[LT_SLOTS * l + ps]; raw[4 * l + 3] = b3[LT_SLOTS * l + ps];
+      }
+      zt = wsd[(size_t)(WS_ZETA0 + s) * N];
+      pz = wsd[(size_t)(WS_PZ0 + s) * N];
+    };
+    if (spl) request(0);
+    QuadWeights w;
+    w.regime = 1; w.node_hit = 0; w.t = w.u = w.W1 = w.W2 = w.W3 = w.W4 = 0.0;
+    if (act && !zero) {
+      Quad q;
+      if (var == 2) q = load_quad_rho(P.rnode, nd);
+      else if (var == 0) q = load_quad_xy(P.unode, nd);
+      else q = load_quad_xy(P.vnode, nd);
+      if (var == 0) nd_next = P.VE[ev_ - 1];
+      else if (var == 1) nd_next = P.RE[er - 1];
+      w = quad_weights(Xs, Ys, q.x, q.y);
+    }
+    TICK(1);
+    if (loglayer) {
+      // log layer :1493-1522: level 1 of u,v; level 2 of w
+      const int k = (var == 2) ? 2 : 1;
+      const LevCoef qt = level_coef_d((var == 2) ? wtab : rtab, k, h, P.hc, VT, dv);
+#pragma unroll
+      for (int s = 0; s < 3; s++) {
+        const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
+        const double zeta = wsd[(size_t)(WS_ZETA0 + s) * N];
+        double val = apply_interp(w, fld(F, nd.x, L, k, ps), fld(F, nd.y, L, k, ps),
+                                  fld(F, nd.z, L, k, ps), fld(F, nd.w, L, k, ps));
+        double ztop = level_at(qt, zeta, h, VT);
+        ws.res[s][lane] = val * log10((Zs - wzb1) / P.z0) / log10((ztop - wzb1) / P.z0);
+      }
+    }
+    LevCoef lc[4];
+    if (spl) {
+#pragma unroll
+      for (int l = 0; l < 4; l++) lc[l] = level_coef_d(tab, k0 + l, h, P.hc, VT, dv);
+    }
+#pragma unroll 1
+    for (int s = 0; s < 3; s++) {
+      const int slot9 = var * 3 + s;
+      double YP[4], SL[3];
+      double x1 = 0.0, x2 = 0.0, y1 = 0.0, p1 = 0.0, p2 = 0.0, Sv = 0.0, Pzs = 0.0;
+      int I = 1;
+      bool ok = spl;
+      if (spl) {
+        const double zeta = zt;
+        Pzs = pz;
+        double X[4], Y[4];
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+          X[l] = level_at(lc[l], zeta, h, VT);
+          Y[l] = apply_interp(w, (double)raw[4 * l + 0], (double)raw[4 * l + 1],
+                              (double)raw[4 * l + 2], (double)raw[4 * l + 3]);
+        }
+        if (s < 2) request(s + 1);
+        const double DX1 = X[1] - X[0], DX2 = X[2] - X[1], DX3 = X[3] - X[2];
+        ok = (DX1 > 0.0) && (DX2 > 0.0) && (DX3 > 0.0);
+        if (!ok) degenerate |= (1u << slot9);
+        // YPC1 (tension_module.f90:852-977) with the chord slopes kept for SIGS/HVAL
+        // (seven quotients over five divisors: the reciprocals are prepared once)
+        const Divisor d1 = prep_div(DX1), d2 = prep_div(DX2), d3 = prep_div(DX3);
+        const Divisor d12 = prep_div(DX1 + DX2), d23 = prep_div(DX2 + DX3);
+        SL[0] = div_prep(Y[1] - Y[0], d1);
+        SL[1] = div_prep(Y[2] - Y[1], d2);
+        SL[2] = div_prep(Y[3] - Y[2], d3);
+        YP[0] = ypc1_end(SL[0], SL[0] + div_prep(DX1 * (SL[0] - SL[1]), d12));
+        YP[1] = ypc1_mid_d(DX1, DX2, d12, SL[0], SL[1]);
+        YP[2] = ypc1_mid_d(DX2, DX3, d23, SL[1], SL[2]);
+        YP[3] = ypc1_end(SL[2], SL[2] + div_prep(DX3 * (SL[2] - SL[1]), d23));
+        I = (Pzs < X[1]) ? 1 : (Pzs < X[2]) ? 2 : 3;
+        if (Pzs > X[3]) I = 3;
+        x1 = (I == 1) ? X[0] : (I == 2) ? X[1] : X[2];
+        x2 = (I == 1) ? X[1] : (I == 2) ? X[2] : X[3];
+        y1 = (I == 1) ? Y[0] : (I == 2) ? Y[1] : Y[2];
+        p1 = (I == 1) ? YP[0] : (I == 2) ? YP[1] : YP[2];
+        p2 = (I == 1) ? YP[1] : (I == 2) ? YP[2] : YP[3];
+        Sv = (I == 1) ? SL[0] : (I == 2) ? SL[1] : SL[2];
+      }
+      TICK(2);
+      // SIGS (tension_module.f90:448-776), screened without divisions or loops.
+      // Only the evaluation interval's tension is used by HVAL; the other two
+      // matter only through SigErr, which only the convexity Newton iteration
+      // can raise, so they are queued just when they are Newton candidates.
+      bool evdone = false;
+      double sigI = 0.0;
+      {
+        double n0, d0, n1, d1, n2, d2;
+        const bool c0 = ok && sigs_candidate(SL[0], YP[0], YP[1], n0, d0);
+        const bool c1 = ok && sigs_candidate(SL[1], YP[1], YP[2], n1, d1);
+        const bool c2 = ok && sigs_candidate(SL[2], YP[2], YP[3], n2, d2);
+        // the two non-evaluation intervals: I=1 -> (2,3), I=2 -> (1,3), I=3 -> (1,2)
+        const bool ca = (I == 1) ? c1 : c0, cb = (I == 3) ? c1 : c2;
+        const double na = (I == 1) ? n1 : n0, da = (I == 1) ? d1 : d0;
+        const double nb = (I == 3) ? n1 : n2, db = (I == 3) ? d1 : d2;
+        if (ok) evdone = sigs_eval_known(Sv, p1, p2, sigI);
+        const bool neede = ok && !evdone;
+        const unsigned long long ma = __ballot(ca), mb = __ballot(cb), me = __ballot(neede);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (ca) {
+          const int idx = nchk + __popcll(ma & below);
+          if (idx < LT_CHK_CAP) {
+            ws.chk[idx][0] = na; ws.chk[idx][1] = da;
+            ws.chk_owner[idx] = (unsigned short)(lane | (slot9 << 6));
+          } else degenerate |= (1u << slot9);
+        }
+        nchk += __popcll(ma);
+        if (cb) {
+          const int idx = nchk + __popcll(mb & below);
+          if (idx < LT_CHK_CAP) {
+            ws.chk[idx][0] = nb; ws.chk[idx][1] = db;
+            ws.chk_owner[idx] = (unsigned short)(lane | (slot9 << 6));
+          } else degenerate |= (1u << slot9);
+        }
+        nchk += __popcll(mb);
+        if (neede) {
+          const int idx = nev + __popcll(me & below);
+          double* e = ws.ev[idx];
+          e[0] = x1; e[1] = x2; e[2] = y1; e[3] = p1; e[4] = p2; e[5] = Sv; e[6] = Pzs;
+          ws.ev_owner[idx] = (unsigned short)(lane | (slot9 << 6));
+        }
+        nev += __popcll(me);
+#ifdef LT_RK_TIMING
+        { const unsigned long long mk = __ballot(evdone && sigI != 0.0);
+          if (lane == 0) { ws.tim[6] += __popcll(me); ws.tim[7] += __popcll(mk); } }
+#endif
+      }
+      // HVAL now when the evaluation interval's tension is already known
+      if (evdone) ws.res[s][lane] = hval_interval_s(Pzs, x1, x2, y1, p1, p2, Sv, sigI);
+      TICK(3);
+    }
+    // ---------------- pass B: everything of this variable that iterates
+    run_tasks(ws, (nchk < LT_CHK_CAP) ? nchk : LT_CHK_CAP, nev, lane);
+    TICK(4);
+    // ---------------- pass C: time interpolation :1534-1598 / hydrodynamic_module.f90:2653-2670
+    if (act && !zero) {
+      const double Pv0 = ws.res[0][lane], Pv1 = ws.res[1][lane], Pv2 = ws.res[2][lane];
+      double e1 = Pv0, e2 = Pv1, e3 = Pv2;
+      if (P.p == 1) { e2 = Pv0; e3 = Pv1; }
+      const double val = polintd3(P.ex0, P.ex1, P.ex2, e1, e2, e3, ixv);
+      if (var == 0) Uad = val; else if (var == 1) Vad = val; else Wad = val;
+    }
+    TICK(5);
+  }
+  if (act && !zero) {
+    const unsigned em = ws.errmask[lane];
+    if (em) sigerr_count += __popc(em);
+    if (spl && (degenerate | em)) slow = true;  // this particle-step is redone by k_rk_slow
+  }
+  // the next stage reuses the scratch: all lanes must have read their results
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  TICK(5);
+}
+
+// ------------------------------------------------------------ the step
+// update_particles() is run as three kernels over the same particle index so
+// that the register-hungry RK4 part does not carry the state of the element
+// search and boundary code (occupancy), exchanging 13 doubles + one flag word
+// per particle through a workspace in HBM (SoA, stride numpar):
+//   k_pre   gates, setEle, setInterp/getInterp, vertical clamps   (per lane)
+//   k_rk    RK4 over find_currents/WCTS_ITPI                      (wave-cooperative)
+//   k_post  behaviour, reflection, boundaries, setEle, settlement, commit
+
+template <typename SlabT>
+__global__ __launch_bounds__(256) void k_pre(const StepParams P) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned c_active = 0;
+  if (n < P.numpar) {
+    const size_t N = (size_t)P.numpar;
+    double* par = P.par + n;
+    double* wsd = P.ws_d + n;
+#define PARV(k) par[(size_t)(k) * N]
+    // Everything the gates may look at is requested at once (the kernel is a chain of
+    // dependent loads, not arithmetic): state, status flags, the stored elements and,
+    // through them, the nodes of the rho element.
+    const double X = PARV(pX), Y = PARV(pY);
+    double Z = PARV(pZ);
+    const double dob = PARV(pDOB), age0 = PARV(pAge);
+    const int settle_n = P.settlementon ? P.settle[n] : 0;
+    const double deadage_n = P.mortality ? P.P_deadage[n] : 0.0;
+    int dead_n = P.mortality ? P.dead[n] : 0;
+    const int oob_n = P.OpenOceanBoundary ? P.oob[n] : 0;
+    const int ele_ok = P.ele_ok[n];
+    int er = P.P_r_element[n], eu = P.P_u_element[n], ev = P.P_v_element[n];
+    int4 rn = P.RE[er - 1], un, vn;  // stored element ids are always valid ids
+    int flags = 0, err = 0;
+    // the gates of LTRANS.f90:790-816
+    const bool released = !(P.ix2 <= dob);
+    bool track = released;
+    if (released) {
+      double age = age0 + (double)(float)P.idt;
+      PARV(pAge) = age;
+      // updateStatus, behavior_module.f90:162-179
+      bool settled = P.settlementon ? (settle_n != 0) : false;
+      if (P.mortality && age >= deadage_n) {
+        if (!(P.settlementon && settled)) { P.dead[n] = 1; dead_n = 1; }
+      }
+      if (P.settlementon && settled) track = false;
+      if (track && P.mortality && dead_n != 0) track = false;
+      if (track && P.OpenOceanBoundary && oob_n != 0) track = false;
+      if (!track) flags |= FL_KEEP_PN;
+    }
+    if (track) {
+      // setEle :830 (all three grids are searched even after a miss).  When the
+      // previous step's closing setEle (:1317) found these very elements for this
+      // very position, the first probe of each grid is that element and succeeds
+      // again: the search is skipped and only the rho nodes are used.
+      bool okr = true, oku = true, okv = true;
+      if (!ele_ok) {
+        find_elements3(P, X, Y, er, eu, ev, rn, un, vn, okr, oku, okv);
+        P.P_r_element[n] = er; P.P_u_element[n] = eu; P.P_v_element[n] = ev;
+      }
+      if (!okv) err = 6; else if (!oku) err = 5; else if (!okr) err = 4;  // last assignment wins
+      if (err == 0) {
+        flags |= FL_ACT;
+        c_active = 1;
+        // setInterp + getInterp :882-896
+        RhoNode r1 = P.rnode[rn.x - 1], r2 = P.rnode[rn.y - 1], r3 = P.rnode[rn.z - 1],
+                r4 = P.rnode[rn.w - 1];
+        double qx[4] = {r1.x, r2.x, r3.x, r4.x}, qy[4] = {r1.y, r2.y, r3.y, r4.y};
+        const QuadWeights w0 = quad_weights(X, Y, qx, qy);
+        const double P_depth = -1.0 * apply_getinterp(w0, r1.depth, r2.depth, r3.depth, r4.depth);
+        const double P_angle = apply_getinterp(w0, r1.angle, r2.angle, r3.angle, r4.angle);
+        using Z4 = typename SlabTraits<SlabT>::zeta4;
+        const Z4* zt = (const Z4*)P.zeta;
+        Z4 z1 = zt[rn.x - 1], z2 = zt[rn.y - 1], z3 = zt[rn.z - 1], z4 = zt[rn.w - 1];
+        auto pick = [](const Z4& v, int s) -> double {
+          return (double)((s == 0) ? v.x : (s == 1) ? v.y : (s == 2) ? v.z : v.w);
+        };
+        double zeta[3], Pz[3];
+        zeta[0] = apply_getinterp(w0, pick(z1, P.tb), pick(z2, P.tb), pick(z3, P.tb), pick(z4, P.tb));
+        zeta[1] = apply_getinterp(w0, pick(z1, P.tc), pick(z2, P.tc), pick(z3, P.tc), pick(z4, P.tc));
+        zeta[2] = apply_getinterp(w0, pick(z1, P.tf), pick(z2, P.tf), pick(z3, P.tf), pick(z4, P.tf));
+        // vertical clamps :900-922
+        if (Z < P_depth) {
+          Z = P_depth + (double)0.001f;
+          if (P.TrackCollisions) P.hitBottom[n] += 1;
+        }
+        Pz[0] = Pz[1] = Pz[2] = Z;
+        if (Z > zeta[0]) Pz[0] = zeta[0] - (double)0.001f;
+        if (Z > zeta[1]) Pz[1] = zeta[1] - (double)0.001f;
+        if (Z > zeta[2]) Pz[2] = zeta[2] - (double)0.001f;
+        const double Zpar = polintd3(P.ex0, P.ex1, P.ex2, Pz[0], Pz[1], Pz[2], P.ix1);
+        wsd[(size_t)WS_PDEPTH * N] = P_depth;
+        wsd[(size_t)WS_COSA * N] = cos(P_angle);
+        wsd[(size_t)WS_SINA * N] = sin(P_angle);
+        wsd[(size_t)WS_ZETA0 * N] = zeta[0];
+        wsd[(size_t)WS_ZETA1 * N] = zeta[1];
+        wsd[(size_t)WS_ZETA2 * N] = zeta[2];
+        wsd[(size_t)WS_PZ0 * N] = Pz[0];
+        wsd[(size_t)WS_PZ1 * N] = Pz[1];
+        wsd[(size_t)WS_PZ2 * N] = Pz[2];
+        wsd[(size_t)WS_ZPAR * N] = Zpar;  // = par(n,pZ) after :922
+      }
+    }
+    P.ws_i[n] = flags | (err << FL_ERR_SHIFT);
+#undef PARV
+  }
+  // tracked particles of this block -> block_active[block]; k_post's block 0 adds them up
+  // (one atomic per wave on a single counter serialised at the L2: 160 us per step)
+  __shared__ unsigned wsum[4];
+  unsigned v = c_active;
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) P.block_active[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// WCTS_ITPI (hydrodynamic_module.f90:2577-2688) of a rho-grid field with us levels (salinity,
+// temperature) at the start-of-step position, version 4 = (vb + 4 vc + vf)/6: straight
+// transcription (used once or twice per particle-step, only with behaviours 4,5,7 / SaltTempOn)
+template <typename SlabT>
+LT_DEV double wcts_itpi_rho(const StepParams& P, const double* lev, const Column& C, int4 rn,
+                            const QuadWeights& w, const SlabT* F, int deplvl) {
+  double Pv[3];
+#pragma unroll 1
+  for (int s = 0; s < 3; s++) {
+    const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
+    double az[4], av[4];
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+      az[l] = level_z(lev, deplvl + l, C.zeta[s], C.h, P.hc, P.Vtransform);
+      av[l] = apply_interp(w, fld(F, rn.x, P.us, deplvl + l, ps), fld(F, rn.y, P.us, deplvl + l, ps),
+                           fld(F, rn.z, P.us, deplvl + l, ps), fld(F, rn.w, P.us, deplvl + l, ps));
+    }
+    int dummy = 0;
+    Pv[s] = spline4_eval(az, av, C.Pz[s], dummy);
+  }
+  double e1 = Pv[0], e2 = Pv[1], e3 = Pv[2];
+  if (P.p == 1) { e2 = Pv[0]; e3 = Pv[1]; }
+  const double vb = polintd3(P.ex0, P.ex1, P.ex2, e1, e2, e3, P.ix0);
+  const double vc = polintd3(P.ex0, P.ex1, P.ex2, e1, e2, e3, P.ix1);
+  const double vf = polintd3(P.ex0, P.ex1, P.ex2, e1, e2, e3, P.ix2);
+  return (vb + vc * 4 + vf) / 6.0;
+}
+
+// Everything of behave() (behavior_module.f90:181-551) and of the SaltTempOn block
+// (LTRANS.f90:1062-1076) that does not depend on the random deviates or on the RK4 result:
+// swimming speed, stage changes, the C. ariakensis timer, the salinity at the particle, the
+// salinity-gradient cue, and with them WHAT the behaviour will draw (none / one directed
+// deviate / two random-swimming deviates / both), which the draw offsets of all later
+// particles depend on.  k_post consumes the deviates and finishes the behaviour.
+template <typename SlabT>
+__global__ __launch_bounds__(256) void k_beh_pre(const StepParams P) {
+  __shared__ double lev[6 * LT_LEV_STRIDE];
+  for (int i = threadIdx.x; i < 6 * LT_LEV_STRIDE; i += blockDim.x) lev[i] = P.lev[i];
+  __syncthreads();
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= P.numpar) return;
+  int fl = P.ws_i[n];
+  if (!(fl & FL_ACT)) return;
+  const size_t N = (size_t)P.numpar;
+  double* wsd = P.ws_d + n;
+  const double X = P.par[(size_t)pX * N + n], Y = P.par[(size_t)pY * N + n];
+  const double P_age = P.par[(size_t)pAge * N + n];
+  const double Zpar = wsd[(size_t)WS_ZPAR * N];
+  Column C;
+  C.h = -1.0 * wsd[(size_t)WS_PDEPTH * N];
+#pragma unroll
+  for (int s = 0; s < 3; s++) {
+    C.zeta[s] = wsd[(size_t)(WS_ZETA0 + s) * N];
+    C.Pz[s] = wsd[(size_t)(WS_PZ0 + s) * N];
+  }
+  const double P_depth = -C.h, P_zc = C.Pz[1], P_zetac = C.zeta[1];
+  int beh = (P.Behavior != 0) ? P.P_behave[n] : 0;
+  double tim = 0.0;
+  if (P.Behavior != 0) {
+    // :214-215 swimming speed at the current age
+    double sw3 = P.P_swim[n + 2 * N];
+    bool dirty = false;
+    if (P_age >= P.swimstart) { sw3 = P.P_swim[n] * P_age + P.P_swim[n + N]; dirty = true; }
+    if (P_age >= P.P_pediage[n]) { sw3 = P.swimfast; dirty = true; }
+    if (dirty) P.P_swim[n + 2 * N] = sw3;
+    // :220-229 oyster larvae: pediveliger stage, timer
+    if (beh == 4 || beh == 5) {
+      if (P_age >= P.P_pediage[n] && P_age < P.P_deadage[n]) { beh = 2; P.P_behave[n] = 2; }
+      tim = P.timer[n];
+      tim = (0.0 > tim - (double)P.dt) ? 0.0 : tim - (double)P.dt;
+      P.timer[n] = tim;
+    }
+  }
+  // salinity (and temperature) at the particle :233-246, LTRANS.f90:1062-1076
+  const bool want_S = (beh == 4) || (beh == 5 && tim == 0.0) || (beh == 7);
+  double P_S = 0.0;
+  if (want_S || P.SaltTempOn) {
+    const int4 rn = P.RE[P.P_r_element[n] - 1];
+    const Quad q = load_quad_rho(P.rnode, rn);
+    const QuadWeights w = quad_weights(X, Y, q.x, q.y);
+    const int deplvl = level_window(lev, P.us, Zpar, C.zeta[0], C.zeta[1], C.zeta[2], C.h, P.hc, P.Vtransform);
+    P_S = wcts_itpi_rho<SlabT>(P, lev, C, rn, w, (const SlabT*)P.S, deplvl);
+    if (P.SaltTempOn) {
+      P.P_Salt[n] = P_S;
+      P.P_Temp[n] = wcts_itpi_rho<SlabT>(P, lev, C, rn, w, (const SlabT*)P.T, deplvl);
+    }
+  }
+  bool directed = false, random = false;
+  double thr1 = 0.0, thr2 = 0.0;
+  // TYPE 1 :256-283
+  if (beh == 1) {
+    random = true;
+    thr2 = (P_zc < (P_zetac - 1.0)) ? (double)0.80f : 0.5;
+  }
+  // TYPE 2 :287-313 (also C. ariakensis while its timer runs)
+  if (beh == 2 || (beh == 5 && tim > 0.0)) {
+    random = true;
+    thr2 = (P_zc > (P_depth + 1.0)) ? (double)0.20f : 0.5;
+  }
+  // TYPE 3 :316-353
+  if (beh == 3) {
+    const double daytime = P.ix2 / 86400.0;
+    const double dtime = (daytime - trunc(daytime)) * 24.0;
+    double E0 = 0.0;
+    if (dtime > P.twistart && dtime < P.twiend) {
+      const double tst = (dtime - P.twistart) * 3600.0;
+      E0 = P.Em * sin(P.PI * tst / (P.daylength * 3600.0)) * sin(P.PI * tst / (P.daylength * 3600.0));
+    }
+    const double P_light = E0 * exp(P.Kd * P_zc);
+    if (P_light < P.thresh) { random = true; thr2 = 0.5; }
+    if (P_light > P.thresh) { random = true; thr2 = (double)0.20f; }
+  }
+  // TYPES 4 and 5 :357-461: the salinity-gradient cue
+  if (beh == 4 || (beh == 5 && tim == 0.0)) {
+    double Sprev = P.P_Sprev[n], zprev = P.P_zprev[n];
+    if (P.it == 1) { Sprev = P_S; zprev = P_zc; }
+    double Sslope = 0.0;
+    const double deltaS = Sprev - P_S, deltaz = zprev - P_zc;
+    if (P.it > 1) Sslope = deltaS / deltaz;
+    bool btest = false;
+    if (fabs(Sslope) > P.Sgradient) {
+      directed = true;
+      btest = true;
+      if (beh == 4) {
+        thr1 = (double)0.80f;
+      } else {
+        thr1 = (double)0.20f;
+        tim = 2.0 * 3600.0;
+        if (P_age < (double)(3.5f * 24.f * 3600.f)) { btest = false; tim = 0.; }
+        P.timer[n] = tim;
+      }
+    }
+    if (!btest) {
+      random = true;
+      double sw;
+      if (beh == 4) {
+        if (P_age < (double)(1.5f * 24.f * 3600.f)) sw = (double)0.1f;
+        else if (P_age < (double)(5.f * 24.f * 3600.f)) sw = (double)0.49f;
+        else if (P_age < (double)(8.f * 24.f * 3600.f)) sw = (double)0.50f;
+        else {
+          const double switchslope = ((double)0.50f - (double)0.517f) / (8.0 * 24.0 * 3600.0 - P.P_pediage[n]);
+          sw = switchslope * P_age + (double)0.50f - switchslope * 8.0 * 24.0 * 3600.0;
+          if (P_zc < P_depth + 1.) sw = 0.5;
+        }
+        thr2 = 1 - sw;  // :393 dev1 .GT. (1-switch)
+      } else {
+        sw = (double)0.495f;
+        if (P_age < (double)(1.5f * 24.f * 3600.f)) sw = (double)0.9f;
+        if (P_age > (double)(2.0f * 24.f * 3600.f) && P_age < (double)(3.5f * 24.f * 3600.f)) {
+          const double switchslope =
+              ((double)0.3f - (double)0.495f) / (2.0 * 24.0 * 3600.0 - (double)3.5f * 24.0 * 3600.0);
+          sw = switchslope * P_age + (double)0.3f - switchslope * 2.0 * 24.0 * 3600.0;
+        }
+        thr2 = sw;
+      }
+    }
+    P.P_Sprev[n] = P_S;  // :404-405, :461-462
+    P.P_zprev[n] = P_zc;
+  }
+  // TYPE 7 :497-500 first iteration (the rest needs the RK4 currents: k_post)
+  if (beh == 7 && P.it == 1) P.P_Sprev[n] = P_S;
+  wsd[(size_t)WS_PS * N] = P_S;
+  wsd[(size_t)WS_BTHR1 * N] = thr1;
+  wsd[(size_t)WS_BTHR2 * N] = thr2;
+  fl |= (directed ? FL_BEH_DIRECTED : 0) | (random ? FL_BEH_RANDOM : 0);
+  P.ws_i[n] = fl;
+}
+
+template <typename SlabT, int VT, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_rk(const StepParams P) {
+  __shared__ double lev[6 * LT_LEV_STRIDE];
+  __shared__ WaveScratch wsc[4];
+  for (int i = threadIdx.x; i < 6 * LT_LEV_STRIDE; i += blockDim.x) lev[i] = P.lev[i];
+  __syncthreads();
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t N = (size_t)P.numpar;
+  const bool act = (n < P.numpar) && ((P.ws_i[n] & FL_ACT) != 0);
+  const double* wsd = P.ws_d + (act ? n : 0);
+  double h = 1.0, Xs = 0.0, Ys = 0.0, Zs = 0.0;
+  if (act) {
+    h = -1.0 * wsd[(size_t)WS_PDEPTH * N];
+    Xs = P.par[(size_t)pX * N + n];
+    Ys = P.par[(size_t)pY * N + n];
+    Zs = wsd[(size_t)WS_ZPAR * N];
+  }
+  // RK4 :990-1053, executed by the whole wave
+  double sumU = 0.0, sumV = 0.0, sumW = 0.0;
+  int sigerr_count = 0;
+  bool slow = false;
+  WaveScratch& ws = wsc[threadIdx.x >> 6];
+#ifdef LT_RK_TIMING
+  if ((threadIdx.x & 63) < 8) ws.tim[threadIdx.x & 63] = 0;
+#endif
+  const Divisor dv = prep_div((VT == 2) ? P.hc + h : h);  // every level depth divides by it
+  // the RK stages keep the elements of the start position (LTRANS.f90:990-1053)
+  int er = 1, eu = 1, ev_ = 1;
+  if (act) { er = P.P_r_element[n]; eu = P.P_u_element[n]; ev_ = P.P_v_element[n]; }
+#pragma unroll 1
+  for (int st = 0; st < 4; st++) {
+    const int version = (st == 0) ? 1 : (st == 3) ? 3 : 2;
+    double Uad, Vad, Wad;
+    // (h made opaque per stage: otherwise every h-dependent level coefficient is hoisted
+    // out of the stage loop and held in registers for the whole kernel)
+    asm volatile("" : "+v"(h));
+    find_currents<SlabT, VT>(P, lev, ws, act, n, er, eu, ev_, h, dv, Xs, Ys, Zs, version, Uad, Vad, Wad, sigerr_count, slow);
+    if (st == 0) { sumU = Uad; sumV = Vad; sumW = Wad; }
+    else if (st == 3) { sumU = sumU + Uad; sumV = sumV + Vad; sumW = sumW + Wad; }
+    else { sumU = sumU + 2.0 * Uad; sumV = sumV + 2.0 * Vad; sumW = sumW + 2.0 * Wad; }
+    if (st < 3 && act) {
+      // next RK position :999-1035; the per-particle constants come back from
+      // the workspace / par (coalesced) instead of staying in registers
+      const double X = P.par[(size_t)pX * N + n], Y = P.par[(size_t)pY * N + n];
+      const double Zpar = wsd[(size_t)WS_ZPAR * N];
+      const double cosA = wsd[(size_t)WS_COSA * N], sinA = wsd[(size_t)WS_SINA * N];
+      const double dtf = (double)P.idt;
+      if (st < 2) {
+        Xs = X + (Uad * cosA - Vad * sinA) * dtf / 2.0;
+        Ys = Y + (Uad * sinA + Vad * cosA) * dtf / 2.0;
+        Zs = Zpar + Wad * dtf / 2.0;
+      } else {
+        Xs = X + (Uad * cosA - Vad * sinA) * dtf;
+        Ys = Y + (Uad * sinA + Vad * cosA) * dtf;
+        Zs = Zpar + Wad * dtf;
+      }
+      // maxpartdepth / minpartdepth :981-987
+      const double* wtab = lev + 3 * LT_LEV_STRIDE;
+      const LevCoef w1 = level_coef_d(wtab, 1, h, P.hc, VT, dv);
+      const LevCoef wN = level_coef_d(wtab, P.ws, h, P.hc, VT, dv);
+      const double zb = wsd[(size_t)WS_ZETA0 * N], zc = wsd[(size_t)WS_ZETA1 * N], zf = wsd[(size_t)WS_ZETA2 * N];
+      double maxpartdepth = level_at(w1, zb, h, VT);
+      double t1 = level_at(w1, zc, h, VT), t2 = level_at(w1, zf, h, VT);
+      if (t1 > maxpartdepth) maxpartdepth = t1;
+      if (t2 > maxpartdepth) maxpartdepth = t2;
+      double minpartdepth = level_at(wN, zb, h, VT);
+      t1 = level_at(wN, zc, h, VT); t2 = level_at(wN, zf, h, VT);
+      if (t1 < minpartdepth) minpartdepth = t1;
+      if (t2 < minpartdepth) minpartdepth = t2;
+      if (Zs > minpartdepth) Zs = minpartdepth - (double)0.000001f;
+      if (Zs < maxpartdepth) Zs = maxpartdepth + (double)0.000001f;
+    }
+  }
+#ifdef LT_RK_TIMING
+  if ((threadIdx.x & 63) < 8) atomicAdd(&g_tim[threadIdx.x & 63], ws.tim[threadIdx.x & 63]);
+#endif
+  if (act) {
+    double* wso = P.ws_d + n;
+    wso[(size_t)WS_SUMU * N] = sumU;
+    wso[(size_t)WS_SUMV * N] = sumV;
+    wso[(size_t)WS_SUMW * N] = sumW;
+    if (slow) P.ws_i[n] |= FL_SLOW;
+  }
+  unsigned v = (unsigned)sigerr_count;
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(&P.counters[CNT_SIGERR], (unsigned long long)v);
+}
+
+// ---- k_rk_slow: the particle-steps k_rk could not finish on its fast path
+// (a SigErr in some spline fit, or a degenerate level window) are redone here
+// by a straight per-lane transcription of find_currents / WCTS_ITPI
+// (LTRANS.f90:1422-1614, hydrodynamic_module.f90:2577-2689): YPC1, the SIGS
+// interval loop with its early RETURN, HVAL or the linint fallback.
+template <typename SlabT>
+LT_DEV void find_currents_ref(const StepParams& P, const double* lev, const Column& C, int4 rn,
+                              int4 un, int4 vn, double Xs, double Ys, double Zs, int version,
+                              double& Uad, double& Vad, double& Wad) {
+  const double* rtab = lev;
+  const double* wtab = lev + 3 * LT_LEV_STRIDE;
+  const double ixv = (version == 1) ? P.ix0 : (version == 2) ? P.ix1 : P.ix2;
+  if ((Zs < C.wz1[0] + P.z0) || (Zs < C.wz1[1] + P.z0) || (Zs < C.wz1[2] + P.z0)) {
+    Uad = 0.0; Vad = 0.0; Wad = 0.0;
+    return;
+  }
+  const bool loglayer = (Zs < C.z1[0]) || (Zs < C.z1[1]) || (Zs < C.z1[2]);
+  const int ii = level_window(rtab, P.us, Zs, C.zeta[0], C.zeta[1], C.zeta[2], C.h, P.hc, P.Vtransform);
+  const int iii = level_window(wtab, P.ws, Zs, C.zeta[0], C.zeta[1], C.zeta[2], C.h, P.hc, P.Vtransform);
+#pragma unroll 1
+  for (int var = 0; var < 3; var++) {
+    const int4 nd = (var == 0) ? un : (var == 1) ? vn : rn;
+    Quad q = (var == 2) ? load_quad_rho(P.rnode, nd)
+                        : load_quad_xy((var == 0) ? P.unode : P.vnode, nd);
+    const QuadWeights w = quad_weights(Xs, Ys, q.x, q.y);
+    const SlabT* F = (const SlabT*)((var == 0) ? P.U : (var == 1) ? P.V : P.W);
+    const int L = (var == 2) ? P.ws : P.us;
+    const double* tab = (var == 2) ? wtab : rtab;
+    double Pv0 = 0.0, Pv1 = 0.0, Pv2 = 0.0;
+#pragma unroll 1
+    for (int s = 0; s < 3; s++) {
+      const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
+      const double zeta = (s == 0) ? C.zeta[0] : (s == 1) ? C.zeta[1] : C.zeta[2];
+      double r;
+      if (loglayer) {
+        const int k = (var == 2) ? 2 : 1;
+        double val = apply_interp(w, fld(F, nd.x, L, k, ps), fld(F, nd.y, L, k, ps),
+                                  fld(F, nd.z, L, k, ps), fld(F, nd.w, L, k, ps));
+        const double z1s = (s == 0) ? C.z1[0] : (s == 1) ? C.z1[1] : C.z1[2];
+        double ztop = (var == 2) ? level_z(wtab, 2, zeta, C.h, P.hc, P.Vtransform) : z1s;
+        r = val * log10((Zs - C.wz1[0]) / P.z0) / log10((ztop - C.wz1[0]) / P.z0);
+      } else {
+        const int k0 = (var == 2) ? iii : ii;
+        const double Pzs = (s == 0) ? C.Pz[0] : (s == 1) ? C.Pz[1] : C.Pz[2];
+        double az[4], av[4];
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+          az[l] = level_z(tab, k0 + l, zeta, C.h, P.hc, P.Vtransform);
+          av[l] = apply_interp(w, fld(F, nd.x, L, k0 + l, ps), fld(F, nd.y, L, k0 + l, ps),
+                               fld(F, nd.z, L, k0 + l, ps), fld(F, nd.w, L, k0 + l, ps));
+        }
+        int dummy = 0;
+        r = spline4_eval(az, av, Pzs, dummy);
+      }
+      if (s == 0) Pv0 = r; else if (s == 1) Pv1 = r; else Pv2 = r;
+    }
+    double e1 = Pv0, e2 = (P.p == 1) ? Pv0 : Pv1, e3 = (P.p == 1) ? Pv1 : Pv2;
+    double val = polintd3(P.ex0, P.ex1, P.ex2, e1, e2, e3, ixv);
+    if (var == 0) Uad = val; else if (var == 1) Vad = val; else Wad = val;
+  }
+}
+
+template <typename SlabT>
+__global__ __launch_bounds__(256) void k_rk_slow(const StepParams P) {
+  __shared__ double lev[6 * LT_LEV_STRIDE];
+  for (int i = threadIdx.x; i < 6 * LT_LEV_STRIDE; i += blockDim.x) lev[i] = P.lev[i];
+  __syncthreads();
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= P.numpar) return;
+  if (!(P.ws_i[n] & FL_SLOW)) return;
+  const size_t N = (size_t)P.numpar;
+  double* wsd = P.ws_d + n;
+  const double X = P.par[(size_t)pX * N + n], Y = P.par[(size_t)pY * N + n];
+  const double Zpar = wsd[(size_t)WS_ZPAR * N];
+  const double cosA = wsd[(size_t)WS_COSA * N], sinA = wsd[(size_t)WS_SINA * N];
+  const int4 rn = P.RE[P.P_r_element[n] - 1], un = P.UE[P.P_u_element[n] - 1],
+             vn = P.VE[P.P_v_element[n] - 1];
+  Column C;
+  C.h = -1.0 * wsd[(size_t)WS_PDEPTH * N];
+#pragma unroll
+  for (int s = 0; s < 3; s++) {
+    C.zeta[s] = wsd[(size_t)(WS_ZETA0 + s) * N];
+    C.Pz[s] = wsd[(size_t)(WS_PZ0 + s) * N];
+    C.wz1[s] = level_z(lev + 3 * LT_LEV_STRIDE, 1, C.zeta[s], C.h, P.hc, P.Vtransform);
+    C.z1[s] = level_z(lev, 1, C.zeta[s], C.h, P.hc, P.Vtransform);
+  }
+  double maxpartdepth = C.wz1[0];
+  if (C.wz1[1] > maxpartdepth) maxpartdepth = C.wz1[1];
+  if (C.wz1[2] > maxpartdepth) maxpartdepth = C.wz1[2];
+  double minpartdepth = level_z(lev + 3 * LT_LEV_STRIDE, P.ws, C.zeta[0], C.h, P.hc, P.Vtransform);
+  {
+    double t1 = level_z(lev + 3 * LT_LEV_STRIDE, P.ws, C.zeta[1], C.h, P.hc, P.Vtransform);
+    double t2 = level_z(lev + 3 * LT_LEV_STRIDE, P.ws, C.zeta[2], C.h, P.hc, P.Vtransform);
+    if (t1 < minpartdepth) minpartdepth = t1;
+    if (t2 < minpartdepth) minpartdepth = t2;
+  }
+  double sumU = 0.0, sumV = 0.0, sumW = 0.0, Xs = X, Ys = Y, Zs = Zpar;
+#pragma unroll 1
+  for (int st = 0; st < 4; st++) {
+    const int version = (st == 0) ? 1 : (st == 3) ? 3 : 2;
+    double Uad, Vad, Wad;
+    find_currents_ref<SlabT>(P, lev, C, rn, un, vn, Xs, Ys, Zs, version, Uad, Vad, Wad);
+    if (st == 0) { sumU = Uad; sumV = Vad; sumW = Wad; }
+    else if (st == 3) { sumU = sumU + Uad; sumV = sumV + Vad; sumW = sumW + Wad; }
+    else { sumU = sumU + 2.0 * Uad; sumV = sumV + 2.0 * Vad; sumW = sumW + 2.0 * Wad; }
+    if (st < 3) {
+      const double dtf = (double)P.idt;
+      if (st < 2) {
+        Xs = X + (Uad * cosA - Vad * sinA) * dtf / 2.0;
+        Ys = Y + (Uad * sinA + Vad * cosA) * dtf / 2.0;
+        Zs = Zpar + Wad * dtf / 2.0;
+      } else {
+        Xs = X + (Uad * cosA - Vad * sinA) * dtf;
+        Ys = Y + (Uad * sinA + Vad * cosA) * dtf;
+        Zs = Zpar + Wad * dtf;
+      }
+      if (Zs > minpartdepth) Zs = minpartdepth - (double)0.000001f;
+      if (Zs < maxpartdepth) Zs = maxpartdepth + (double)0.000001f;
+    }
+  }
+  wsd[(size_t)WS_SUMU * N] = sumU;
+  wsd[(size_t)WS_SUMV * N] = sumV;
+  wsd[(size_t)WS_SUMW * N] = sumW;
+}

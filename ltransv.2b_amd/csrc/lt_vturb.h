@@ -1,0 +1,473 @@
+// lt_vturb.h -- HTurb / VTurb helpers and the three VTurb kernels (table, SIGS, walk).
+// Part of lt_kernels.h (included inside namespace ltd); see the notes there.
+#pragma once
+
+// ---------------------------------------------------------------- turbulence
+// one uniform deviate of genrand_real3 (random_module.f90:239-246) from the
+// materialised stream
+LT_DEV double draw_real3(const StepParams& P, unsigned long long idx) {
+  const uint32_t y = ltmt_temper(P.rng_ring[idx & P.rng_mask]);
+  return ((double)y + 0.5) / 4294967296.0;
+}
+// norm(), norm_module.f90:25-39: two uniforms per deviate, cos branch only
+// genrand_real1 (random_module.f90:213-219): [0,1]
+LT_DEV double draw_real1(const StepParams& P, unsigned long long idx) {
+  const uint32_t y = ltmt_temper(P.rng_ring[idx & P.rng_mask]);
+  return (double)y / 4294967295.0;
+}
+LT_DEV double draw_norm(const StepParams& P, unsigned long long idx) {
+  const double dev1 = draw_real3(P, idx), dev2 = draw_real3(P, idx + 1);
+  return sqrt(-2.0 * log(dev1)) * cos(2.0 * P.PI * dev2);
+}
+
+// HVAL / HPVAL on a spline table in memory (element k of array a at a[k*stride]),
+// tension_module.f90:980-1253.  `il` caches the last interval like INTRVL's SAVE IL.
+template <bool DERIV>
+LT_DEV double hval_table(double T, int n, const double* x, const double* y, const double* yp,
+                         const double* sig, size_t stride, int& il) {
+  int I;
+  if (T < x[0]) I = 1;
+  else if (T > x[(size_t)(n - 1) * stride]) I = n - 1;
+  else {
+    // INTRVL :1287-1354: try the previous interval, else bisection
+    bool hit = false;
+    if (il >= 1 && il < n) hit = (x[(size_t)(il - 1) * stride] <= T) && (T < x[(size_t)il * stride]);
+    if (!hit) {
+      int lo = 1, hi = n;
+      while (hi > lo + 1) {
+        int kk = (lo + hi) >> 1;
+        if (T < x[(size_t)(kk - 1) * stride]) hi = kk; else lo = kk;
+      }
+      il = lo;
+    }
+    I = il;
+  }
+  const size_t a = (size_t)(I - 1) * stride, b = (size_t)I * stride;
+  const double X1 = x[a], X2 = x[b], Y1 = y[a], Y2 = y[b], P1 = yp[a], P2 = yp[b], SG = sig[a];
+  if (X2 - X1 <= 0.0) return 0.0;  // IER = -2
+  if (DERIV) return hpval_interval(T, X1, X2, Y1, Y2, P1, P2, SG);
+  return hval_interval(T, X1, X2, Y1, Y2, P1, P2, SG);
+}
+
+// polintd at the three internal times ix(1..3) of one (ex, ey) triple
+// (ver_turb_module.f90:236-238,258-260): the two inner quotients of polintd do
+// not depend on x, so they are formed once (same values, 5 divisions instead of 9).
+// (ns, the node of the time axis closest to x, is the same for every particle: the host
+// finds it once per step with polintd's own comparisons, StepParams::pns)
+LT_DEV double polintd_shared(double xa1, double xa2, double xa3, double ya1, double ya2, double ya3,
+                             double q32, double q21, double r13, bool fd, double x, int ns) {
+  double c = (xa2 - x) * q32;
+  c = c - (xa2 - x) * q21;
+  c = div_by(c, xa1 - xa3, r13, fd);
+  const double a = (ns == 3) ? q32 : q21;
+  // xa(ns) - x picked among the three differences (selects on computed values only)
+  const double d1 = xa1 - x, d2 = xa2 - x, d3 = xa3 - x;
+  const double bb = (ns == 3) ? d3 : d1;
+  const double yns = (ns == 1) ? ya1 : (ns == 2) ? ya2 : ya3;
+  const double dns = (ns == 1) ? d1 : (ns == 2) ? d2 : d3;
+  return yns + dns * a + bb * c;
+}
+LT_DEV void polintd3x3(const StepParams& P, double ya1, double ya2, double ya3,
+                       double& rb, double& rc, double& rf) {
+  const double xa1 = P.ex0, xa2 = P.ex1, xa3 = P.ex2;
+  const bool fd = P.fastdiv != 0;
+  const double q32 = div_by(ya3 - ya2, xa2 - xa3, P.r_d23, fd);
+  const double q21 = div_by(ya2 - ya1, xa1 - xa2, P.r_d12, fd);
+  rb = polintd_shared(xa1, xa2, xa3, ya1, ya2, ya3, q32, q21, P.r_d13, fd, P.ix0, P.pns0);
+  rc = polintd_shared(xa1, xa2, xa3, ya1, ya2, ya3, q32, q21, P.r_d13, fd, P.ix1, P.pns1);
+  rf = polintd_shared(xa1, xa2, xa3, ya1, ya2, ya3, q32, q21, P.r_d13, fd, P.ix2, P.pns2);
+}
+
+// The interval of the VTurb spline table a walk is in, kept in registers: HVAL and
+// HPVAL (tension_module.f90:980-1253) reload from HBM only when the depth leaves it.
+// For a strictly increasing abscissa table INTRVL's answer (:1287-1354) is the unique
+// I with X(I) <= T < X(I+1), clamped to 1..N-1, whatever its saved IL was, so
+// stepping from the cached interval finds the same I as its bisection.
+struct VtInterval { int I; double X1, X2, Y1, Y2, P1, P2, SG; };
+LT_DEV void vt_seek(VtInterval& c, double T, int n, const double* x, const double* y,
+                    const double* yp, const double* sig, size_t stride) {
+  bool moved = false;
+  if (c.I == 0) {  // first use: bisection
+    int lo = 1, hi = n;
+    while (hi > lo + 1) {
+      const int kk = (lo + hi) >> 1;
+      if (T < x[(size_t)(kk - 1) * stride]) hi = kk; else lo = kk;
+    }
+    c.I = lo;
+    c.X1 = x[(size_t)(lo - 1) * stride];
+    c.X2 = x[(size_t)lo * stride];
+    moved = true;
+  }
+  while (T < c.X1 && c.I > 1) { c.I -= 1; c.X2 = c.X1; c.X1 = x[(size_t)(c.I - 1) * stride]; moved = true; }
+  while (T >= c.X2 && c.I < n - 1) { c.I += 1; c.X1 = c.X2; c.X2 = x[(size_t)c.I * stride]; moved = true; }
+  if (moved) {
+    const size_t a = (size_t)(c.I - 1) * stride, b = (size_t)c.I * stride;
+    c.Y1 = y[a]; c.Y2 = y[b]; c.P1 = yp[a]; c.P2 = yp[b]; c.SG = sig[a];
+  }
+}
+
+// per-wave LDS queue of the spline intervals of the VTurb table whose tension
+// factor needs an iteration (SIGS, tension_module.f90:531-760)
+#define LT_VT_CAP 256
+struct VtScratch {
+  double S[LT_VT_CAP], S1[LT_VT_CAP], S2[LT_VT_CAP];
+  unsigned short where[LT_VT_CAP];  // interval index k (0-based)
+  unsigned char lane[LT_VT_CAP];
+  unsigned int failed[64];
+};
+
+LT_DEV void vt_run_tasks(VtScratch& q, int ntask, int lane, int wave_first, double* vt_sig,
+                         int p2) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+  for (int t = lane; t < ntask; t += 64) {
+    double sg, T;
+    bool failed = false;
+    const int kind = sigs_classify(q.S[t], q.S1[t], q.S2[t], sg, T);
+    if (kind == SIGK_NEWTON) sg = sigs_newton(T, failed);
+    else if (kind == SIGK_SECANT) sg = sigs_secant(q.S[t], q.S1[t], q.S2[t]);
+    vt_sig[((size_t)(wave_first >> 6) * (size_t)p2 + q.where[t]) * 64 + q.lane[t]] = sg;
+    if (failed) atomicOr(&q.failed[q.lane[t]], 1u);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// VTurb, ver_turb_module.f90:30-380, as three kernels, one lane per particle:
+//   k_vt_table  builds the spline table of the time-interpolated, smoothed Kh profile
+//               (the register-heavy, arithmetic part);
+//   k_vt_sigs   chooses the tension factors (SIGS), iterating only the intervals that
+//               need it, 64 at a time per wave;
+//   k_vt_walk   runs the idt/2 random-walk sub-steps on the table.
+// The ~30 work arrays of the reference are never materialised: the proliferated /
+// smoothed profile is produced as a stream over k (8-point window in registers),
+// the YPC1 derivative of point k-1 is formed as soon as point k exists, and only the
+// final spline table (x, y, yp, sigma)(k) goes to HBM, [wave][k][lane], so every table
+// access of the build phases is coalesced and a wave streams one contiguous block.
+// SIGS' "RETURN at the first SigErr" leaves later tensions at 0 in the reference;
+// since SigErr switches every later evaluation to linint, which ignores the
+// tensions, computing all of them here changes nothing.
+template <typename SlabT, int VT>
+__global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
+  __shared__ double lev[6 * LT_LEV_STRIDE];
+  __shared__ double wring[3][8][256];
+  for (int i = threadIdx.x; i < 6 * LT_LEV_STRIDE; i += blockDim.x) lev[i] = P.lev[i];
+  __syncthreads();
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= P.numpar || !(P.ws_i[n] & FL_ACT)) return;
+  const bool act = true;
+  const size_t N = (size_t)P.numpar;
+  const int na = act ? n : 0;
+  double* wsd = P.ws_d + na;
+  const double* wtab = lev + 3 * LT_LEV_STRIDE;
+  const int ws = P.ws, p2 = 4 * P.ws;
+  double P_depth = -1.0, h = 1.0;
+  double zeta[3] = {0.0, 0.0, 0.0};
+  int4 rn = make_int4(1, 1, 1, 1);
+  QuadWeights w0;
+  w0.regime = 1; w0.node_hit = 0; w0.t = w0.u = w0.W1 = w0.W2 = w0.W3 = w0.W4 = 0.0;
+  if (act) {
+    P_depth = wsd[(size_t)WS_PDEPTH * N]; h = -1.0 * P_depth;
+    zeta[0] = wsd[(size_t)WS_ZETA0 * N]; zeta[1] = wsd[(size_t)WS_ZETA1 * N]; zeta[2] = wsd[(size_t)WS_ZETA2 * N];
+    // getInterp weights of the start position in the rho element (setInterp :882)
+    const double X = P.par[(size_t)pX * N + n], Y = P.par[(size_t)pY * N + n];
+    rn = P.RE[P.P_r_element[n] - 1];
+    Quad qq = load_quad_rho(P.rnode, rn);
+    w0 = quad_weights(X, Y, qq.x, qq.y);
+  }
+  const SlabT* K = (const SlabT*)P.Kh;
+  const int pslot[3] = {P.tb, P.tc, P.tf};
+  auto KH = [&](int s, int i) -> double {  // Pwc_KH{b,c,f}(i) :102-108
+    return apply_getinterp(w0, fld(K, rn.x, ws, i, pslot[s]), fld(K, rn.y, ws, i, pslot[s]),
+                           fld(K, rn.z, ws, i, pslot[s]), fld(K, rn.w, ws, i, pslot[s]));
+  };
+  auto WZ = [&](int s, int i) -> double {  // Pwc_wz{b,c,f}(i)
+    return level_at(level_coef(wtab, i, h, P.hc, VT), zeta[s], h, VT);
+  };
+  double wz1[3], wzN[3], kh1[3], khN[3], rng_[3];
+#pragma unroll
+  for (int s = 0; s < 3; s++) {
+    wz1[s] = WZ(s, 1); wzN[s] = WZ(s, ws);
+    kh1[s] = KH(s, 1); khN[s] = KH(s, ws);
+    rng_[s] = wzN[s] - wz1[s];
+  }
+  auto NEWX = [&](int s, int j) -> double {  // :121-123
+    return wz1[s] + div_by(((double)(float)(j - 4)) * rng_[s], (double)p2, P.r_p2, P.fastdiv != 0);
+  };
+  // piecewise-linear profile segment per slot :126-163.  Moving up one level reuses
+  // the upper end of the previous segment (same values), and the Kh of the level after
+  // that was asked for one segment earlier, so its latency is off the critical path.
+  int jlo[3] = {1, 1, 1};
+  double slope[3], icpt[3], wzhi[3], khhi[3];
+  SlabT rawn[3][4];
+  auto RAW = [&](int s, int i) {
+    const size_t o = (size_t)(i - 1) * LT_SLOTS + pslot[s], L3 = (size_t)ws * LT_SLOTS;
+    rawn[s][0] = K[(size_t)(rn.x - 1) * L3 + o]; rawn[s][1] = K[(size_t)(rn.y - 1) * L3 + o];
+    rawn[s][2] = K[(size_t)(rn.z - 1) * L3 + o]; rawn[s][3] = K[(size_t)(rn.w - 1) * L3 + o];
+  };
+  auto LINE = [&](int s, double a, double b, double ka, double kb) {
+    slope[s] = (ka - kb) / (a - b);
+    icpt[s] = ka - slope[s] * a;
+    wzhi[s] = b;
+    khhi[s] = kb;
+  };
+#pragma unroll
+  for (int s = 0; s < 3; s++) {
+    LINE(s, wz1[s], WZ(s, 2), kh1[s], KH(s, 2));
+    RAW(s, 3);  // ws >= 6
+  }
+  auto NEWY = [&](int s, int j) -> double {  // newy{b,c,f}(j), j = 5..p2+3
+    const double xj = NEWX(s, j);
+    while (!(wzhi[s] > xj) && jlo[s] < ws - 1) {
+      jlo[s] += 1;
+      const double kb = apply_getinterp(w0, (double)rawn[s][0], (double)rawn[s][1], (double)rawn[s][2],
+                                        (double)rawn[s][3]);
+      LINE(s, wzhi[s], WZ(s, jlo[s] + 1), khhi[s], kb);
+      if (jlo[s] + 2 <= ws) RAW(s, jlo[s] + 2);
+    }
+    return slope[s] * xj + icpt[s];
+  };
+  // newy(1..8): the low pads (:170-173, all three use Pwc_KHb(1)) and the first 4 points.
+  // The 8-point window lives in LDS as a ring: newy(j) of slot s at wring[s][j & 7][thread].
+#pragma unroll
+  for (int s = 0; s < 3; s++) {
+#pragma unroll
+    for (int j = 1; j <= 4; j++) wring[s][j & 7][threadIdx.x] = kh1[0];
+#pragma unroll
+    for (int j = 5; j <= 8; j++) wring[s][j & 7][threadIdx.x] = NEWY(s, j);
+  }
+  // table layout: [wave][k][lane], a wave streams one contiguous 4*ws*512 B block per array
+  const size_t TS = 64, toff = (size_t)(na >> 6) * (size_t)p2 * 64 + (size_t)(na & 63);
+  double* tx = P.vt_x + toff; double* ty = P.vt_y + toff; double* typ = P.vt_yp + toff;
+  // streaming YPC1 / SIGS state: previous point, previous interval, YP(k-2)
+  double xm1 = 0.0, ym1 = 0.0, Sp = 0.0, DXp = 0.0, YPp = 0.0;
+  bool ypc_fail = false;
+#pragma unroll 1
+  for (int k = 1; k <= p2; k++) {
+    if (act) {
+      double mx[3], my[3];
+#pragma unroll
+      for (int s = 0; s < 3; s++) {
+        if (k == 1) { mx[s] = wz1[s]; my[s] = kh1[s]; }            // :197-210 pinned ends
+        else if (k == p2) { mx[s] = wzN[s]; my[s] = khN[s]; }
+        else {                                                      // :184-194 8-point average
+          const int t = threadIdx.x;
+          my[s] = (wring[s][k & 7][t] + wring[s][(k + 1) & 7][t] + wring[s][(k + 2) & 7][t] + wring[s][(k + 3) & 7][t] +
+                   wring[s][(k + 4) & 7][t] + wring[s][(k + 5) & 7][t] + wring[s][(k + 6) & 7][t] + wring[s][(k + 7) & 7][t]) / 8.0;
+          const double xa = NEWX(s, k);
+          mx[s] = xa + (NEWX(s, k + 7) - xa) / 2.0;
+        }
+      }
+      // :220-275 interpolation to the internal times, clamp, Simpson in time
+      // (selects on values, not on array elements: those would turn into stack indexing)
+      const double mx0 = mx[0], mx1 = mx[1], mx2 = mx[2], my0 = my[0], my1 = my[1], my2 = my[2];
+      double ex1 = mx0, ex2 = mx1, ex3 = mx2, ey1 = my0, ey2 = my1, ey3 = my2;
+      if (P.p == 1) { ex2 = mx0; ex3 = mx1; ey2 = my0; ey3 = my1; }
+      double fxb, fxc, fxf, fyb, fyc, fyf;
+      polintd3x3(P, ex1, ex2, ex3, fxb, fxc, fxf);
+      polintd3x3(P, ey1, ey2, ey3, fyb, fyc, fyf);
+      if (fyb < 0.0) fyb = 0.0;
+      if (fyc < 0.0) fyc = 0.0;
+      if (fyf < 0.0) fyf = 0.0;
+      const double yk = div_by(fyb + 4.0 * fyc + fyf, 6.0, P.r_6, P.fastdiv != 0);
+      const double xk = div_by(fxb + 4.0 * fxc + fxf, 6.0, P.r_6, P.fastdiv != 0);
+      tx[(size_t)(k - 1) * TS] = xk;
+      ty[(size_t)(k - 1) * TS] = yk;
+      // TSPSI(p2) as a stream: YPC1 (tension_module.f90:852-977), SIGS (:314-781)
+      if (k >= 2 && !ypc_fail) {
+        const double DX = xk - xm1;  // DX_{k-1}
+        if (DX <= 0.0) {
+          ypc_fail = true;  // YPC1 fails -> TSPSI returns IER = -4 and SIGS never runs
+          typ[(size_t)(k - 2) * TS] = 0.0;  // derivatives not reached stay 0
+        } else {
+          const double S = (yk - ym1) / DX;  // S_{k-1}
+          if (k == 3) {
+            YPp = ypc1_end(Sp, Sp + DXp * (Sp - S) / (DXp + DX));  // YP(1)
+            typ[0] = YPp;
+          }
+          if (k >= 3) {
+            const double YPc = ypc1_mid(DXp, DX, Sp, S);  // YP(k-1)
+            typ[(size_t)(k - 2) * TS] = YPc;
+            YPp = YPc;
+          }
+          if (k == p2) {
+            const double YPn = ypc1_end(S, S + DX * (S - Sp) / (DXp + DX));  // YP(N)
+            typ[(size_t)(k - 1) * TS] = YPn;
+          }
+          Sp = S;
+          DXp = DX;
+        }
+      }
+      if (ypc_fail) typ[(size_t)(k - 1) * TS] = 0.0;
+      xm1 = xk;
+      ym1 = yk;
+      // slide the 8-point window: drop newy(k), append newy(k+8)
+      if (k + 8 <= p2 + 7) {
+#pragma unroll
+        for (int s = 0; s < 3; s++) {
+          wring[s][k & 7][threadIdx.x] = (k + 8 >= p2 + 4) ? khN[s] : NEWY(s, k + 8);  // high pads
+        }
+      }
+    }
+  }
+  if (ypc_fail) P.ws_i[n] |= FL_VT_YPCFAIL;
+}
+
+// SIGS over the finished tables (tension_module.f90:314-781): intervals whose tension
+// is known without iterating are stored at once, the others are queued for the wave.
+// Whole waves stay converged (ballots); a particle whose YPC1 failed is skipped: TSPSI
+// returned IER = -4 before SIGS, so its tensions stay 0 and SigErr = 0.
+__global__ __launch_bounds__(256) void k_vt_sigs(const StepParams P) {
+  __shared__ VtScratch vsc[4];
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wave_first = n - lane;
+  VtScratch& q = vsc[threadIdx.x >> 6];
+  q.failed[lane] = 0;
+  const int fl = (n < P.numpar) ? P.ws_i[n] : 0;
+  const bool act = (fl & FL_ACT) != 0;
+  const bool ypc_fail = (fl & FL_VT_YPCFAIL) != 0;
+  const int na = act ? n : 0;
+  const int p2 = 4 * P.ws;
+  const size_t TS = 64, toff = (size_t)(na >> 6) * (size_t)p2 * 64 + (size_t)(na & 63);
+  const double* tx = P.vt_x + toff; const double* ty = P.vt_y + toff; const double* typ = P.vt_yp + toff;
+  double* tsg = P.vt_sig + toff;
+  int ntask = 0;  // wave-uniform
+  {
+    double x0 = 0.0, y0 = 0.0, p0 = 0.0;
+    const bool run = act && !ypc_fail;
+    if (act && ypc_fail)
+      for (int k = 0; k < p2 - 1; k++) tsg[(size_t)k * TS] = 0.0;
+    if (run) { x0 = tx[0]; y0 = ty[0]; p0 = typ[0]; }
+#pragma unroll 1
+    for (int k0 = 0; k0 < p2 - 1; k0 += 4) {
+      // the table comes back from HBM: 12 loads in flight per lane, then the arithmetic
+      double xs[4], ys[4], ps[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int kk = (k0 + j + 1 < p2) ? (k0 + j + 1) : (p2 - 1);
+        xs[j] = ys[j] = ps[j] = 0.0;
+        if (run) { xs[j] = tx[(size_t)kk * TS]; ys[j] = ty[(size_t)kk * TS]; ps[j] = typ[(size_t)kk * TS]; }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (k0 + j < p2 - 1) {
+          if (ntask > LT_VT_CAP - 64) {
+            vt_run_tasks(q, ntask, lane, wave_first, P.vt_sig, p2);
+            ntask = 0;
+          }
+          double S = 0.0, sg = 0.0;
+          bool need = false;
+          if (run) {
+            S = (ys[j] - y0) / (xs[j] - x0);
+            need = !sigs_eval_known(S, p0, ps[j], sg);
+            if (!need) tsg[(size_t)(k0 + j) * TS] = sg;
+          }
+          const unsigned long long m = __ballot(need);
+          if (need) {
+            const int idx = ntask + __popcll(m & ((1ull << lane) - 1ull));
+            q.S[idx] = S; q.S1[idx] = p0; q.S2[idx] = ps[j];
+            q.where[idx] = (unsigned short)(k0 + j);
+            q.lane[idx] = (unsigned char)lane;
+          }
+          ntask += __popcll(m);
+          x0 = xs[j]; y0 = ys[j]; p0 = ps[j];
+        }
+      }
+    }
+  }
+  vt_run_tasks(q, ntask, lane, wave_first, P.vt_sig, p2);
+  if (act && q.failed[lane]) P.ws_i[n] = fl | FL_VT_SIGERR;
+}
+
+// :282-335 random displacement model, idt/2 sub-steps of 2 s
+struct __attribute__((packed, aligned(4))) RawWords4 { uint32_t a, b, c, d; };
+__global__ __launch_bounds__(256) void k_vt_walk(const StepParams P) {
+  __shared__ uint2 rbuf[8][256];
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= P.numpar) return;
+  const int fl = P.ws_i[n];
+  if (!(fl & FL_ACT)) return;
+  const bool ypc_fail = (fl & FL_VT_YPCFAIL) != 0;
+  const int sigerr = (fl & FL_VT_SIGERR) ? 1 : 0;
+  const size_t N = (size_t)P.numpar;
+  double* wsd = P.ws_d + n;
+  const int p2 = 4 * P.ws;
+  const size_t TS = 64, toff = (size_t)(n >> 6) * (size_t)p2 * 64 + (size_t)(n & 63);
+  const double* tx = P.vt_x + toff; const double* ty = P.vt_y + toff; const double* typ = P.vt_yp + toff;
+  const double* tsg = P.vt_sig + toff;
+  const double P_depth = wsd[(size_t)WS_PDEPTH * N], P_zc = wsd[(size_t)WS_PZ1 * N];
+  const double P_zetac = wsd[(size_t)WS_ZETA1 * N];
+  // :282-335 random displacement model, idt/2 sub-steps of 2 s
+  const double background = (double)1.0E-6f, deltat = 2.0;
+  const int loop = P.idt / (int)deltat;
+  // this particle's window of the serial stream: HTurb's 4 draws come first (:1087,1098)
+  unsigned long long di = P.rng_base + (unsigned long long)(unsigned)P.rank[P.orig[n]] +
+                          (P.HTurbOn ? 4ull : 0ull);
+  double ParZc = P_zc;
+  int il = 1;
+  VtInterval ci;
+  ci.I = 0; ci.X1 = ci.X2 = ci.Y1 = ci.Y2 = ci.P1 = ci.P2 = ci.SG = 0.0;
+  const bool cached = (sigerr == 0) && !ypc_fail;
+#pragma unroll 1
+  for (int i = 1; i <= loop; i++) {
+    // The particle's raw words are consecutive in the ring: 16 of them (8 sub-steps,
+    // one 64-B line) are fetched at a time with four 16-byte loads and parked in this
+    // thread's LDS column; word-by-word loads re-fetched the line for every sub-step.
+    const int sub = (i - 1) & 7;
+    if (sub == 0) {
+      const unsigned long long o = di & P.rng_mask;
+      if (o + 16 <= P.rng_mask + 1ull) {
+        const RawWords4* src = (const RawWords4*)(P.rng_ring + o);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const RawWords4 w = src[j];
+          rbuf[2 * j][threadIdx.x] = make_uint2(w.a, w.b);
+          rbuf[2 * j + 1][threadIdx.x] = make_uint2(w.c, w.d);
+        }
+      } else {  // the window wraps around the end of the ring
+#pragma unroll 1
+        for (int j = 0; j < 8; j++)
+          rbuf[j][threadIdx.x] = make_uint2(P.rng_ring[(di + 2 * j) & P.rng_mask],
+                                            P.rng_ring[(di + 2 * j + 1) & P.rng_mask]);
+      }
+    }
+    const uint2 rw = rbuf[sub][threadIdx.x];
+    const uint32_t raw1 = rw.x, raw2 = rw.y;
+    di += 2;
+    double Kprimec = 0.0;
+    if (!(ParZc < P_depth || ParZc > P_zetac)) {
+      if (cached) {
+        vt_seek(ci, ParZc, p2, tx, ty, typ, tsg, TS);
+        Kprimec = hpval_interval(ParZc, ci.X1, ci.X2, ci.Y1, ci.Y2, ci.P1, ci.P2, ci.SG);
+      } else if (sigerr == 0) {
+        Kprimec = hval_table<true>(ParZc, p2, tx, ty, typ, tsg, TS, il);
+      } else { double yy; linint_n(tx, ty, p2, (int)TS, ParZc, yy, Kprimec); }
+    }
+    const double KprimeZc = -1.0 * Kprimec * deltat;
+    const double Z3rdc = ParZc + 0.5 * KprimeZc;
+    double KH3rdc;
+    if (Z3rdc < P_depth || Z3rdc > P_zetac) {
+      KH3rdc = background;
+    } else {
+      if (cached) {
+        vt_seek(ci, Z3rdc, p2, tx, ty, typ, tsg, TS);
+        KH3rdc = hval_interval(Z3rdc, ci.X1, ci.X2, ci.Y1, ci.Y2, ci.P1, ci.P2, ci.SG);
+      } else if (sigerr == 0) {
+        KH3rdc = hval_table<false>(Z3rdc, p2, tx, ty, typ, tsg, TS, il);
+      } else { double mm; linint_n(tx, ty, p2, (int)TS, Z3rdc, KH3rdc, mm); }
+      if (KH3rdc < background) KH3rdc = background;
+    }
+    // norm(), norm_module.f90:25-39
+    const double dev1 = ((double)ltmt_temper(raw1) + 0.5) / 4294967296.0;
+    const double dev2 = ((double)ltmt_temper(raw2) + 0.5) / 4294967296.0;
+    const double DEV = sqrt(-2.0 * log(dev1)) * cos(2.0 * P.PI * dev2);
+    // (2/r * KH3rd * deltat)**0.5 with r = 1
+    ParZc = ParZc + KprimeZc + DEV * sqrt(2.0 / 1.0 * KH3rdc * deltat);
+  }
+  wsd[(size_t)WS_TURBV * N] = P_zc - ParZc;  // :342
+  if (sigerr != 0) atomicAdd(&P.counters[CNT_SIGERR], 1ull);
+}
