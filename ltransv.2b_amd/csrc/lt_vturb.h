@@ -184,8 +184,9 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
     return apply_getinterp(w0, fld(K, rn.x, ws, i, pslot[s]), fld(K, rn.y, ws, i, pslot[s]),
                            fld(K, rn.z, ws, i, pslot[s]), fld(K, rn.w, ws, i, pslot[s]));
   };
+  const Divisor dvh = prep_div((VT == 2) ? P.hc + h : h);  // every level depth divides by it
   auto WZ = [&](int s, int i) -> double {  // Pwc_wz{b,c,f}(i)
-    return level_at(level_coef(wtab, i, h, P.hc, VT), zeta[s], h, VT);
+    return level_at(level_coef_d(wtab, i, h, P.hc, VT, dvh), zeta[s], h, VT);
   };
   double wz1[3], wzN[3], kh1[3], khN[3], rng_[3];
 #pragma unroll
