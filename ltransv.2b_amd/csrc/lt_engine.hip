@@ -1380,7 +1380,7 @@ int lt_step(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32
       e->rng_before = 0;
       e->stats.rng_draws = own;
     }
-    // lt_profile_* times the dominant kernel of the configuration: k_vturb when
+    // lt_profile_* times the dominant kernel(s) of the configuration: the three VTurb kernels when
     // vertical turbulence is on, k_rk otherwise
     const bool prof_rk = prof && !e->cfg.VTurbOn, prof_vt = prof && e->cfg.VTurbOn;
     if (prof_rk) HIPCHK(e, hipEventRecord(e->prof_ev[e->prof_used], e->stream));

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void k_post(const StepParams P) {
       const double AdvectX = P.idt * (P_U * cosA - P_V * sinA);
       const double AdvectY = P.idt * (P_U * sinA + P_V * cosA);
       const double AdvectZ = P.idt * P_W;
-      // HTurb, hor_turb_module.f90:29-50: X deviate before Y; VTurb's TurbV from k_vturb
+      // HTurb, hor_turb_module.f90:29-50: X deviate before Y; VTurb's TurbV from k_vt_walk
       double TurbHx = 0.0, TurbHy = 0.0, TurbV = 0.0;
       if (P.HTurbOn) {
         const unsigned long long di = P.rng_base + (unsigned long long)(unsigned)P.rank[P.orig[n]];

@@ -376,13 +376,9 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
 }
 
 // ------------------------------------------------------------ the step
-// update_particles() is run as three kernels over the same particle index so
-// that the register-hungry RK4 part does not carry the state of the element
-// search and boundary code (occupancy), exchanging 13 doubles + one flag word
-// per particle through a workspace in HBM (SoA, stride numpar):
-//   k_pre   gates, setEle, setInterp/getInterp, vertical clamps   (per lane)
-//   k_rk    RK4 over find_currents/WCTS_ITPI                      (wave-cooperative)
-//   k_post  behaviour, reflection, boundaries, setEle, settlement, commit
+// The kernels of this file exchange a per-particle workspace in HBM (WS_* columns + one flag
+// word, SoA, stride numpar) with k_post and the VTurb kernels, so that the register-hungry
+// RK4 part does not carry the state of the element search and boundary code (lt_kernels.h).
 
 template <typename SlabT>
 __global__ __launch_bounds__(256) void k_pre(const StepParams P) {
