@@ -339,6 +339,25 @@ LT_DEV double ypc1_mid_d(double DXIM1, double DXI, const Divisor& dsum, double S
                      : dmax(dmin(0.0, T), -3.0 * dmin(ASIM1, ASI));
 }
 
+// The same two formulas with the hardware's min / max (one instruction instead of a compare
+// and two selects each), for the fast path of k_rk: identical values for finite operands;
+// only the SIGN of a zero result can differ from the compare-and-select forms above, and no
+// later operation of the path looks at the sign of a zero derivative (they are subtracted
+// from slopes, multiplied and compared with 0).  NaN operands do not reach it (degenerate
+// level windows are taken out before).
+LT_DEV double ypc1_end_f(double SI, double T) {
+  const double lim = 3.0 * SI;
+  return (SI >= 0.0) ? __builtin_fmin(__builtin_fmax(0.0, T), lim) : __builtin_fmax(__builtin_fmin(0.0, T), lim);
+}
+LT_DEV double ypc1_mid_f(double DXIM1, double DXI, const Divisor& dsum, double SIM1, double SI) {
+  const double T = div_prep(DXIM1 * SI + DXI * SIM1, dsum);
+  const double ASIM1 = fabs(SIM1), ASI = fabs(SI);
+  double SGN = fsign1(SI);
+  if (ASIM1 > ASI) SGN = fsign1(SIM1);
+  const double lim = 3.0 * __builtin_fmin(ASIM1, ASI);
+  return (SGN > 0.0) ? __builtin_fmin(__builtin_fmax(0.0, T), lim) : __builtin_fmax(__builtin_fmin(0.0, T), -lim);
+}
+
 // YPC1 for N = 4.  ier != 0 when the abscissae are not strictly increasing.
 LT_DEV void ypc1_4(const double (&X)[4], const double (&Y)[4], double (&YP)[4], int& ier) {
   double DX1 = X[1] - X[0], DX2 = X[2] - X[1], DX3 = X[3] - X[2];
@@ -534,6 +553,13 @@ LT_DEV bool sigs_candidate(double S, double S1, double S2, double& num, double& 
   num = ab ? D1 : D2;
   den = ab ? D2 : D1;
   return (D1 * D2 > 0.0) && ((ab ? a : b) > 2.0 * (ab ? b : a));
+}
+
+// the test alone (the operands of the quotient are formed only for the few candidates)
+LT_DEV bool sigs_candidate_test(double S, double S1, double S2) {
+  const double D1 = S - S1, D2 = S2 - S;
+  const double a = fabs(D1), b = fabs(D2);
+  return (D1 * D2 > 0.0) && (__builtin_fmax(a, b) > 2.0 * __builtin_fmin(a, b));
 }
 
 // Screening of the EVALUATION interval: true = its tension factor is known

@@ -286,10 +286,10 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
         SL[0] = div_prep(Y[1] - Y[0], d1);
         SL[1] = div_prep(Y[2] - Y[1], d2);
         SL[2] = div_prep(Y[3] - Y[2], d3);
-        YP[0] = ypc1_end(SL[0], SL[0] + div_prep(DX1 * (SL[0] - SL[1]), d12));
-        YP[1] = ypc1_mid_d(DX1, DX2, d12, SL[0], SL[1]);
-        YP[2] = ypc1_mid_d(DX2, DX3, d23, SL[1], SL[2]);
-        YP[3] = ypc1_end(SL[2], SL[2] + div_prep(DX3 * (SL[2] - SL[1]), d23));
+        YP[0] = ypc1_end_f(SL[0], SL[0] + div_prep(DX1 * (SL[0] - SL[1]), d12));
+        YP[1] = ypc1_mid_f(DX1, DX2, d12, SL[0], SL[1]);
+        YP[2] = ypc1_mid_f(DX2, DX3, d23, SL[1], SL[2]);
+        YP[3] = ypc1_end_f(SL[2], SL[2] + div_prep(DX3 * (SL[2] - SL[1]), d23));
         I = (Pzs < X[1]) ? 1 : (Pzs < X[2]) ? 2 : 3;
         if (Pzs > X[3]) I = 3;
         x1 = (I == 1) ? X[0] : (I == 2) ? X[1] : X[2];
@@ -307,14 +307,20 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
       bool evdone = false;
       double sigI = 0.0;
       {
-        double n0, d0, n1, d1, n2, d2;
-        const bool c0 = ok && sigs_candidate(SL[0], YP[0], YP[1], n0, d0);
-        const bool c1 = ok && sigs_candidate(SL[1], YP[1], YP[2], n1, d1);
-        const bool c2 = ok && sigs_candidate(SL[2], YP[2], YP[3], n2, d2);
+        const bool c0 = ok && sigs_candidate_test(SL[0], YP[0], YP[1]);
+        const bool c1 = ok && sigs_candidate_test(SL[1], YP[1], YP[2]);
+        const bool c2 = ok && sigs_candidate_test(SL[2], YP[2], YP[3]);
         // the two non-evaluation intervals: I=1 -> (2,3), I=2 -> (1,3), I=3 -> (1,2)
         const bool ca = (I == 1) ? c1 : c0, cb = (I == 3) ? c1 : c2;
-        const double na = (I == 1) ? n1 : n0, da = (I == 1) ? d1 : d0;
-        const double nb = (I == 3) ? n1 : n2, db = (I == 3) ? d1 : d2;
+        double na = 0.0, da = 0.0, nb = 0.0, db = 0.0;
+        if (ca) {  // ~1 % of the intervals: the operands of T = MAX(D1/D2, D2/D1)
+          if (I == 1) (void)sigs_candidate(SL[1], YP[1], YP[2], na, da);
+          else (void)sigs_candidate(SL[0], YP[0], YP[1], na, da);
+        }
+        if (cb) {
+          if (I == 3) (void)sigs_candidate(SL[1], YP[1], YP[2], nb, db);
+          else (void)sigs_candidate(SL[2], YP[2], YP[3], nb, db);
+        }
         if (ok) evdone = sigs_eval_known(Sv, p1, p2, sigI);
         const bool neede = ok && !evdone;
         const unsigned long long ma = __ballot(ca), mb = __ballot(cb), me = __ballot(neede);
