@@ -864,6 +864,16 @@ LT_DEV QuadWeights quad_weights(double xp, double yp, const double (&x)[4], cons
 }
 
 // interp() value formula, hydrodynamic_module.f90:2530-2561
+// apply_interp for values whose node order was already rotated to (3,4,1,2) when the weights
+// are those of the second triangle (regime 2): both triangle forms are v1+(v2-v1)t+(v3-v1)u
+LT_DEV double apply_interp_rot(const QuadWeights& w, double v1, double v2, double v3, double v4) {
+  double r = v1 + (v2 - v1) * w.t + (v3 - v1) * w.u;
+  if (w.regime >= 3) {
+    if (w.regime == 3) r = w.W1 * v1 + w.W2 * v2 + w.W3 * v3 + w.W4 * v4;
+    else r = (w.node_hit == 1) ? v1 : (w.node_hit == 2) ? v2 : (w.node_hit == 3) ? v3 : v4;
+  }
+  return r;
+}
 LT_DEV double apply_interp(const QuadWeights& w, double v1, double v2, double v3, double v4) {
   // regimes 1 and 2 share one expression with permuted operands
   // (v1+(v2-v1)*t+(v3-v1)*u  |  v3+(v4-v3)*t+(v1-v3)*u): select, then evaluate once

@@ -238,6 +238,22 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
       else if (var == 1) nd_next = P.RE[er - 1];
       w = quad_weights(Xs, Ys, q.x, q.y);
     }
+    // The second-triangle form (regime 2) is the first-triangle form on the nodes (3,4,1):
+    // v3+(v4-v3)t+(v1-v3)u.  Instead of selecting the operands at every one of the 12
+    // interpolations of this variable, the node order itself is rotated once: the values of
+    // slot 0 (already requested) with one select each on the stored type, the base pointers
+    // for the two later requests.  Regimes 3 / 4 (inverse distance, on a node) keep (1,2,3,4).
+    const bool rot = spl && (w.regime == 2);
+    if (rot) {
+#pragma unroll
+      for (int l = 0; l < 4; l++) {
+        const SlabT r0 = raw[4 * l + 0], r1 = raw[4 * l + 1];
+        raw[4 * l + 0] = raw[4 * l + 2]; raw[4 * l + 1] = raw[4 * l + 3];
+        raw[4 * l + 2] = r0; raw[4 * l + 3] = r1;
+      }
+      const SlabT *t0 = b0, *t1 = b1;
+      b0 = b2; b1 = b3; b2 = t0; b3 = t1;
+    }
     TICK(1);
     if (loglayer) {
       // log layer :1493-1522: level 1 of u,v; level 2 of w
@@ -272,8 +288,8 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
 #pragma unroll
         for (int l = 0; l < 4; l++) {
           X[l] = level_at(lc[l], zeta, h, VT);
-          Y[l] = apply_interp(w, (double)raw[4 * l + 0], (double)raw[4 * l + 1],
-                              (double)raw[4 * l + 2], (double)raw[4 * l + 3]);
+          Y[l] = apply_interp_rot(w, (double)raw[4 * l + 0], (double)raw[4 * l + 1],
+                                  (double)raw[4 * l + 2], (double)raw[4 * l + 3]);
         }
         if (s < 2) request(s + 1);
         const double DX1 = X[1] - X[0], DX2 = X[2] - X[1], DX3 = X[3] - X[2];
