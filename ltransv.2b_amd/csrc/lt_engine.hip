@@ -1177,6 +1177,100 @@ int lt_test_div(const double* a, const double* b, double* q_fast, double* q_ref,
   return rc == hipSuccess ? LT_OK : LT_ERR_DEVICE;
 }
 
+/* test aid (device): the leaf numerics of lt_math.h on caller-supplied inputs, one item per
+ * thread, so that tests can hold them against the vectors the REFERENCE's own modules produced
+ * (tests/golden/leaf_golden.npz).  kind 1: polintd3, rows (xa1..3, ya1..3, x) -> y.
+ * kind 2: gridcell_one, rows (ex1..4, ey1..4, x, y) -> 0/1.  kind 3: SNHCSH, x -> 3 values.
+ * kind 4: a 4-knot spline, rows (x1..4, y1..4, t1..8) -> 37 values: the reference-shaped
+ * YPC1 (4), SIGS tensions (3, zeros after a SigErr), SigErr count, HVAL and HPVAL at the 8
+ * points (16); then what the fast path of k_rk computes for the same knots: YPC1 through the
+ * prepared divisors and the hardware min / max (4), tensions through sigs_classify +
+ * sigs_newton / sigs_secant (3), SigErr flag, HVAL at the 8 points through hval_interval_s (8;
+ * the last 5 unused). */
+__global__ void k_test_leaf(int kind, const double* in, double* out, int n) {
+  using namespace ltd;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (kind == 1) {
+    const double* r = in + (size_t)i * 7;
+    out[i] = polintd3(r[0], r[1], r[2], r[3], r[4], r[5], r[6]);
+  } else if (kind == 2) {
+    const double* r = in + (size_t)i * 10;
+    const double qx[4] = {r[0], r[1], r[2], r[3]}, qy[4] = {r[4], r[5], r[6], r[7]};
+    out[i] = gridcell_one(qx, qy, r[8], r[9]) ? 1.0 : 0.0;
+  } else if (kind == 3) {
+    double a, b, c;
+    snhcsh(in[i], a, b, c);
+    out[3 * (size_t)i] = a; out[3 * (size_t)i + 1] = b; out[3 * (size_t)i + 2] = c;
+  } else if (kind == 4) {
+    const double* r = in + (size_t)i * 16;
+    double* o = out + (size_t)i * 37;
+    const double X[4] = {r[0], r[1], r[2], r[3]}, Y[4] = {r[4], r[5], r[6], r[7]};
+    double YP[4], SG[3] = {0.0, 0.0, 0.0};
+    int ier = 0, sigerr = 0;
+    ypc1_4(X, Y, YP, ier);
+    for (int iv = 0; iv < 3 && ier == 0; iv++) {
+      const double sg = sigs_interval(X[iv + 1] - X[iv], Y[iv], Y[iv + 1], YP[iv], YP[iv + 1], sigerr);
+      if (sigerr != 0) break;  // SIGS returns at the first failure
+      SG[iv] = sg;
+    }
+    for (int k = 0; k < 4; k++) o[k] = YP[k];
+    for (int k = 0; k < 3; k++) o[4 + k] = SG[k];
+    o[7] = (double)sigerr;
+    for (int k = 0; k < 8; k++) {
+      const double T = r[8 + k];
+      int I = (T < X[1]) ? 1 : (T < X[2]) ? 2 : 3;
+      if (T > X[3]) I = 3;
+      o[8 + k] = hval_interval(T, X[I - 1], X[I], Y[I - 1], Y[I], YP[I - 1], YP[I], SG[I - 1]);
+      o[16 + k] = hpval_interval(T, X[I - 1], X[I], Y[I - 1], Y[I], YP[I - 1], YP[I], SG[I - 1]);
+    }
+    // the fast path's forms
+    const double DX1 = X[1] - X[0], DX2 = X[2] - X[1], DX3 = X[3] - X[2];
+    const Divisor d1 = prep_div(DX1), d2 = prep_div(DX2), d3 = prep_div(DX3);
+    const Divisor d12 = prep_div(DX1 + DX2), d23 = prep_div(DX2 + DX3);
+    double SL[3], YF[4], SF[3] = {0.0, 0.0, 0.0};
+    SL[0] = div_prep(Y[1] - Y[0], d1); SL[1] = div_prep(Y[2] - Y[1], d2); SL[2] = div_prep(Y[3] - Y[2], d3);
+    YF[0] = ypc1_end_f(SL[0], SL[0] + div_prep(DX1 * (SL[0] - SL[1]), d12));
+    YF[1] = ypc1_mid_f(DX1, DX2, d12, SL[0], SL[1]);
+    YF[2] = ypc1_mid_f(DX2, DX3, d23, SL[1], SL[2]);
+    YF[3] = ypc1_end_f(SL[2], SL[2] + div_prep(DX3 * (SL[2] - SL[1]), d23));
+    bool anyfail = false;
+    for (int iv = 0; iv < 3; iv++) {
+      double sg = 0.0, T = 0.0;
+      bool failed = false;
+      const int kind2 = sigs_classify(SL[iv], YF[iv], YF[iv + 1], sg, T);
+      if (kind2 == SIGK_NEWTON) sg = sigs_newton(T, failed);
+      else if (kind2 == SIGK_SECANT) sg = sigs_secant(SL[iv], YF[iv], YF[iv + 1]);
+      SF[iv] = sg;
+      anyfail = anyfail || failed;
+    }
+    for (int k = 0; k < 4; k++) o[24 + k] = YF[k];
+    for (int k = 0; k < 3; k++) o[28 + k] = SF[k];
+    o[31] = anyfail ? 1.0 : 0.0;
+    for (int k = 0; k < 5; k++) {
+      const double T = r[8 + k];
+      int I = (T < X[1]) ? 1 : (T < X[2]) ? 2 : 3;
+      if (T > X[3]) I = 3;
+      o[32 + k] = hval_interval_s(T, X[I - 1], X[I], Y[I - 1], YF[I - 1], YF[I], SL[I - 1], SF[I - 1]);
+    }
+  }
+}
+int lt_test_leaf(int32_t kind, const double* in, int32_t n, int32_t in_per_item, double* out, int32_t out_per_item) {
+  if (!in || !out || n < 0 || kind < 1 || kind > 4) return LT_ERR_ARG;
+  const int expect_in[5] = {0, 7, 10, 1, 16}, expect_out[5] = {0, 1, 1, 3, 37};
+  if (in_per_item != expect_in[kind] || out_per_item != expect_out[kind]) return LT_ERR_ARG;
+  double *di = nullptr, *dout = nullptr;
+  const size_t bi = (size_t)n * in_per_item * 8, bo = (size_t)n * out_per_item * 8;
+  if (hipMalloc(&di, bi + 8) != hipSuccess || hipMalloc(&dout, bo + 8) != hipSuccess) return LT_ERR_NOMEM;
+  (void)hipMemcpy(di, in, bi, hipMemcpyHostToDevice);
+  (void)hipMemset(dout, 0, bo);
+  hipLaunchKernelGGL(k_test_leaf, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, (int)kind, di, dout, (int)n);
+  const hipError_t rc = hipDeviceSynchronize();
+  (void)hipMemcpy(out, dout, bo, hipMemcpyDeviceToHost);
+  (void)hipFree(di); (void)hipFree(dout);
+  return rc == hipSuccess ? LT_OK : LT_ERR_DEVICE;
+}
+
 /* test aid (device): n tempered words of the engine's stream starting `offset` words
  * after the cursor, read back from the materialised ring. */
 int lt_test_mt_ring(lt_engine* e, uint64_t offset, int32_t n, uint32_t* out) {
