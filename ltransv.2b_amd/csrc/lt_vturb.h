@@ -83,7 +83,73 @@ LT_DEV void polintd3x3(const StepParams& P, double ya1, double ya2, double ya3,
 // For a strictly increasing abscissa table INTRVL's answer (:1287-1354) is the unique
 // I with X(I) <= T < X(I+1), clamped to 1..N-1, whatever its saved IL was, so
 // stepping from the cached interval finds the same I as its bisection.
-struct VtInterval { int I; double X1, X2, Y1, Y2, P1, P2, SG; };
+// Beside the knot data it holds what HVAL / HPVAL compute from the interval alone (chord
+// slope, second differences, the prepared divisor DX and, for 1e-9 <= sigma <= .5, SNHCSH of
+// sigma), formed once when the interval is entered: the same operations, hoisted.
+struct VtInterval {
+  int I;
+  double X1, X2, Y1, Y2, P1, P2, SG;
+  double S, D1, D2, SM, CM, CMM;
+  Divisor dx;
+};
+LT_DEV void vt_prepare(VtInterval& c) {
+  const double DX = c.X2 - c.X1;
+  c.dx = prep_div(DX);
+  c.S = (c.Y2 - c.Y1) / DX;
+  c.D1 = c.S - c.P1;
+  c.D2 = c.P2 - c.S;
+  const double SIG = fabs(c.SG);
+  c.SM = c.CM = c.CMM = 0.0;
+  if (SIG >= 1.e-9 && SIG <= .5) snhcsh(SIG, c.SM, c.CM, c.CMM);
+}
+// HVAL (tension_module.f90:1052-1117) and HPVAL (:1196-1250) on the prepared interval
+LT_DEV double hval_prepared(double T, const VtInterval& c) {
+  const double DX = c.X2 - c.X1, U = T - c.X1;
+  const double B2 = div_prep(U, c.dx), B1 = 1.0 - B2;
+  const double S1 = c.P1, S = c.S, D1 = c.D1, D2 = c.D2, SIG = fabs(c.SG);
+  if (SIG < 1.e-9) {
+    return c.Y1 + U * (S1 + B2 * (D1 + B1 * (D1 - D2)));
+  } else if (SIG <= .5) {
+    double SB2 = SIG * B2, SM2, CM2, DUMMY;
+    const double SM = c.SM, CM = c.CM, CMM = c.CMM;
+    snhcsh(SB2, SM2, CM2, DUMMY);
+    const double E = SIG * SM - CMM - CMM;
+    return c.Y1 + S1 * U +
+           DX * ((CM * SM2 - SM * CM2) * (D1 + D2) + SIG * (CM * CM2 - (SM + SIG) * SM2) * D1) / (SIG * E);
+  } else {
+    const double SB1 = SIG * B1, SB2 = SIG - SB1;
+    if (-SB1 > LT_SBIG || -SB2 > LT_SBIG) return c.Y1 + S * U;
+    const double E1 = exp(-SB1), E2 = exp(-SB2);
+    const double EMS = E1 * E2, TM = 1.0 - EMS, TS = TM * TM, TP = 1.0 + EMS;
+    const double E = TM * (SIG * TP - TM - TM);
+    return c.Y1 + S * U +
+           DX * (TM * (TP - E1 - E2) * (D1 + D2) +
+                 SIG * ((E2 + EMS * (E1 - 2.0) - B1 * TS) * D1 + (E1 + EMS * (E2 - 2.0) - B2 * TS) * D2)) /
+               (SIG * E);
+  }
+}
+LT_DEV double hpval_prepared(double T, const VtInterval& c) {
+  const double B1 = div_prep(c.X2 - T, c.dx), B2 = 1.0 - B1;
+  const double S1 = c.P1, S = c.S, D1 = c.D1, D2 = c.D2, SIG = fabs(c.SG);
+  if (SIG < 1.e-9) {
+    return S1 + B2 * (D1 + D2 - 3.0 * B1 * (D2 - D1));
+  } else if (SIG <= .5) {
+    double SB2 = SIG * B2, SM2, CM2, DUMMY;
+    const double SM = c.SM, CM = c.CM, CMM = c.CMM;
+    snhcsh(SB2, SM2, CM2, DUMMY);
+    const double SINH2 = SM2 + SB2;
+    const double E = SIG * SM - CMM - CMM;
+    return S1 + ((CM * CM2 - SM * SINH2) * (D1 + D2) + SIG * (CM * SINH2 - (SM + SIG) * CM2) * D1) / E;
+  } else {
+    const double SB1 = SIG * B1, SB2 = SIG - SB1;
+    if (-SB1 > LT_SBIG || -SB2 > LT_SBIG) return S;
+    const double E1 = exp(-SB1), E2 = exp(-SB2);
+    const double EMS = E1 * E2, TM = 1.0 - EMS;
+    const double E = TM * (SIG * (1.0 + EMS) - TM - TM);
+    return S + (TM * ((E2 - E1) * (D1 + D2) + TM * (D1 - D2)) +
+                SIG * ((E1 * EMS - E2) * D1 + (E1 - E2 * EMS) * D2)) / E;
+  }
+}
 LT_DEV void vt_seek(VtInterval& c, double T, int n, const double* x, const double* y,
                     const double* yp, const double* sig, size_t stride) {
   bool moved = false;
@@ -103,6 +169,7 @@ LT_DEV void vt_seek(VtInterval& c, double T, int n, const double* x, const doubl
   if (moved) {
     const size_t a = (size_t)(c.I - 1) * stride, b = (size_t)c.I * stride;
     c.Y1 = y[a]; c.Y2 = y[b]; c.P1 = yp[a]; c.P2 = yp[b]; c.SG = sig[a];
+    vt_prepare(c);
   }
 }
 
@@ -412,6 +479,7 @@ __global__ __launch_bounds__(256) void k_vt_walk(const StepParams P) {
   int il = 1;
   VtInterval ci;
   ci.I = 0; ci.X1 = ci.X2 = ci.Y1 = ci.Y2 = ci.P1 = ci.P2 = ci.SG = 0.0;
+  ci.S = ci.D1 = ci.D2 = ci.SM = ci.CM = ci.CMM = 0.0; ci.dx.b = 1.0; ci.dx.y = 1.0;
   const bool cached = (sigerr == 0) && !ypc_fail;
 #pragma unroll 1
   for (int i = 1; i <= loop; i++) {
@@ -443,7 +511,7 @@ __global__ __launch_bounds__(256) void k_vt_walk(const StepParams P) {
     if (!(ParZc < P_depth || ParZc > P_zetac)) {
       if (cached) {
         vt_seek(ci, ParZc, p2, tx, ty, typ, tsg, TS);
-        Kprimec = hpval_interval(ParZc, ci.X1, ci.X2, ci.Y1, ci.Y2, ci.P1, ci.P2, ci.SG);
+        Kprimec = hpval_prepared(ParZc, ci);
       } else if (sigerr == 0) {
         Kprimec = hval_table<true>(ParZc, p2, tx, ty, typ, tsg, TS, il);
       } else { double yy; linint_n(tx, ty, p2, (int)TS, ParZc, yy, Kprimec); }
@@ -456,7 +524,7 @@ __global__ __launch_bounds__(256) void k_vt_walk(const StepParams P) {
     } else {
       if (cached) {
         vt_seek(ci, Z3rdc, p2, tx, ty, typ, tsg, TS);
-        KH3rdc = hval_interval(Z3rdc, ci.X1, ci.X2, ci.Y1, ci.Y2, ci.P1, ci.P2, ci.SG);
+        KH3rdc = hval_prepared(Z3rdc, ci);
       } else if (sigerr == 0) {
         KH3rdc = hval_table<false>(Z3rdc, p2, tx, ty, typ, tsg, TS, il);
       } else { double mm; linint_n(tx, ty, p2, (int)TS, Z3rdc, KH3rdc, mm); }
