@@ -515,11 +515,17 @@ void wait_rng(lt_engine* e) {
 }
 template <typename SlabT>
 void launch_vturb_t(lt_engine* e, const StepParams& P, unsigned blocks) {
+#define LT_LAUNCH_VT_TABLE(VT)                                                                         \
+  do {                                                                                                \
+    if (P.fastdiv) hipLaunchKernelGGL((k_vt_table<SlabT, VT, true>), dim3(blocks), dim3(256), 0, e->stream, P); \
+    else hipLaunchKernelGGL((k_vt_table<SlabT, VT, false>), dim3(blocks), dim3(256), 0, e->stream, P);          \
+  } while (0)
   switch (e->cfg.Vtransform) {
-    case 1: hipLaunchKernelGGL((k_vt_table<SlabT, 1>), dim3(blocks), dim3(256), 0, e->stream, P); break;
-    case 2: hipLaunchKernelGGL((k_vt_table<SlabT, 2>), dim3(blocks), dim3(256), 0, e->stream, P); break;
-    default: hipLaunchKernelGGL((k_vt_table<SlabT, 3>), dim3(blocks), dim3(256), 0, e->stream, P); break;
+    case 1: LT_LAUNCH_VT_TABLE(1); break;
+    case 2: LT_LAUNCH_VT_TABLE(2); break;
+    default: LT_LAUNCH_VT_TABLE(3); break;
   }
+#undef LT_LAUNCH_VT_TABLE
   hipLaunchKernelGGL(k_vt_sigs, dim3(blocks), dim3(256), 0, e->stream, P);
   wait_rng(e);
   hipLaunchKernelGGL(k_vt_walk, dim3(blocks), dim3(256), 0, e->stream, P);

@@ -67,10 +67,11 @@ LT_DEV double polintd_shared(double xa1, double xa2, double xa3, double ya1, dou
   const double dns = (ns == 1) ? d1 : (ns == 2) ? d2 : d3;
   return yns + dns * a + bb * c;
 }
+template <bool FD>
 LT_DEV void polintd3x3(const StepParams& P, double ya1, double ya2, double ya3,
                        double& rb, double& rc, double& rf) {
   const double xa1 = P.ex0, xa2 = P.ex1, xa3 = P.ex2;
-  const bool fd = P.fastdiv != 0;
+  constexpr bool fd = FD;
   const double q32 = div_by(ya3 - ya2, xa2 - xa3, P.r_d23, fd);
   const double q21 = div_by(ya2 - ya1, xa1 - xa2, P.r_d12, fd);
   rb = polintd_shared(xa1, xa2, xa3, ya1, ya2, ya3, q32, q21, P.r_d13, fd, P.ix0, P.pns0);
@@ -217,7 +218,9 @@ LT_DEV void vt_run_tasks(VtScratch& q, int ntask, int lane, int wave_first, doub
 // SIGS' "RETURN at the first SigErr" leaves later tensions at 0 in the reference;
 // since SigErr switches every later evaluation to linint, which ignores the
 // tensions, computing all of them here changes nothing.
-template <typename SlabT, int VT>
+// FD: the per-step divisors (4*ws, 6, the ex differences) have usable reciprocals (div_by);
+// a template parameter so that the ~20 quotients per knot carry no branch
+template <typename SlabT, int VT, bool FD>
 __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
   __shared__ double lev[6 * LT_LEV_STRIDE];
   __shared__ double wring[3][8][256];
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
     rng_[s] = wzN[s] - wz1[s];
   }
   auto NEWX = [&](int s, int j) -> double {  // :121-123
-    return wz1[s] + div_by(((double)(float)(j - 4)) * rng_[s], (double)p2, P.r_p2, P.fastdiv != 0);
+    return wz1[s] + div_by(((double)(float)(j - 4)) * rng_[s], (double)p2, P.r_p2, FD);
   };
   // piecewise-linear profile segment per slot :126-163.  Moving up one level reuses
   // the upper end of the previous segment (same values), and the Kh of the level after
@@ -335,13 +338,13 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
       double ex1 = mx0, ex2 = mx1, ex3 = mx2, ey1 = my0, ey2 = my1, ey3 = my2;
       if (P.p == 1) { ex2 = mx0; ex3 = mx1; ey2 = my0; ey3 = my1; }
       double fxb, fxc, fxf, fyb, fyc, fyf;
-      polintd3x3(P, ex1, ex2, ex3, fxb, fxc, fxf);
-      polintd3x3(P, ey1, ey2, ey3, fyb, fyc, fyf);
+      polintd3x3<FD>(P, ex1, ex2, ex3, fxb, fxc, fxf);
+      polintd3x3<FD>(P, ey1, ey2, ey3, fyb, fyc, fyf);
       if (fyb < 0.0) fyb = 0.0;
       if (fyc < 0.0) fyc = 0.0;
       if (fyf < 0.0) fyf = 0.0;
-      const double yk = div_by(fyb + 4.0 * fyc + fyf, 6.0, P.r_6, P.fastdiv != 0);
-      const double xk = div_by(fxb + 4.0 * fxc + fxf, 6.0, P.r_6, P.fastdiv != 0);
+      const double yk = div_by(fyb + 4.0 * fyc + fyf, 6.0, P.r_6, FD);
+      const double xk = div_by(fxb + 4.0 * fxc + fxf, 6.0, P.r_6, FD);
       tx[(size_t)(k - 1) * TS] = xk;
       ty[(size_t)(k - 1) * TS] = yk;
       // TSPSI(p2) as a stream: YPC1 (tension_module.f90:852-977), SIGS (:314-781)
