@@ -322,15 +322,15 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
       double mx[3], my[3];
 #pragma unroll
       for (int s = 0; s < 3; s++) {
-        if (k == 1) { mx[s] = wz1[s]; my[s] = kh1[s]; }            // :197-210 pinned ends
-        else if (k == p2) { mx[s] = wzN[s]; my[s] = khN[s]; }
-        else {                                                      // :184-194 8-point average
-          const int t = threadIdx.x;
-          my[s] = (wring[s][k & 7][t] + wring[s][(k + 1) & 7][t] + wring[s][(k + 2) & 7][t] + wring[s][(k + 3) & 7][t] +
-                   wring[s][(k + 4) & 7][t] + wring[s][(k + 5) & 7][t] + wring[s][(k + 6) & 7][t] + wring[s][(k + 7) & 7][t]) / 8.0;
-          const double xa = NEWX(s, k);
-          mx[s] = xa + (NEWX(s, k + 7) - xa) / 2.0;
-        }
+        // :184-194 8-point average (formed at every k, selected below: no branch)
+        const int t = threadIdx.x;
+        const double av = (wring[s][k & 7][t] + wring[s][(k + 1) & 7][t] + wring[s][(k + 2) & 7][t] + wring[s][(k + 3) & 7][t] +
+                           wring[s][(k + 4) & 7][t] + wring[s][(k + 5) & 7][t] + wring[s][(k + 6) & 7][t] + wring[s][(k + 7) & 7][t]) / 8.0;
+        const double xa = NEWX(s, k);
+        const double xm = xa + (NEWX(s, k + 7) - xa) / 2.0;
+        // :197-210 pinned ends
+        mx[s] = (k == 1) ? wz1[s] : (k == p2) ? wzN[s] : xm;
+        my[s] = (k == 1) ? kh1[s] : (k == p2) ? khN[s] : av;
       }
       // :220-275 interpolation to the internal times, clamp, Simpson in time
       // (selects on values, not on array elements: those would turn into stack indexing)
