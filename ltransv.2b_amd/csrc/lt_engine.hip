@@ -1192,9 +1192,10 @@ int lt_test_div(const double* a, const double* b, double* q_fast, double* q_ref,
  * points (16); then what the fast path of k_rk computes for the same knots: YPC1 through the
  * prepared divisors and the hardware min / max (4), tensions through sigs_classify +
  * sigs_newton / sigs_secant (3), SigErr flag, HVAL at the 8 points through hval_interval_s (8;
- * the last 5 unused). */
+ * the last 5 unused).  kind 5: x -> exp_core(x), lt_exp(x) (the host-libm-exact exp). */
 __global__ void k_test_leaf(int kind, const double* in, double* out, int n) {
   using namespace ltd;
+  exp_table_load();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   if (kind == 1) {
@@ -1259,11 +1260,14 @@ __global__ void k_test_leaf(int kind, const double* in, double* out, int n) {
       if (T > X[3]) I = 3;
       o[32 + k] = hval_interval_s(T, X[I - 1], X[I], Y[I - 1], YF[I - 1], YF[I], SL[I - 1], SF[I - 1]);
     }
+  } else if (kind == 5) {
+    out[2 * (size_t)i] = exp_core(in[i]);
+    out[2 * (size_t)i + 1] = lt_exp(in[i]);
   }
 }
 int lt_test_leaf(int32_t kind, const double* in, int32_t n, int32_t in_per_item, double* out, int32_t out_per_item) {
-  if (!in || !out || n < 0 || kind < 1 || kind > 4) return LT_ERR_ARG;
-  const int expect_in[5] = {0, 7, 10, 1, 16}, expect_out[5] = {0, 1, 1, 3, 37};
+  if (!in || !out || n < 0 || kind < 1 || kind > 5) return LT_ERR_ARG;
+  const int expect_in[6] = {0, 7, 10, 1, 16, 1}, expect_out[6] = {0, 1, 1, 3, 37, 2};
   if (in_per_item != expect_in[kind] || out_per_item != expect_out[kind]) return LT_ERR_ARG;
   double *di = nullptr, *dout = nullptr;
   const size_t bi = (size_t)n * in_per_item * 8, bo = (size_t)n * out_per_item * 8;

@@ -14,6 +14,7 @@
 // comparison chain, and nothing is allocated.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "lt_exp_table.h"
 
 namespace ltd {
 
@@ -72,6 +73,79 @@ LT_DEV double div_prep(double a, const Divisor& d) {
   const double r = __builtin_fma(-d.b, q, a);
   // a zero numerator: q already is the zero of the right sign, the correction would lose it
   return (a == 0.0) ? q : __builtin_fma(r, d.y, q);
+}
+
+// exp() as the CPU run of LTRANS evaluates it.  The tension-spline code branches on quantities that
+// depend on the last bit of exp (SIGS' Newton stopping tests and its 10000-iteration SigErr exit,
+// tension_module.f90:531-580), so a merely faithful exp makes a few particles per million take the
+// other branch and their trajectories drift apart over hundreds of steps.  The host libm (glibc >= 2.28
+// on an FMA-capable x86-64: the published table-driven algorithm, N = 128, degree-5 polynomial) is a
+// fixed sequence of 8 fma, 3 mul, 2 add and one table read; restated here operation for operation it
+// returns the same bits (tests/test_gpu_div.py checks 2.5e6 arguments against the host) and is ~3x
+// shorter than the device library's exp.  The 2 KB table is copied to LDS by every kernel that
+// evaluates an exp (exp_table_load(), before any early exit): the read sits on the dependency chain
+// of the Newton iteration.
+//   exp_core(x): |x| < 512 (HVAL/HPVAL: |SIG*B| <= 170; SNHCSH; the secant loop, SIG <= 85; x2lon/y2lat)
+//   lt_exp(x):   any x <= 0 the way libm's out-of-line path does it (unfused scale + scale*tmp on a
+//                2^1022-scaled value, the double-double fix-up of subnormal results, 0 below -1024) --
+//                the Newton loop starts at SIG = sqrt(10 T - 20) with T unbounded -- and the device
+//                library's exp for x >= 512, which no caller produces.
+struct ExpPair { unsigned long long tail, sbits; };
+__device__ const ExpPair g_exp_tab[128] __attribute__((aligned(16))) = LT_EXP_TABLE_INIT;
+__shared__ ExpPair s_exp_tab[128];
+
+LT_DEV void exp_table_load() {
+  for (int i = threadIdx.x; i < 128; i += blockDim.x) s_exp_tab[i] = g_exp_tab[i];
+  __syncthreads();
+}
+
+// exp(x) = scale * (1 + tmp): the polynomial part and the bits of the scale 2^(k/128)
+LT_DEV void exp_parts(double x, double& tmp, unsigned long long& sbits) {
+  const double InvLn2N = 0x1.71547652b82fep+7, Shift = 0x1.8p+52;
+  const double NegLn2hiN = -0x1.62e42fefa0000p-8, NegLn2loN = -0x1.cf79abc9e3b3ap-47;
+  const double C2 = 0x1.ffffffffffdbdp-2, C3 = 0x1.555555555543cp-3;
+  const double C4 = 0x1.55555cf172b91p-5, C5 = 0x1.1111167a4d017p-7;
+  const double z = __builtin_fma(x, InvLn2N, Shift);
+  const unsigned long long ki = (unsigned long long)__double_as_longlong(z);
+  const double kd = z - Shift;
+  double r = __builtin_fma(kd, NegLn2hiN, x);
+  r = __builtin_fma(kd, NegLn2loN, r);
+  const ExpPair e = s_exp_tab[ki & 127u];
+  const double tail = __longlong_as_double((long long)e.tail);
+  sbits = e.sbits + (ki << 45);
+  const double p23 = __builtin_fma(C3, r, C2);
+  const double t3 = r + tail;
+  const double r2 = r * r;
+  const double p45 = __builtin_fma(r, C5, C4);
+  tmp = __builtin_fma(p23, r2, t3);
+  const double r4 = r2 * r2;
+  tmp = __builtin_fma(r4, p45, tmp);
+}
+LT_DEV double exp_core(double x) {
+  double tmp;
+  unsigned long long sbits;
+  exp_parts(x, tmp, sbits);
+  const double scale = __longlong_as_double((long long)sbits);
+  return __builtin_fma(scale, tmp, scale);
+}
+LT_DEV double lt_exp(double x) {
+  if (fabs(x) < 512.0) return exp_core(x);
+  if (!(x < 0.0)) return exp(x);  // x >= 512 or NaN
+  if (x <= -1024.0) return 0.0;
+  double tmp;
+  unsigned long long sbits;
+  exp_parts(x, tmp, sbits);
+  const double scale = __longlong_as_double((long long)(sbits + (1022ull << 52)));
+  const double st = scale * tmp;
+  double y = scale + st;
+  if (y < 1.0) {  // subnormal result: round once, at the final scaling
+    double lo = scale - y + st;
+    const double hi = 1.0 + y;
+    lo = 1.0 - hi + y + lo;
+    y = (hi + lo) - 1.0;
+    if (y == 0.0) y = 0.0;
+  }
+  return 0x1p-1022 * y;
 }
 
 // SIGS' convexity Newton iteration (tension_module.f90:531-580) gives up after
@@ -174,7 +248,7 @@ LT_DEV void snhcsh(double X, double& SINHM, double& COSHM, double& COSHMM) {
     COSHMM = XSD2 * F * (F + 2.0);
     COSHM = COSHMM + XSD2;
   } else {
-    double EXPX = exp(AX);
+    double EXPX = exp_core(AX);
     SINHM = -(((1.0 / EXPX + AX) + AX) - EXPX) / 2.0;
     if (X < 0.0) SINHM = -SINHM;
     COSHM = ((1.0 / EXPX - 2.0) + EXPX) / 2.0;
@@ -220,7 +294,7 @@ LT_DEV double sigs_interval(double DX, double Y1, double Y2, double S1, double S
         T1 = COSHM / SINHM;
         FP = T1 + SIG * (SIG / SINHM - T1 * T1 + 1.0);
       } else {
-        double EMS = exp(-SIG);
+        double EMS = lt_exp(-SIG);
         double SSM = 1.0 - EMS * (EMS + SIG + SIG);
         T1 = (1.0 - EMS) * (1.0 - EMS) / SSM;
         FP = T1 + SIG * (2.0 * SIG * EMS / SSM - T1 * T1 + 1.0);
@@ -280,7 +354,7 @@ LT_DEV double sigs_interval(double DX, double Y1, double Y2, double S1, double S
       A = C2 - C1;
       E = SIG * SINHM - COSHMM - COSHMM;
     } else {
-      double EMS = exp(-SIG);
+      double EMS = exp_core(-SIG);
       double EMS2 = EMS + EMS;
       double TM = 1.0 - EMS;
       double SSINH = TM * (1.0 + EMS);
@@ -401,7 +475,7 @@ LT_DEV double hval_interval(double T, double X1, double X2, double Y1, double Y2
     double SB1 = SIG * B1;
     double SB2 = SIG - SB1;
     if (-SB1 > LT_SBIG || -SB2 > LT_SBIG) return Y1 + S * U;
-    double E1 = exp(-SB1), E2 = exp(-SB2);
+    double E1 = exp_core(-SB1), E2 = exp_core(-SB2);
     double EMS = E1 * E2;
     double TM = 1.0 - EMS;
     double TS = TM * TM;
@@ -439,7 +513,7 @@ LT_DEV double hpval_interval(double T, double X1, double X2, double Y1, double Y
     double SB1 = SIG * B1;
     double SB2 = SIG - SB1;
     if (-SB1 > LT_SBIG || -SB2 > LT_SBIG) return S;
-    double E1 = exp(-SB1), E2 = exp(-SB2);
+    double E1 = exp_core(-SB1), E2 = exp_core(-SB2);
     double EMS = E1 * E2;
     double TM = 1.0 - EMS;
     double E = TM * (SIG * (1.0 + EMS) - TM - TM);
@@ -601,7 +675,7 @@ LT_DEV double sigs_newton(double T, bool& failed) {
       T1 = div_prep(COSHM, ds);
       FP = T1 + SIG * (div_prep(SIG, ds) - T1 * T1 + 1.0);
     } else {
-      double EMS = exp(-SIG);
+      double EMS = lt_exp(-SIG);
       double SSM = 1.0 - EMS * (EMS + SIG + SIG);
       const Divisor ds = prep_div(SSM);  // two quotients over SSM
       T1 = div_prep((1.0 - EMS) * (1.0 - EMS), ds);
@@ -664,7 +738,7 @@ __device__ __noinline__ double sigs_secant(double S, double S1, double S2) {
       A = C2 - C1;
       E = SIG * SINHM - COSHMM - COSHMM;
     } else {
-      double EMS = exp(-SIG);
+      double EMS = exp_core(-SIG);
       double EMS2 = EMS + EMS;
       double TM = 1.0 - EMS;
       double SSINH = TM * (1.0 + EMS);
@@ -727,7 +801,7 @@ LT_DEV double hval_interval_s(double T, double X1, double X2, double Y1, double 
     double SB1 = SIG * B1;
     double SB2 = SIG - SB1;
     if (-SB1 > LT_SBIG || -SB2 > LT_SBIG) return Y1 + S * U;
-    double E1 = exp(-SB1), E2 = exp(-SB2);
+    double E1 = exp_core(-SB1), E2 = exp_core(-SB2);
     double EMS = E1 * E2;
     double TM = 1.0 - EMS;
     double TS = TM * TM;

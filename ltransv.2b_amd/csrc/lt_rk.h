@@ -545,7 +545,7 @@ template <typename SlabT>
 __global__ __launch_bounds__(256) void k_beh_pre(const StepParams P) {
   __shared__ double lev[6 * LT_LEV_STRIDE];
   for (int i = threadIdx.x; i < 6 * LT_LEV_STRIDE; i += blockDim.x) lev[i] = P.lev[i];
-  __syncthreads();
+  exp_table_load();
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= P.numpar) return;
   int fl = P.ws_i[n];
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(256) void k_beh_pre(const StepParams P) {
       const double tst = (dtime - P.twistart) * 3600.0;
       E0 = P.Em * sin(P.PI * tst / (P.daylength * 3600.0)) * sin(P.PI * tst / (P.daylength * 3600.0));
     }
-    const double P_light = E0 * exp(P.Kd * P_zc);
+    const double P_light = E0 * lt_exp(P.Kd * P_zc);
     if (P_light < P.thresh) { random = true; thr2 = 0.5; }
     if (P_light > P.thresh) { random = true; thr2 = (double)0.20f; }
   }
@@ -680,7 +680,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_rk(const StepParams P) 
   __shared__ double lev[6 * LT_LEV_STRIDE];
   __shared__ WaveScratch wsc[4];
   for (int i = threadIdx.x; i < 6 * LT_LEV_STRIDE; i += blockDim.x) lev[i] = P.lev[i];
-  __syncthreads();
+  exp_table_load();
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   const size_t N = (size_t)P.numpar;
   const bool act = (n < P.numpar) && ((P.ws_i[n] & FL_ACT) != 0);
@@ -829,7 +829,7 @@ template <typename SlabT>
 __global__ __launch_bounds__(256) void k_rk_slow(const StepParams P) {
   __shared__ double lev[6 * LT_LEV_STRIDE];
   for (int i = threadIdx.x; i < 6 * LT_LEV_STRIDE; i += blockDim.x) lev[i] = P.lev[i];
-  __syncthreads();
+  exp_table_load();
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= P.numpar) return;
   if (!(P.ws_i[n] & FL_SLOW)) return;

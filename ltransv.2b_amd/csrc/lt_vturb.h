@@ -120,7 +120,7 @@ LT_DEV double hval_prepared(double T, const VtInterval& c) {
   } else {
     const double SB1 = SIG * B1, SB2 = SIG - SB1;
     if (-SB1 > LT_SBIG || -SB2 > LT_SBIG) return c.Y1 + S * U;
-    const double E1 = exp(-SB1), E2 = exp(-SB2);
+    const double E1 = exp_core(-SB1), E2 = exp_core(-SB2);
     const double EMS = E1 * E2, TM = 1.0 - EMS, TS = TM * TM, TP = 1.0 + EMS;
     const double E = TM * (SIG * TP - TM - TM);
     return c.Y1 + S * U +
@@ -144,7 +144,7 @@ LT_DEV double hpval_prepared(double T, const VtInterval& c) {
   } else {
     const double SB1 = SIG * B1, SB2 = SIG - SB1;
     if (-SB1 > LT_SBIG || -SB2 > LT_SBIG) return S;
-    const double E1 = exp(-SB1), E2 = exp(-SB2);
+    const double E1 = exp_core(-SB1), E2 = exp_core(-SB2);
     const double EMS = E1 * E2, TM = 1.0 - EMS;
     const double E = TM * (SIG * (1.0 + EMS) - TM - TM);
     return S + (TM * ((E2 - E1) * (D1 + D2) + TM * (D1 - D2)) +
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
   __shared__ double lev[6 * LT_LEV_STRIDE];
   __shared__ double wring[3][8][256];
   for (int i = threadIdx.x; i < 6 * LT_LEV_STRIDE; i += blockDim.x) lev[i] = P.lev[i];
-  __syncthreads();
+  exp_table_load();
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= P.numpar || !(P.ws_i[n] & FL_ACT)) return;
   const bool act = true;
@@ -393,6 +393,7 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
 // returned IER = -4 before SIGS, so its tensions stay 0 and SigErr = 0.
 __global__ __launch_bounds__(256) void k_vt_sigs(const StepParams P) {
   __shared__ VtScratch vsc[4];
+  exp_table_load();
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const int wave_first = n - lane;
@@ -458,6 +459,7 @@ __global__ __launch_bounds__(256) void k_vt_sigs(const StepParams P) {
 struct __attribute__((packed, aligned(4))) RawWords4 { uint32_t a, b, c, d; };
 __global__ __launch_bounds__(256) void k_vt_walk(const StepParams P) {
   __shared__ uint2 rbuf[8][256];
+  exp_table_load();
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= P.numpar) return;
   const int fl = P.ws_i[n];

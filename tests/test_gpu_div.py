@@ -56,3 +56,50 @@ def test_prepared_division_near_one_and_fp32_values(hip_lib):
     a2 = b2 * rng.integers(1, 1 << 20, n)
     qf, qr = _run(hip_lib, a2, b2)
     assert np.array_equal(qf.view(np.uint64), qr.view(np.uint64))
+
+
+def _dev_exp(lib, x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty((x.size, 2))
+    lib.lt_test_leaf.restype = C.c_int
+    rc = lib.lt_test_leaf(C.c_int32(5), x.ctypes.data_as(C.c_void_p), C.c_int32(x.size), C.c_int32(1),
+                          out.ctypes.data_as(C.c_void_p), C.c_int32(2))
+    assert rc == 0
+    return out[:, 0], out[:, 1]
+
+
+def test_exp_is_the_host_libm_exp(hip_lib):
+    """exp_core / lt_exp (lt_math.h) restate the host libm's exp operation for operation: the
+    tension-spline branches (SIGS' Newton stopping tests, tension_module.f90:531-580) then take the
+    same side as in the CPU run.  The oracle calls that libm exp, so it is the comparison here."""
+    import math
+    rng = np.random.default_rng(11)
+    n = 1_000_000
+
+    def host_bits(x):
+        return np.array([math.exp(v) for v in x]).view(np.uint64)
+
+    # exp_core: |x| < 512
+    x = np.concatenate([
+        -rng.uniform(0.0, 170.0, n),                                # -SIG*B of HVAL / HPVAL
+        -np.exp(rng.uniform(np.log(1e-30), np.log(85.0), n // 2)),  # tiny arguments
+        rng.uniform(-512.0, 512.0, n // 2),
+        np.array([0.0, -0.0, 1.0, -1.0, 511.999, -511.999, 1e-300, -1e-300, 2.0 ** -54, -2.0 ** -54]),
+    ])
+    core, full = _dev_exp(hip_lib, x)
+    host = host_bits(x)
+    assert np.array_equal(core.view(np.uint64), host)
+    assert np.array_equal(full.view(np.uint64), host)
+    # lt_exp: every x <= 0, through libm's out-of-line path (unfused sum, subnormal results, zero)
+    x = np.concatenate([
+        -rng.uniform(512.0, 708.0, n // 4), -rng.uniform(708.0, 746.0, n // 4), -rng.uniform(746.0, 1100.0, 1000),
+        -np.exp(rng.uniform(np.log(1e3), np.log(1e300), 1000)),
+        np.array([-512.0, -708.396, -745.13, -745.14, -1023.999, -1024.0, -np.inf]),
+    ])
+    _, full = _dev_exp(hip_lib, x)
+    assert np.array_equal(full.view(np.uint64), host_bits(x))
+    # x >= 512 is outside what the engine evaluates: device library exp, a faithful result
+    big = np.array([512.5, 600.0, 709.5])
+    _, full = _dev_exp(hip_lib, big)
+    host = np.array([math.exp(v) for v in big])
+    assert np.all(np.abs(full - host) <= 4e-16 * host)

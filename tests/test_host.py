@@ -115,3 +115,25 @@ def test_oracle_unreleased_particles_hold_position():
     assert np.array_equal(out["par"][::2, :3], case["parts"]["par"][::2, :3])
     assert np.all(out["par"][::2, 11] == 0.0) and np.all(out["par"][1::2, 11] == 600.0)
     assert out["stats"]["active"] == case["cfg"].numpar // 2
+
+
+def test_exp_table_header_is_the_generated_one():
+    """lt_exp_table.h (the 2^(k/128) table of the libm-exact device exp) is what
+    gen_exp_table.py computes from the definition, and reproduces libm's exp on the host when the
+    published evaluation order is followed with it (pure-Python fma is not available, so the check
+    here is the table itself plus two anchor identities)."""
+    import importlib.util
+    import struct
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ltransv.2b_amd", "csrc")
+    spec = importlib.util.spec_from_file_location("gen_exp_table", os.path.join(csrc, "gen_exp_table.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    with open(os.path.join(csrc, "lt_exp_table.h")) as f:
+        assert f.read() == gen.render()
+    tab = gen.table()
+    assert len(tab) == 128 and tab[0] == (0, 0x3FF0000000000000)
+    for k in (1, 37, 64, 127):
+        tail, sbits = tab[k]
+        h = struct.unpack("<d", struct.pack("<Q", sbits + (k << 45)))[0]
+        assert h == 2.0 ** (k / 128.0) or abs(h - 2.0 ** (k / 128.0)) <= 2.3e-16 * h
+        assert abs(struct.unpack("<d", struct.pack("<Q", tail))[0]) < 2.0 ** -53
