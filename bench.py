@@ -400,6 +400,19 @@ def main():
         t0 = time.perf_counter(); e.get_output(); t_out = time.perf_counter() - t0
         t0 = time.perf_counter(); e.get_particles(); t_all = time.perf_counter() - t0
         out["config"]["print_step"] = {"lt_get_output_ms": t_out * 1e3, "lt_get_particles_ms": t_all * 1e3}
+        # init-time geometry: setEle_all for this shard's particles and the three
+        # adjacency tables on the device, checked against the host-side construction of the inputs
+        px, py = parts["par"][:, 0].copy(), parts["par"][:, 1].copy()
+        e.locate_particles(px[:1024], py[:1024])
+        t0 = time.perf_counter(); er, eu, ev, lerr, _ = e.locate_particles(px, py); t_loc = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        adj = [e.build_adjacency(geo[k], row) for k, row in (("RE", g["vi"]), ("UE", g["ui"]), ("VE", g["vi"]))]
+        t_adj = time.perf_counter() - t0
+        same = (lerr == 0 and np.array_equal(er, parts["P_r_element"]) and np.array_equal(eu, parts["P_u_element"])
+                and np.array_equal(ev, parts["P_v_element"]) and np.array_equal(adj[0], geo["r_Adjacent"])
+                and np.array_equal(adj[1], geo["u_Adjacent"]) and np.array_equal(adj[2], geo["v_Adjacent"]))
+        out["config"]["init_geometry"] = {"lt_locate_particles_ms": t_loc * 1e3, "lt_build_adjacency_ms": t_adj * 1e3,
+                                          "matches_host_construction": bool(same)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ltrans_amd, args, vi, uj, us, g, geo, bounds, records)
     elif rank == 0:

@@ -339,6 +339,39 @@ int lt_pack_positions(lt_engine *e, void *dst_device);
 /* the engine's HIP stream (hipStream_t) for ordering external work */
 void *lt_stream(lt_engine *e);
 
+/* init-time geometry on the device ------------------------ */
+/* The adjacency lists of initGrid (hydrodynamic_module.f90:588-645): for element i the
+ * elements j of [i-(row+2), i+row+2] that share a node with it, ascending, after i itself;
+ * row = vi for the rho and v grids, ui for the u grid.  E is (4,elements), adjacent is
+ * (elements,10) in Fortran order, zero filled.  Needs no engine; device = HIP ordinal or -1.
+ * LT_ERR_ARG when an element has more than 9 such neighbours (the reference would write
+ * past column 10). */
+int lt_build_adjacency(int32_t device, int32_t elements, int32_t row, const int32_t *E,
+                       int32_t *adjacent);
+/* setEle_all (hydrodynamic_module.f90:1536-1676) for n positions given in the reference's
+ * particle order, on the grid of lt_set_grid: particle 1 by a scan of all elements, particle
+ * n by the adjacency row of particle n-1's element, then a scan of all elements -- the
+ * element tests (gridcell) run on the device for all particles at once, the dependence on
+ * the previous particle (it only matters for a point on an edge shared by elements) is
+ * resolved afterwards.  *err = 0, or 1/2/3 = not in any rho/u/v element with *par = that
+ * particle (1-based), as the reference's optional arguments; elements of particles from
+ * *par on are 0 where the reference leaves them unset.  Any output pointer may be NULL. */
+int lt_locate_particles(lt_engine *e, int32_t n, const double *Xpar, const double *Ypar,
+                        int32_t *P_r_element, int32_t *P_u_element, int32_t *P_v_element,
+                        int32_t *err, int32_t *par);
+/* createPolySpecs (settlement_module.f90:245-480): from the edge-point tables of h (polys,
+ * holes, pedges, hedges, the id ranges, maxbdis, maxhdis) builds polyspecs, holespecs, the
+ * habitat polygons of every rho element (the O(rho_elements x pedges) gridcell / inpoly
+ * part, on the device) and the holes of every polygon, and installs the habitat as
+ * lt_set_habitat does; the list members of h are ignored and may be NULL.
+ * lt_get_polyspecs copies the lists out (any pointer may be NULL; *_cap = capacity of the
+ * id arrays, LT_ERR_ARG if too small -- the ptr arrays, which are always filled first,
+ * then tell the size needed). */
+int lt_create_polyspecs(lt_engine *e, const lt_habitat *h);
+int lt_get_polyspecs(lt_engine *e, int32_t *polyspecs, int32_t *holespecs,
+                     int32_t *elepolys_ptr, int32_t *elepolys_ids, int32_t elepolys_cap,
+                     int32_t *polyholes_ptr, int32_t *polyholes_ids, int32_t polyholes_cap);
+
 /* measurement aids (not part of the reference interface) ------------------- */
 /* HIP-event timing of the step kernel on the engine's stream: arm up to
  * max_steps (start, stop) pairs, then synchronise and sum them. */

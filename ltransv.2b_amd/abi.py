@@ -178,6 +178,7 @@ ENTRY_POINTS = [
     "set_slab", "set_time_slots", "slab_prefetch", "slab_commit", "set_rng", "get_rng", "count_active", "set_rng_window",
     "count_draws", "set_rng_window_draws",
     "step", "sync", "get_stats", "get_particles", "get_output",
+    "build_adjacency", "locate_particles", "create_polyspecs", "get_polyspecs",
 ]
 HIP_ONLY_ENTRY_POINTS = ["last_error", "abi_version", "pack_positions", "stream",
                          "profile_begin", "profile_end", "get_counters"]

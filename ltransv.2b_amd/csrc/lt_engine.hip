@@ -62,6 +62,11 @@ struct lt_engine {
   DevBuf polys, holes, polyspecs, holespecs, maxbdis, maxhdis, ep_ptr, ep_ids, ph_ptr, ph_ids;
   lt_habitat hab{};
   int npoly = 0, nhole = 0;
+  // host copies for the init-time geometry functions (lt_locate_particles, lt_get_polyspecs)
+  std::vector<double> h_nx[3], h_ny[3];      // node coordinates of the rho / u / v grids
+  std::vector<int32_t> h_E[3];               // (4,elements) node ids
+  std::vector<int> h_adj[3];                 // [element][10]
+  std::vector<int32_t> h_polyspecs, h_holespecs, h_ep_ptr, h_ep_ids, h_ph_ptr, h_ph_ids;
   // particles
   DevBuf ws_d, ws_i, orig, ele_ok, block_active, count_slots, out_cols, out_hits;
   // internal particle order: slot i of every device array holds the reference's
@@ -720,6 +725,13 @@ int lt_set_grid(lt_engine* e, const lt_grid* g) {
   TRY(upload(e, e->lev, lev.data(), lev.size() * 8));
   e->rho_nodes = g->rho_nodes; e->u_nodes = g->u_nodes; e->v_nodes = g->v_nodes;
   e->rho_elements = g->rho_elements; e->u_elements = g->u_elements; e->v_elements = g->v_elements;
+  e->h_nx[0].assign(g->rx, g->rx + g->rho_nodes); e->h_ny[0].assign(g->ry, g->ry + g->rho_nodes);
+  e->h_nx[1].assign(g->ux, g->ux + g->u_nodes);   e->h_ny[1].assign(g->uy, g->uy + g->u_nodes);
+  e->h_nx[2].assign(g->vx, g->vx + g->v_nodes);   e->h_ny[2].assign(g->vy, g->vy + g->v_nodes);
+  e->h_E[0].assign(g->RE, g->RE + (size_t)4 * g->rho_elements);
+  e->h_E[1].assign(g->UE, g->UE + (size_t)4 * g->u_elements);
+  e->h_E[2].assign(g->VE, g->VE + (size_t)4 * g->v_elements);
+  e->h_adj[0].swap(ra); e->h_adj[1].swap(ua); e->h_adj[2].swap(va);
   // slabs: ALLOCATE + zero (hydrodynamic_module.f90:682-698)
   const size_t se = slab_elem(e);
   const size_t us = e->cfg.us, ws = e->cfg.ws;
@@ -822,7 +834,307 @@ int lt_set_habitat(lt_engine* e, const lt_habitat* h) {
   TRY(upload(e, e->ph_ptr, h->polyholes_ptr, ((size_t)e->npoly + 1) * 4));
   TRY(upload(e, e->ph_ids, h->polyholes_ids, (size_t)nph * 4));
   HIPCHK(e, hipStreamSynchronize(e->stream));
+  e->h_polyspecs.assign(h->polyspecs, h->polyspecs + (size_t)e->npoly * 2);
+  if (e->nhole > 0 && h->holespecs) e->h_holespecs.assign(h->holespecs, h->holespecs + (size_t)e->nhole * 2);
+  else e->h_holespecs.clear();
+  e->h_ep_ptr.assign(h->elepolys_ptr, h->elepolys_ptr + (size_t)e->rho_elements + 1);
+  e->h_ep_ids.assign(h->elepolys_ids, h->elepolys_ids + nlist);
+  e->h_ph_ptr.assign(h->polyholes_ptr, h->polyholes_ptr + (size_t)e->npoly + 1);
+  e->h_ph_ids.assign(h->polyholes_ids, h->polyholes_ids + nph);
   e->have_habitat = true;
+  return LT_OK;
+}
+
+// ---- init-time geometry on the device (lt_init.h) ---------------------------------------
+int lt_build_adjacency(int32_t device, int32_t elements, int32_t row, const int32_t* E, int32_t* adjacent) {
+  if (elements <= 0 || row < 0 || !E || !adjacent) return LT_ERR_ARG;
+  if (device >= 0 && hipSetDevice(device) != hipSuccess) return LT_ERR_DEVICE;
+  int4* dE = nullptr;
+  int *dA = nullptr, *dO = nullptr;
+  const size_t be = (size_t)elements * 16, ba = (size_t)elements * 10 * 4;
+  int rc = LT_OK, overflow = 0;
+  if (hipMalloc(&dE, be) != hipSuccess || hipMalloc(&dA, ba) != hipSuccess || hipMalloc(&dO, 4) != hipSuccess) {
+    rc = LT_ERR_NOMEM;
+  } else if (hipMemcpy(dE, E, be, hipMemcpyHostToDevice) != hipSuccess || hipMemset(dA, 0, ba) != hipSuccess ||
+             hipMemset(dO, 0, 4) != hipSuccess) {
+    rc = LT_ERR_DEVICE;
+  } else {
+    hipLaunchKernelGGL(ltd::k_adjacency, dim3((unsigned)((elements + 255) / 256)), dim3(256), 0, 0, dE, (int)elements,
+                       (int)row, dA, dO);
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(adjacent, dA, ba, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(&overflow, dO, 4, hipMemcpyDeviceToHost) != hipSuccess)
+      rc = LT_ERR_DEVICE;
+    else if (overflow)
+      rc = LT_ERR_ARG;  // an element with more than 9 node-sharing neighbours in the window
+  }
+  (void)hipFree(dE); (void)hipFree(dA); (void)hipFree(dO);
+  return rc;
+}
+
+namespace {
+
+// uniform bins over the elements' bounding boxes, ids ascending in every bin
+void build_ele_bins(const std::vector<double>& nx, const std::vector<double>& ny, const std::vector<int32_t>& E,
+                    int elements, ltd::EleBins& B, HostIndex& H) {
+  double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
+  std::vector<double> bb((size_t)elements * 4);
+  for (int i = 0; i < elements; i++) {
+    double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+    for (int k = 0; k < 4; k++) {
+      const int nd = E[(size_t)i * 4 + k] - 1;
+      x0 = std::min(x0, nx[nd]); x1 = std::max(x1, nx[nd]);
+      y0 = std::min(y0, ny[nd]); y1 = std::max(y1, ny[nd]);
+    }
+    bb[(size_t)i * 4] = x0; bb[(size_t)i * 4 + 1] = x1; bb[(size_t)i * 4 + 2] = y0; bb[(size_t)i * 4 + 3] = y1;
+    xmin = std::min(xmin, x0); xmax = std::max(xmax, x1); ymin = std::min(ymin, y0); ymax = std::max(ymax, y1);
+  }
+  const double wx = std::max(xmax - xmin, 1e-300), wy = std::max(ymax - ymin, 1e-300);
+  double cell = std::sqrt(wx * wy / std::max(elements, 1));
+  if (!(cell > 0.0)) cell = std::max(wx, wy);
+  while ((wx / cell + 1.0) * (wy / cell + 1.0) > 4.0e6) cell *= 2.0;
+  B.x0 = xmin; B.y0 = ymin; B.inv = 1.0 / cell;
+  B.ncx = (int)std::floor(wx / cell) + 1;
+  B.ncy = (int)std::floor(wy / cell) + 1;
+  // the same expression as k_locate's, so that bin(min) <= bin(x) <= bin(max) for min <= x <= max
+  auto cx = [&](double x) { double f = std::floor((x - B.x0) * B.inv); return (int)std::min(std::max(f, 0.0), (double)(B.ncx - 1)); };
+  auto cy = [&](double y) { double f = std::floor((y - B.y0) * B.inv); return (int)std::min(std::max(f, 0.0), (double)(B.ncy - 1)); };
+  const size_t ncell = (size_t)B.ncx * B.ncy;
+  H.ptr.assign(ncell + 1, 0);
+  for (int pass = 0; pass < 2; pass++) {
+    std::vector<int> cur;
+    if (pass) {
+      for (size_t c = 0; c < ncell; c++) H.ptr[c + 1] += H.ptr[c];
+      H.ids.assign((size_t)H.ptr[ncell], 0);
+      cur.assign(H.ptr.begin(), H.ptr.end() - 1);
+    }
+    for (int i = 0; i < elements; i++) {
+      const int a0 = cx(bb[(size_t)i * 4]), a1 = cx(bb[(size_t)i * 4 + 1]);
+      const int b0 = cy(bb[(size_t)i * 4 + 2]), b1 = cy(bb[(size_t)i * 4 + 3]);
+      for (int b = b0; b <= b1; b++)
+        for (int a = a0; a <= a1; a++) {
+          const size_t c = (size_t)a + (size_t)b * B.ncx;
+          if (pass) H.ids[(size_t)cur[c]++] = i + 1; else H.ptr[c + 1]++;
+        }
+    }
+  }
+}
+
+// a scan of all elements (gridcell without checkele): the first element that ends the scan, else
+// the last one that set P_ele (gridcell_kind 2), 0 if none
+int full_scan_result(const int* codes, int c) {
+  int res = 0;
+  for (int t = 0; t < c; t++) {
+    if ((codes[t] & 3) == 1) return codes[t] >> 2;
+    res = codes[t] >> 2;
+  }
+  return res;
+}
+
+}  // namespace
+
+int lt_locate_particles(lt_engine* e, int32_t n, const double* Xpar, const double* Ypar, int32_t* P_r_element,
+                        int32_t* P_u_element, int32_t* P_v_element, int32_t* err, int32_t* par) {
+  if (!e) return LT_ERR_ARG;
+  if (n < 0 || (n > 0 && (!Xpar || !Ypar))) return fail(e, LT_ERR_ARG, "lt_locate_particles: bad arguments");
+  if (!e->have_grid) return fail(e, LT_ERR_STATE, "lt_locate_particles before lt_set_grid");
+  HIPCHK(e, hipSetDevice(e->device));
+  int32_t* outp[3] = {P_r_element, P_u_element, P_v_element};
+  const int nele[3] = {e->rho_elements, e->u_elements, e->v_elements};
+  const void* nodes[3] = {e->rnode.p, e->unode.p, e->vnode.p};
+  const int4* EL[3] = {(const int4*)e->RE.p, (const int4*)e->UE.p, (const int4*)e->VE.p};
+  std::vector<std::vector<int>> codes(3), cnt(3);
+  if (n > 0) {
+    DevBuf dX, dY, dcodes, dcnt, dptr, dids;
+    int rc = LT_OK;
+    auto body = [&]() -> int {
+      TRY(upload(e, dX, Xpar, (size_t)n * 8));
+      TRY(upload(e, dY, Ypar, (size_t)n * 8));
+      TRY(dev_alloc(e, dcodes, (size_t)n * LT_LOC_CAP * 4));
+      TRY(dev_alloc(e, dcnt, (size_t)n * 4));
+      for (int g = 0; g < 3; g++) {
+        ltd::EleBins B;
+        HostIndex H;
+        build_ele_bins(e->h_nx[g], e->h_ny[g], e->h_E[g], nele[g], B, H);
+        if (H.ids.empty()) H.ids.push_back(0);
+        TRY(upload(e, dptr, H.ptr.data(), H.ptr.size() * 4));
+        TRY(upload(e, dids, H.ids.data(), H.ids.size() * 4));
+        B.ptr = (const int*)dptr.p; B.ids = (const int*)dids.p;
+        const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+        if (g == 0)
+          hipLaunchKernelGGL(ltd::k_locate<true>, grid, block, 0, e->stream, nodes[g], EL[g], B, (const double*)dX.p,
+                             (const double*)dY.p, (int)n, (int*)dcodes.p, (int*)dcnt.p);
+        else
+          hipLaunchKernelGGL(ltd::k_locate<false>, grid, block, 0, e->stream, nodes[g], EL[g], B, (const double*)dX.p,
+                             (const double*)dY.p, (int)n, (int*)dcodes.p, (int*)dcnt.p);
+        HIPCHK(e, hipGetLastError());
+        codes[g].resize((size_t)n * LT_LOC_CAP);
+        cnt[g].resize((size_t)n);
+        HIPCHK(e, hipMemcpyAsync(codes[g].data(), dcodes.p, (size_t)n * LT_LOC_CAP * 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipMemcpyAsync(cnt[g].data(), dcnt.p, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+      }
+      return LT_OK;
+    };
+    rc = body();
+    for (DevBuf* b : {&dX, &dY, &dcodes, &dcnt, &dptr, &dids}) if (b->p) (void)hipFree(b->p);
+    if (rc != LT_OK) return rc;
+    for (int g = 0; g < 3; g++)
+      for (int k = 0; k < n; k++)
+        if (cnt[g][k] > LT_LOC_CAP)
+          return fail(e, LT_ERR_ARG, "lt_locate_particles: particle %d lies in more than %d elements", k + 1, LT_LOC_CAP);
+  }
+  // the particle loop of setEle_all: only the ORDER of the tests depends on the previous particle
+  std::vector<int32_t> out[3];
+  for (int g = 0; g < 3; g++) out[g].assign((size_t)n, 0);
+  int error = 0, p = 0;
+  if (n >= 1) {
+    for (int g = 0; g < 3; g++) {  // :1553-1583, no early exit between the three grids
+      out[g][0] = full_scan_result(&codes[g][0], cnt[g][0]);
+      if (out[g][0] == 0) { error = g + 1; p = 1; }
+    }
+  }
+  for (int k = 1; k < n && error == 0; k++) {
+    for (int g = 0; g < 3; g++) {
+      const int* cd = &codes[g][(size_t)k * LT_LOC_CAP];
+      const int c = cnt[g][k];
+      int res = 0;
+      if (c == 1) {
+        res = cd[0] >> 2;  // the only element that contains it, whichever test finds it
+      } else if (c > 1) {
+        const int* row = &e->h_adj[g][(size_t)(out[g][k - 1] - 1) * 10];
+        bool done = false;
+        for (int i = 0; i < 10 && !done; i++) {
+          const int a = row[i];
+          if (a == 0) { res = full_scan_result(cd, c); done = true; break; }
+          for (int t = 0; t < c; t++)
+            if ((cd[t] >> 2) == a) { res = a; done = true; break; }
+        }
+      }
+      if (res == 0) { error = g + 1; p = k + 1; break; }
+      out[g][k] = res;
+    }
+  }
+  for (int g = 0; g < 3; g++)
+    if (outp[g] && n > 0) memcpy(outp[g], out[g].data(), (size_t)n * 4);
+  if (err) *err = error;
+  if (par) *par = p;
+  return LT_OK;
+}
+
+int lt_create_polyspecs(lt_engine* e, const lt_habitat* h) {
+  if (!e || !h) return LT_ERR_ARG;
+  if (!e->have_grid) return fail(e, LT_ERR_STATE, "lt_create_polyspecs before lt_set_grid");
+  if (h->pedges <= 0 || !h->polys || !h->maxbdis || h->maxpolyid < h->minpolyid ||
+      (h->hedges > 0 && (!h->holes || h->maxholeid < h->minholeid)))
+    return fail(e, LT_ERR_ARG, "lt_create_polyspecs: bad arguments");
+  HIPCHK(e, hipSetDevice(e->device));
+  const int pedges = h->pedges, hedges = h->hedges;
+  const int npoly = h->maxpolyid - h->minpolyid + 1;
+  const int nhole = (hedges > 0) ? h->maxholeid - h->minholeid + 1 : 0;
+  auto POLYS = [&](int i, int k) { return h->polys[((size_t)i - 1) + (size_t)pedges * (k - 1)]; };
+  auto HOLES = [&](int i, int k) { return h->holes[((size_t)i - 1) + (size_t)hedges * (k - 1)]; };
+  for (int i = 1; i <= pedges; i++) {
+    const long id = lround(POLYS(i, 1));
+    if (id < h->minpolyid || id > h->maxpolyid) return fail(e, LT_ERR_ARG, "lt_create_polyspecs: polygon id %ld outside minpolyid..maxpolyid", id);
+  }
+  for (int i = 1; i <= hedges; i++) {
+    const long id = lround(HOLES(i, 1));
+    if (id < h->minholeid || id > h->maxholeid) return fail(e, LT_ERR_ARG, "lt_create_polyspecs: hole id %ld outside minholeid..maxholeid", id);
+  }
+  // polyspecs / holespecs: first row and number of edge points of every id, settlement_module.f90:277-289,393-405
+  std::vector<int32_t> ps((size_t)npoly * 2, 0), hs((size_t)std::max(nhole, 1) * 2, 0);
+  auto specs = [](std::vector<int32_t>& sp, int n, int nrow, int minid, auto ID) {
+    int count = 1;
+    sp[(size_t)(lround(ID(1)) - minid)] = 1;
+    for (int i = 2; i <= nrow; i++) {
+      if (ID(i) != ID(i - 1)) {
+        sp[(size_t)(lround(ID(i)) - minid)] = i;
+        sp[(size_t)(lround(ID(i - 1)) - minid) + n] = count;
+        count = 1;
+      } else if (i == nrow) {
+        sp[(size_t)(lround(ID(i)) - minid) + n] = count + 1;
+      } else {
+        count = count + 1;
+      }
+    }
+  };
+  specs(ps, npoly, pedges, h->minpolyid, [&](int i) { return POLYS(i, 1); });
+  if (hedges > 0) specs(hs, nhole, hedges, h->minholeid, [&](int i) { return HOLES(i, 1); });
+  // holes of every polygon :410-468
+  std::vector<int32_t> php((size_t)npoly + 1, 0), phi;
+  for (int id = h->minpolyid; id <= h->maxpolyid; id++) {
+    int count = 0;
+    const int first = ps[(size_t)(id - h->minpolyid)];
+    if (hedges > 0 && first != 0) {
+      for (int j = 1; j <= hedges; j++)
+        if ((j == 1 || HOLES(j, 1) != HOLES(j - 1, 1)) && HOLES(j, 6) == POLYS(first, 1)) {
+          count++;
+          phi.push_back((int32_t)lround(HOLES(j, 1)));
+        }
+    }
+    php[(size_t)(id - h->minpolyid) + 1] = php[(size_t)(id - h->minpolyid)] + count;
+  }
+  // polygons of every rho element :293-386, on the device
+  TRY(upload(e, e->polys, h->polys, (size_t)pedges * 5 * 8));
+  TRY(upload(e, e->holes, h->holes, (size_t)hedges * 6 * 8));
+  TRY(upload(e, e->polyspecs, ps.data(), (size_t)npoly * 2 * 4));
+  TRY(upload(e, e->holespecs, hs.data(), (size_t)nhole * 2 * 4));
+  TRY(upload(e, e->maxbdis, h->maxbdis, (size_t)npoly * 8));
+  TRY(upload(e, e->maxhdis, h->maxhdis, (size_t)(h->maxhdis ? nhole : 0) * 8));
+  const int ne = e->rho_elements;
+  std::vector<int32_t> epp((size_t)ne + 1, 0), epi;
+  {
+    DevBuf dcount;
+    TRY(dev_alloc(e, dcount, (size_t)ne * 4));
+    const dim3 grid((unsigned)((ne + 255) / 256)), block(256);
+    hipLaunchKernelGGL(ltd::k_elepolys, grid, block, 0, e->stream, (const RhoNode*)e->rnode.p, (const int4*)e->RE.p, ne,
+                       (const double*)e->polys.p, pedges, (const int*)e->polyspecs.p, (const double*)e->maxbdis.p,
+                       (int)h->minpolyid, npoly, (const int*)nullptr, (int*)dcount.p, 0);
+    std::vector<int32_t> counts((size_t)ne);
+    hipError_t he = hipMemcpyAsync(counts.data(), dcount.p, (size_t)ne * 4, hipMemcpyDeviceToHost, e->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    (void)hipFree(dcount.p);
+    if (he != hipSuccess) return fail(e, LT_ERR_DEVICE, "lt_create_polyspecs: %s", hipGetErrorString(he));
+    for (int i = 0; i < ne; i++) epp[(size_t)i + 1] = epp[(size_t)i] + counts[(size_t)i];
+    epi.assign((size_t)std::max(epp[(size_t)ne], 1), 0);
+    TRY(upload(e, e->ep_ptr, epp.data(), epp.size() * 4));
+    TRY(dev_alloc(e, e->ep_ids, epi.size() * 4));
+    hipLaunchKernelGGL(ltd::k_elepolys, grid, block, 0, e->stream, (const RhoNode*)e->rnode.p, (const int4*)e->RE.p, ne,
+                       (const double*)e->polys.p, pedges, (const int*)e->polyspecs.p, (const double*)e->maxbdis.p,
+                       (int)h->minpolyid, npoly, (const int*)e->ep_ptr.p, (int*)e->ep_ids.p, 1);
+    HIPCHK(e, hipMemcpyAsync(epi.data(), e->ep_ids.p, epi.size() * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    epi.resize((size_t)epp[(size_t)ne]);
+  }
+  TRY(upload(e, e->ph_ptr, php.data(), php.size() * 4));
+  TRY(upload(e, e->ph_ids, phi.data(), phi.size() * 4));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  e->hab = *h;
+  e->hab.polyspecs = e->hab.holespecs = e->hab.elepolys_ptr = e->hab.elepolys_ids = nullptr;
+  e->hab.polyholes_ptr = e->hab.polyholes_ids = nullptr;
+  e->npoly = npoly;
+  e->nhole = nhole;
+  e->h_polyspecs.swap(ps);
+  if (nhole > 0) e->h_holespecs.swap(hs); else e->h_holespecs.clear();
+  e->h_ep_ptr.swap(epp); e->h_ep_ids.swap(epi); e->h_ph_ptr.swap(php); e->h_ph_ids.swap(phi);
+  e->have_habitat = true;
+  return LT_OK;
+}
+
+int lt_get_polyspecs(lt_engine* e, int32_t* polyspecs, int32_t* holespecs, int32_t* elepolys_ptr, int32_t* elepolys_ids,
+                     int32_t elepolys_cap, int32_t* polyholes_ptr, int32_t* polyholes_ids, int32_t polyholes_cap) {
+  if (!e) return LT_ERR_ARG;
+  if (!e->have_habitat) return fail(e, LT_ERR_STATE, "lt_get_polyspecs: no habitat");
+  auto put = [](int32_t* dst, const std::vector<int32_t>& v) { if (dst && !v.empty()) memcpy(dst, v.data(), v.size() * 4); };
+  put(polyspecs, e->h_polyspecs);
+  put(holespecs, e->h_holespecs);
+  put(elepolys_ptr, e->h_ep_ptr);
+  put(polyholes_ptr, e->h_ph_ptr);
+  if ((elepolys_ids && (size_t)std::max(elepolys_cap, 0) < e->h_ep_ids.size()) ||
+      (polyholes_ids && (size_t)std::max(polyholes_cap, 0) < e->h_ph_ids.size()))
+    return fail(e, LT_ERR_ARG, "lt_get_polyspecs: id arrays too small (%zu, %zu needed)", e->h_ep_ids.size(), e->h_ph_ids.size());
+  put(elepolys_ids, e->h_ep_ids);
+  put(polyholes_ids, e->h_ph_ids);
   return LT_OK;
 }
 

@@ -9,7 +9,7 @@
 //   k_rk_slow   reference-shaped redo of the rare SigErr / degenerate cases      (lt_rk.h)
 //   k_vt_table / k_vt_sigs / k_vt_walk   VTurb                                    (lt_vturb.h)
 //   k_post      HTurb, behaviour, reflection, boundaries, setEle, settlement, commit (lt_post.h)
-// plus the upload / download kernels of lt_io.h.  No MFMA: the path is gather + scalar fp64
+// plus the upload / download kernels of lt_io.h and the init-time geometry kernels of lt_init.h.  No MFMA: the path is gather + scalar fp64
 // spline arithmetic with data-dependent iteration.
 //
 // Shape decisions that differ from the reference (results do not):
@@ -65,5 +65,6 @@ template <> struct SlabTraits<double> { using zeta4 = double4; };
 #include "lt_vturb.h"
 #include "lt_post.h"
 #include "lt_io.h"
+#include "lt_init.h"
 
 }  // namespace ltd

@@ -828,35 +828,40 @@ LT_DEV bool gc_horiz(double ya, double yb, double xa, double xb, double Xpos, do
   return false;
 }
 
-LT_DEV bool gridcell_one(const double (&qx)[4], const double (&qy)[4], double Xpos, double Ypos) {
+// One element of gridcell (gridcell_module.f90:46-254).  0: the point is not in the element;
+// 1: it is, and the scan over elements ends here (EXIT of the element loop); 2: it lies on an
+// edge found by the crossing loop with an even crossing count so far -- P_ele and triangle are
+// set but only the EDGE loop is left (:224,:238), so a scan over all elements goes on and a
+// later element may overwrite P_ele.  With checkele (one element) 1 and 2 are both "found".
+LT_DEV int gridcell_kind(const double (&qx)[4], const double (&qy)[4], double Xpos, double Ypos) {
   // 1, 2: bounding tests :49-59
   if ((Ypos < qy[0] && Ypos < qy[1] && Ypos < qy[2] && Ypos < qy[3]) ||
       (Ypos > qy[0] && Ypos > qy[1] && Ypos > qy[2] && Ypos > qy[3]))
-    return false;
+    return 0;
   if ((Xpos < qx[0] && Xpos < qx[1] && Xpos < qx[2] && Xpos < qx[3]) ||
       (Xpos > qx[0] && Xpos > qx[1] && Xpos > qx[2] && Xpos > qx[3]))
-    return false;
+    return 0;
   // 3: on a node :61-69
   if ((Xpos == qx[0] && Ypos == qy[0]) || (Xpos == qx[1] && Ypos == qy[1]) ||
       (Xpos == qx[2] && Ypos == qy[2]) || (Xpos == qx[3] && Ypos == qy[3]))
-    return true;
+    return 1;
   // 4: horizontal segments :71-149 (pairs in the source order)
   if (qy[0] == qy[1] || qy[0] == qy[2] || qy[0] == qy[3] || qy[1] == qy[2] || qy[1] == qy[3] ||
       qy[2] == qy[3]) {
     bool hit;
-    if (gc_horiz(qy[0], qy[1], qx[0], qx[1], Xpos, Ypos, hit)) return hit;
-    if (gc_horiz(qy[0], qy[2], qx[0], qx[2], Xpos, Ypos, hit)) return hit;
-    if (gc_horiz(qy[0], qy[3], qx[0], qx[3], Xpos, Ypos, hit)) return hit;
-    if (gc_horiz(qy[1], qy[2], qx[1], qx[2], Xpos, Ypos, hit)) return hit;
-    if (gc_horiz(qy[1], qy[3], qx[1], qx[3], Xpos, Ypos, hit)) return hit;
-    if (gc_horiz(qy[2], qy[3], qx[2], qx[3], Xpos, Ypos, hit)) return hit;
+    if (gc_horiz(qy[0], qy[1], qx[0], qx[1], Xpos, Ypos, hit)) return hit ? 1 : 0;
+    if (gc_horiz(qy[0], qy[2], qx[0], qx[2], Xpos, Ypos, hit)) return hit ? 1 : 0;
+    if (gc_horiz(qy[0], qy[3], qx[0], qx[3], Xpos, Ypos, hit)) return hit ? 1 : 0;
+    if (gc_horiz(qy[1], qy[2], qx[1], qx[2], Xpos, Ypos, hit)) return hit ? 1 : 0;
+    if (gc_horiz(qy[1], qy[3], qx[1], qx[3], Xpos, Ypos, hit)) return hit ? 1 : 0;
+    if (gc_horiz(qy[2], qy[3], qx[2], qx[3], Xpos, Ypos, hit)) return hit ? 1 : 0;
   }
   // 5: y equal to a corner y :151-183
   if (Ypos == qy[0] || Ypos == qy[1] || Ypos == qy[2] || Ypos == qy[3]) {
     double bhighy = fmax(fmax(qy[0], qy[1]), fmax(qy[2], qy[3]));
-    if (Ypos == bhighy) return false;
+    if (Ypos == bhighy) return 0;
     double blowy = fmin(fmin(qy[0], qy[1]), fmin(qy[2], qy[3]));
-    if (Ypos == blowy) return false;
+    if (Ypos == blowy) return 0;
   }
   // 6: crossing count :185-254.  An on-edge hit sets triangle=1 and leaves the
   // edge loop; the parity test that follows cannot unset it.
@@ -884,7 +889,10 @@ LT_DEV bool gridcell_one(const double (&qx)[4], const double (&qy)[4], double Xp
       }
     }
   }
-  return on_edge || ((total & 1) != 0);
+  return ((total & 1) != 0) ? 1 : (on_edge ? 2 : 0);
+}
+LT_DEV bool gridcell_one(const double (&qx)[4], const double (&qy)[4], double Xpos, double Ypos) {
+  return gridcell_kind(qx, qy, Xpos, Ypos) != 0;
 }
 
 // ---------------------------------------------------- HYDRO_MOD weights

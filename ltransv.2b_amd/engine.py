@@ -177,6 +177,58 @@ class Engine:
             setattr(s, k, _ip(a))
         self._check(self._fn["set_habitat"](self._h, C.byref(s)), "set_habitat")
 
+    # -- init-time geometry --------------------------------
+    def build_adjacency(self, E, row):
+        """initGrid's adjacency lists (hydrodynamic_module.f90:588-645) of the (4,elements)
+        node table E; row = vi (rho, v) or ui (u).  Returns (elements,10), Fortran order."""
+        E = _fcol(np.asarray(E), np.int32)
+        n = E.size // 4
+        adj = np.zeros((n, 10), dtype=np.int32, order="F")
+        self._check(self._fn["build_adjacency"](C.c_int32(int(self.cfg.device)), C.c_int32(n), C.c_int32(int(row)),
+                                                _ip(E), _ip(adj)), "build_adjacency")
+        return adj
+
+    def locate_particles(self, x, y):
+        """setEle_all (hydrodynamic_module.f90:1536-1676).  Returns (r, u, v, err, par)."""
+        x = _f8(x, name="x")
+        y = _f8(y, x.size, "y")
+        n = x.size
+        r, u, v = (np.zeros(n, dtype=np.int32) for _ in range(3))
+        err, par = C.c_int32(0), C.c_int32(0)
+        self._check(self._fn["locate_particles"](self._h, C.c_int32(n), _dp(x), _dp(y), _ip(r), _ip(u), _ip(v),
+                                                 C.byref(err), C.byref(par)), "locate_particles")
+        return r, u, v, err.value, par.value
+
+    def create_polyspecs(self, h):
+        """createPolySpecs (settlement_module.f90:245-480) from the edge-point tables of h;
+        installs the habitat.  Returns the lists as lt_set_habitat would take them."""
+        s = LtHabitat()
+        keep = []
+        for k in ("pedges", "hedges", "minpolyid", "maxpolyid", "minholeid", "maxholeid"):
+            setattr(s, k, int(h[k]))
+        for k in ("polys", "holes", "maxbdis", "maxhdis"):
+            a = _fcol(h[k], np.float64)
+            keep.append(a)
+            setattr(s, k, _dp(a))
+        self._check(self._fn["create_polyspecs"](self._h, C.byref(s)), "create_polyspecs")
+        npoly = s.maxpolyid - s.minpolyid + 1
+        nhole = (s.maxholeid - s.minholeid + 1) if s.hedges > 0 else 0
+        ne = self._grid["rho_elements"]
+        out = dict(polyspecs=np.zeros((npoly, 2), dtype=np.int32, order="F"),
+                   holespecs=np.zeros((max(nhole, 1), 2), dtype=np.int32, order="F"),
+                   elepolys_ptr=np.zeros(ne + 1, dtype=np.int32),
+                   polyholes_ptr=np.zeros(npoly + 1, dtype=np.int32))
+        get = self._fn["get_polyspecs"]
+        self._check(get(self._h, _ip(out["polyspecs"]), _ip(out["holespecs"]) if nhole else None,
+                        _ip(out["elepolys_ptr"]), None, C.c_int32(0), _ip(out["polyholes_ptr"]), None,
+                        C.c_int32(0)), "get_polyspecs")
+        nl, nph = int(out["elepolys_ptr"][-1]), int(out["polyholes_ptr"][-1])
+        out["elepolys_ids"] = np.zeros(max(nl, 1), dtype=np.int32)
+        out["polyholes_ids"] = np.zeros(max(nph, 1), dtype=np.int32)
+        self._check(get(self._h, None, None, None, _ip(out["elepolys_ids"]), C.c_int32(nl), None,
+                        _ip(out["polyholes_ids"]), C.c_int32(nph)), "get_polyspecs")
+        return out
+
     def set_particles(self, **arrays):
         """par=(numpar,13), P_r_element=..., ... (names of abi.PARTICLE_FIELDS)."""
         s = LtParticles()

@@ -64,6 +64,8 @@ program ltrans_hip_driver
   integer(c_int32_t), allocatable, target :: land(:), hid(:)
   real(c_double), allocatable, target :: par(:,:)
   integer(c_int32_t), allocatable, target :: P_r_element(:), P_u_element(:), P_v_element(:)
+  integer(c_int32_t), allocatable :: loc_r(:), loc_u(:), loc_v(:)
+  integer(c_int32_t) :: loc_err, loc_par
   integer(c_int32_t), allocatable, target :: P_behave(:), dead(:), oob(:), settle(:), endpoly(:), &
                                             hitBottom(:), hitLand(:), err_code(:)
   real(c_double), allocatable, target :: P_swim(:,:), P_pediage(:), P_deadage(:), settletime(:)
@@ -196,6 +198,20 @@ program ltrans_hip_driver
   b%bnd_x = c_loc(bnd_x); b%bnd_y = c_loc(bnd_y); b%land = c_loc(land)
   b%bx = c_loc(bx); b%by = c_loc(by); b%hx = c_loc(hx); b%hy = c_loc(hy); b%hid = c_loc(hid)
   call lt_check(lt_set_bounds(eng, b), eng, 'lt_set_bounds')
+
+  ! setEle_all (LTRANS.f90:410, hydrodynamic_module.f90:1536-1676) on the device; the case file's
+  ! elements (located by the test's host code) are kept only to report the comparison
+  allocate(loc_r(numpar), loc_u(numpar), loc_v(numpar))
+  call lt_check(lt_locate_particles(eng, int(numpar, c_int32_t), par(:,1), par(:,2), loc_r, loc_u, loc_v, &
+                                    loc_err, loc_par), eng, 'lt_locate_particles')
+  if (loc_err /= 0) then
+    write(*,'(a,i0,a,i0)') ' setEle_all: error ', loc_err, ' at particle ', loc_par
+    stop 3
+  end if
+  write(*,'(a,i0,a)') ' setEle_all on the device: ', &
+    count(loc_r /= P_r_element .or. loc_u /= P_u_element .or. loc_v /= P_v_element), &
+    ' particles located differently from the case file'
+  P_r_element = loc_r; P_u_element = loc_u; P_v_element = loc_v
 
   pp%par = c_loc(par)
   pp%P_r_element = c_loc(P_r_element); pp%P_u_element = c_loc(P_u_element); pp%P_v_element = c_loc(P_v_element)

@@ -246,6 +246,41 @@ module ltrans_hip
       type(c_ptr), value :: engine, dst_device
       integer(c_int) :: rc
     end function
+    ! ---- init-time geometry on the device (SURVEY 8f row 4) ----
+    ! the adjacency loops of initGrid (hydrodynamic_module.f90:588-645); adjacent(elements,10)
+    function lt_build_adjacency(device, elements, row, E, adjacent) bind(C, name="lt_build_adjacency") result(rc)
+      import :: c_int, c_int32_t
+      integer(c_int32_t), value :: device, elements, row
+      integer(c_int32_t), intent(in) :: E(4, *)
+      integer(c_int32_t), intent(out) :: adjacent(elements, 10)
+      integer(c_int) :: rc
+    end function
+    ! setEle_all (hydrodynamic_module.f90:1536-1676)
+    function lt_locate_particles(engine, n, Xpar, Ypar, P_r_element, P_u_element, P_v_element, err, par) &
+        bind(C, name="lt_locate_particles") result(rc)
+      import :: c_int, c_int32_t, c_double, c_ptr
+      type(c_ptr), value :: engine
+      integer(c_int32_t), value :: n
+      real(c_double), intent(in) :: Xpar(*), Ypar(*)
+      integer(c_int32_t), intent(out) :: P_r_element(*), P_u_element(*), P_v_element(*)
+      integer(c_int32_t), intent(out) :: err, par
+      integer(c_int) :: rc
+    end function
+    ! createPolySpecs (settlement_module.f90:245-480); the list members of h may be c_null_ptr
+    function lt_create_polyspecs(engine, h) bind(C, name="lt_create_polyspecs") result(rc)
+      import :: c_int, c_ptr, lt_habitat
+      type(c_ptr), value :: engine
+      type(lt_habitat), intent(in) :: h
+      integer(c_int) :: rc
+    end function
+    function lt_get_polyspecs(engine, polyspecs, holespecs, elepolys_ptr, elepolys_ids, elepolys_cap, &
+                              polyholes_ptr, polyholes_ids, polyholes_cap) bind(C, name="lt_get_polyspecs") result(rc)
+      import :: c_int, c_int32_t, c_ptr
+      type(c_ptr), value :: engine
+      type(c_ptr), value :: polyspecs, holespecs, elepolys_ptr, elepolys_ids, polyholes_ptr, polyholes_ids
+      integer(c_int32_t), value :: elepolys_cap, polyholes_cap
+      integer(c_int) :: rc
+    end function
   end interface
 
 contains

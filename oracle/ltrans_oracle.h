@@ -54,6 +54,15 @@ int lto_sync(lto_engine *e);
 int lto_get_stats(lto_engine *e, lt_step_stats *out);
 int lto_get_particles(lto_engine *e, lt_particles *out);
 int lto_get_output(lto_engine *e, lt_output *out, int32_t reset_hits);
+/* init-time geometry (ltrans_oracle_init.inc): initGrid's adjacency lists, setEle_all, createPolySpecs */
+int lto_build_adjacency(int32_t device, int32_t elements, int32_t row, const int32_t *E, int32_t *adjacent);
+int lto_locate_particles(lto_engine *e, int32_t n, const double *Xpar, const double *Ypar,
+                         int32_t *P_r_element, int32_t *P_u_element, int32_t *P_v_element,
+                         int32_t *err, int32_t *par);
+int lto_create_polyspecs(lto_engine *e, const lt_habitat *h);
+int lto_get_polyspecs(lto_engine *e, int32_t *polyspecs, int32_t *holespecs, int32_t *elepolys_ptr,
+                      int32_t *elepolys_ids, int32_t elepolys_cap, int32_t *polyholes_ptr,
+                      int32_t *polyholes_ids, int32_t polyholes_cap);
 
 /* ---- leaf numerics, exported for pinning against oracle/_ref ------------ */
 typedef struct lto_mt { uint32_t mt[624]; int32_t mti; } lto_mt;

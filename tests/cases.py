@@ -123,6 +123,8 @@ def make_engine(case, engine_cls, engine_kw):
     e.set_bounds(case["bounds"])
     if case["habitat"] is not None:
         e.set_habitat(case["habitat"])
+    if case.get("habitat_raw") is not None:     # the lists built by the engine (createPolySpecs)
+        e.create_polyspecs(case["habitat_raw"])
     e.set_particles(**case["parts"])
     return e
 
