@@ -125,7 +125,9 @@ typedef struct lt_config {
   /* build-specific (not in LTRANS.data) */
   int32_t slab_storage;       /* LT_SLAB_F32 / LT_SLAB_F64                             */
   int32_t device;             /* HIP device ordinal, -1 = current device               */
-  int32_t reserved0;
+  int32_t resort_every;       /* internal steps between re-sorts of the device-side particle order by
+                                 rho element (keeps the gathers of a wave local as particles mix);
+                                 0 = default (32), < 0 = never.  No effect on results.     */
 } lt_config;
 
 /* Grid statics produced by initGrid (hydrodynamic_module.f90:88-657). */

@@ -53,7 +53,7 @@ class LtConfig(C.Structure):
         ("lonmin", C.c_double), ("latmin", C.c_double),
         ("seed", C.c_int32), ("ErrorFlag", C.c_int32), ("SaltTempOn", C.c_int32),
         ("TrackCollisions", C.c_int32), ("FreeSlip", C.c_int32),
-        ("slab_storage", C.c_int32), ("device", C.c_int32), ("reserved0", C.c_int32),
+        ("slab_storage", C.c_int32), ("device", C.c_int32), ("resort_every", C.c_int32),
     ]
 
     def __init__(self, **kw):

@@ -73,6 +73,10 @@ struct lt_engine {
   // particle perm[i] (0-based); sorted by rho element for memory locality
   std::vector<int> perm;
   bool sort_particles = true;
+  // periodic re-sort on the device (resort()): the host copy of perm is refreshed lazily
+  bool perm_stale = false;
+  int resort_every = 32, steps_since_sort = 0;
+  DevBuf sort_keys, sort_idx_in, sort_idx_out, sort_tmp, permute_tmp;
   DevBuf par, pr, pu, pv, P_behave, dead, oob, settle, endpoly, hitBottom, hitLand, err_code,
       P_swim, P_pediage, P_deadage, settletime, timer, P_Sprev, P_zprev, bottom, P_Salt, P_Temp;
   // rng: the reference's single serial MT19937 stream, materialised on the device
@@ -416,6 +420,64 @@ int get_field(lt_engine* e, const DevBuf& buf, T* dst, int cols) {
   return LT_OK;
 }
 
+// Re-sort of the internal particle order by rho element, on the device.  The order particles are
+// held in has no effect on results (every array of the ABI is exchanged in the reference's order
+// through `orig`, the random stream is indexed by the reference's particle number), but the gathers
+// of a wave stay local only while its 64 particles are in neighbouring elements: with fully mixed
+// particles a step takes 2.8x as long.  Stable radix sort of (element, slot), then every per-particle
+// array is gathered through the resulting index.
+int sync_perm(lt_engine* e) {
+  if (!e->perm_stale) return LT_OK;
+  HIPCHK(e, hipMemcpyAsync(e->perm.data(), e->orig.p, e->perm.size() * 4, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  e->perm_stale = false;
+  return LT_OK;
+}
+
+template <typename T>
+int permute_buf(lt_engine* e, DevBuf& b, int cols) {
+  if (!b.p) return LT_OK;
+  const int n = e->cfg.numpar;
+  const size_t bytes = (size_t)n * cols * sizeof(T);
+  hipLaunchKernelGGL((ltd::k_permute<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, (const T*)b.p,
+                     (T*)e->permute_tmp.p, (const int*)e->sort_idx_out.p, n, cols);
+  HIPCHK(e, hipMemcpyAsync(b.p, e->permute_tmp.p, bytes, hipMemcpyDeviceToDevice, e->stream));
+  return LT_OK;
+}
+
+int resort(lt_engine* e) {
+  const int n = e->cfg.numpar;
+  if (n <= 1 || !e->pr.p) return LT_OK;
+  TRY(dev_alloc(e, e->sort_keys, (size_t)n * 4));
+  TRY(dev_alloc(e, e->sort_idx_in, (size_t)n * 4));
+  TRY(dev_alloc(e, e->sort_idx_out, (size_t)n * 4));
+  TRY(dev_alloc(e, e->permute_tmp, (size_t)n * 13 * 8));
+  int bits = 1;
+  while (bits < 31 && (1 << bits) <= e->rho_elements) bits++;
+  size_t tmp_bytes = 0;
+  HIPCHK(e, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const int*)e->pr.p, (int*)e->sort_keys.p,
+                                               (const int*)e->sort_idx_in.p, (int*)e->sort_idx_out.p, n, 0, bits,
+                                               e->stream));
+  if (tmp_bytes > e->sort_tmp.bytes) TRY(dev_alloc(e, e->sort_tmp, tmp_bytes));
+  hipLaunchKernelGGL(ltd::k_iota, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, (int*)e->sort_idx_in.p, n);
+  HIPCHK(e, hipcub::DeviceRadixSort::SortPairs(e->sort_tmp.p, tmp_bytes, (const int*)e->pr.p, (int*)e->sort_keys.p,
+                                               (const int*)e->sort_idx_in.p, (int*)e->sort_idx_out.p, n, 0, bits,
+                                               e->stream));
+  TRY(permute_buf<double>(e, e->par, 13));
+  for (DevBuf* b : {&e->pr, &e->pu, &e->pv, &e->P_behave, &e->dead, &e->oob, &e->settle, &e->endpoly, &e->hitBottom,
+                    &e->hitLand, &e->err_code, &e->bottom, &e->orig})
+    TRY(permute_buf<int32_t>(e, *b, 1));
+  TRY(permute_buf<double>(e, e->P_swim, 3));
+  for (DevBuf* b : {&e->P_pediage, &e->P_deadage, &e->settletime, &e->timer, &e->P_Sprev, &e->P_zprev, &e->P_Salt,
+                    &e->P_Temp})
+    TRY(permute_buf<double>(e, *b, 1));
+  // "this particle's stored elements are verified" is per slot: verify again
+  if (e->ele_ok.p) HIPCHK(e, hipMemsetAsync(e->ele_ok.p, 0, e->ele_ok.bytes, e->stream));
+  HIPCHK(e, hipGetLastError());
+  e->perm_stale = true;
+  return LT_OK;
+}
+
 // ---- device MT19937 stream --------------------------------------------------
 
 const ltmt::Poly& mt_phi() {
@@ -635,6 +697,9 @@ int lt_create(const lt_config* cfg, lt_engine** out) {
   (void)hipMemsetAsync(e->flags.p, 0, 16, e->stream);
   const char* envs = getenv("LT_NO_SORT");
   if (envs && atoi(envs) != 0) e->sort_particles = false;
+  e->resort_every = (cfg->resort_every == 0) ? 32 : cfg->resort_every;
+  const char* envr = getenv("LT_RESORT_EVERY");
+  if (envr) e->resort_every = atoi(envr);
   const char* env = getenv("LT_BRUTE_BOUNDS");
   if (env && atoi(env) != 0) { e->use_seg_index = 0; e->use_pip_index = 0; }
   // init_genrand(seed), random_module.f90:108-119 / LTRANS.f90:241
@@ -658,7 +723,8 @@ int lt_destroy(lt_engine* e) {
                     &e->pv, &e->P_behave, &e->dead, &e->oob, &e->settle, &e->endpoly,
                     &e->hitBottom, &e->hitLand, &e->err_code, &e->P_swim, &e->P_pediage,
                     &e->P_deadage, &e->settletime, &e->timer, &e->P_Sprev, &e->P_zprev, &e->bottom, &e->P_Salt, &e->P_Temp, &e->S, &e->T, &e->counters, &e->ws_d, &e->ws_i, &e->orig, &e->ele_ok, &e->block_active, &e->count_slots, &e->out_cols, &e->out_hits, &e->rng_states, &e->rng_ring, &e->rng_gJ, &e->flag, &e->rank, &e->scan_tmp,
-                    &e->vt_x, &e->vt_y, &e->vt_yp, &e->vt_sig};
+                    &e->vt_x, &e->vt_y, &e->vt_yp, &e->vt_sig, &e->sort_keys, &e->sort_idx_in, &e->sort_idx_out,
+                    &e->sort_tmp, &e->permute_tmp};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
@@ -1173,6 +1239,7 @@ int lt_set_particles(lt_engine* e, const lt_particles* p) {
       TRY(dev_alloc(e, e->vt_yp, tb)); TRY(dev_alloc(e, e->vt_sig, tb));
     }
   }
+  TRY(sync_perm(e));
   // positions / elements may change: nothing is known to be verified any more
   TRY(dev_alloc(e, e->ele_ok, n));
   TRY(dev_alloc(e, e->block_active, ((size_t)n + 255) / 256 * 4 + 4));
@@ -1215,6 +1282,7 @@ int lt_get_particles(lt_engine* e, lt_particles* out) {
   if (!e || !out) return LT_ERR_ARG;
   if (!e->have_particles) return fail(e, LT_ERR_STATE, "no particles uploaded");
   HIPCHK(e, hipSetDevice(e->device));
+  TRY(sync_perm(e));
   TRY(get_field<double>(e, e->par, out->par, 13));
   TRY(get_field<int32_t>(e, e->pr, out->P_r_element, 1));
   TRY(get_field<int32_t>(e, e->pu, out->P_u_element, 1));
@@ -1667,6 +1735,10 @@ int lt_set_rng_window_draws(lt_engine* e, int64_t draws_before, int64_t draws_to
 // draws -- the prefix sum that places every tracked particle in the serial random stream.
 // Returns with e->stream idle and the shard's number of draws known.
 static int step_prepare(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32_t it) {
+  if (e->resort_every > 0 && ++e->steps_since_sort > e->resort_every) {
+    TRY(resort(e));
+    e->steps_since_sort = 0;
+  }
   StepParams& P = e->pre_P;
   fill_params(e, P);
   P.ex0 = ex3[0]; P.ex1 = ex3[1]; P.ex2 = ex3[2];

@@ -151,3 +151,18 @@ __global__ void k_count_active(const StepParams P, unsigned long long* out) {
     if (s) atomicAdd(out + (blockIdx.x & 63) * 8, (unsigned long long)s);
   }
 }
+
+// ------------------------------------------------------ re-sort of the internal particle order
+// dst[c*n + i] = src[c*n + idx[i]] for the columns of one per-particle array
+template <typename T>
+__global__ void k_permute(const T* __restrict__ src, T* __restrict__ dst, const int* __restrict__ idx, int n,
+                          int cols) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int j = idx[i];
+  for (int c = 0; c < cols; c++) dst[(size_t)c * n + i] = src[(size_t)c * n + j];
+}
+__global__ void k_iota(int* __restrict__ v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = i;
+}

@@ -36,7 +36,7 @@ module ltrans_hip
     integer(c_int32_t) :: SphericalProjection
     real(c_double)     :: lonmin, latmin
     integer(c_int32_t) :: seed, ErrorFlag, SaltTempOn, TrackCollisions, FreeSlip
-    integer(c_int32_t) :: slab_storage, device, reserved0
+    integer(c_int32_t) :: slab_storage, device, resort_every
   end type lt_config
 
   type, bind(C) :: lt_grid
@@ -303,7 +303,7 @@ contains
     cfg%PI = 3.14159265358979d0
     cfg%Earth_Radius = 6378000.d0; cfg%SphericalProjection = 0; cfg%lonmin = -77.d0; cfg%latmin = 36.d0
     cfg%seed = 9; cfg%ErrorFlag = 1; cfg%SaltTempOn = 0; cfg%TrackCollisions = 0; cfg%FreeSlip = 0
-    cfg%slab_storage = LT_SLAB_F32; cfg%device = -1; cfg%reserved0 = 0
+    cfg%slab_storage = LT_SLAB_F32; cfg%device = -1; cfg%resort_every = 0
   end function
 
   ! engine-owned message of the last failure as a Fortran string

@@ -1,0 +1,84 @@
+"""The periodic device-side re-sort of the internal particle order (lt_engine.hip: resort();
+lt_config.resort_every) must not change anything the host can see: every array of the ABI is
+exchanged in the reference's particle order and the random stream is indexed by the reference's
+particle number."""
+import numpy as np
+import pytest
+
+import cases
+import ltrans_amd
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("par", "P_r_element", "P_u_element", "P_v_element", "dead", "oob", "settle", "endpoly", "hitBottom",
+          "hitLand", "err_code", "P_swim", "settletime")
+
+
+@pytest.mark.parametrize("name", ["tiny_adv", "tiny_turb", "tiny_reflect", "tiny_settle", "tiny_beh5", "tiny_beh7"])
+def test_resort_every_step_changes_nothing(name):
+    out = {}
+    for every in (-1, 1, 7):
+        case = cases.build_case(name, resort_every=every)
+        out[every] = cases.run_case(case, ltrans_amd.Engine, {}, n_external=2)
+    for every in (1, 7):
+        for k in FIELDS:
+            if k in out[-1] and out[-1][k] is not None:
+                assert np.array_equal(out[every][k], out[-1][k]), (every, k)
+        assert out[every]["stats"] == out[-1]["stats"]
+
+
+def test_resort_with_reupload_between_steps():
+    """lt_set_particles / lt_get_particles after a re-sort use the refreshed host copy of the order."""
+    case = cases.build_case("tiny_turb", resort_every=1)
+    ref = cases.run_case(cases.build_case("tiny_turb", resort_every=-1), ltrans_amd.Engine, {}, n_external=1)
+    e = cases.make_engine(case, ltrans_amd.Engine, {})
+    from ltrans_amd.driver import LtransRun
+    run = LtransRun(e, case["cfg"].dt, case["cfg"].idt, case["record"])
+    run.init_hydro()
+
+    def on_step(p, it, ex, ix):
+        if it % 5 == 0:      # download everything and upload it again: a no-op if the order is handled right
+            st = e.get_particles()
+            e.set_particles(**{k: st[k] for k in ("par", "P_r_element", "P_u_element", "P_v_element", "dead", "oob",
+                                                  "hitBottom", "hitLand")})
+
+    run.run(1, on_step=on_step)
+    got = e.get_particles()
+    assert np.array_equal(got["par"], ref["par"])
+    assert np.array_equal(got["P_r_element"], ref["P_r_element"])
+    e.close()
+
+
+def test_resort_recovers_locality(monkeypatch):
+    """Start from the reference's (random) particle order: after the first re-sort a step is as fast
+    as with the order chosen at upload."""
+    import time
+    from ltrans_amd import roms_synth as rs
+    from ltrans_amd.driver import LtransRun
+    monkeypatch.setenv("LT_NO_SORT", "1")
+    g = rs.make_grid(256, 128, 16)
+    geo, bounds = rs.build_geometry(g), rs.create_bounds(g)
+    n = 400_000
+    times = {}
+    for every in (-1, 8):
+        cfg = ltrans_amd.LtConfig(numpar=n, us=16, ws=17, dt=3600, idt=120, resort_every=every)
+        parts = rs.make_particles(g, geo, bounds, n, seed=5)
+        recs = {}
+        e = ltrans_amd.Engine(cfg)
+        e.set_grid(geo)
+        e.set_bounds(bounds)
+        e.set_particles(**parts, **rs.behaviour_state(cfg, n))
+        run = LtransRun(e, cfg.dt, cfg.idt, lambda r: recs.setdefault(r, rs.make_record(g, geo, r, with_kh=False)))
+        run.init_hydro()
+        run.run(1, max_internal=12)
+        e.sync()
+        t0 = time.perf_counter()
+        run.run(1, max_internal=12)
+        e.sync()
+        times[every] = (time.perf_counter() - t0) / 12
+        out = e.get_particles(fields=("par",))
+        times[(every, "par")] = out["par"]
+        e.close()
+    assert np.array_equal(times[(-1, "par")], times[(8, "par")])
+    print(f"step time, particles in random order: {times[-1] * 1e3:.2f} ms; after a re-sort: {times[8] * 1e3:.2f} ms")
+    assert times[8] < 0.8 * times[-1]
