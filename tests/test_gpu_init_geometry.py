@@ -130,6 +130,21 @@ def test_create_polyspecs(okw):
     assert big in ids[ptr[inside - 1]:ptr[inside]]
 
 
+def test_create_polyspecs_without_holes_and_empty_locate(okw):
+    polygons = [(6000.0, 5000.0, 2500.0, 12), (30000.0, 20000.0, 400.0, 5)]
+    g, geo, hip, ora, hab = _engines(okw, 40, 32, [(10, 14, 6, 9)], settle=True, polygons=polygons)
+    assert hab["hedges"] == 0
+    a, b = hip.create_polyspecs(hab), ora.create_polyspecs(hab)
+    for k in ("polyspecs", "elepolys_ptr", "polyholes_ptr"):
+        assert np.array_equal(a[k], b[k]), k
+    n = int(b["elepolys_ptr"][-1])
+    assert n > 0 and np.array_equal(a["elepolys_ids"][:n], b["elepolys_ids"][:n])
+    assert int(a["polyholes_ptr"][-1]) == 0
+    for e in (hip, ora):
+        r, u, v, err, par = e.locate_particles(np.zeros(0), np.zeros(0))
+        assert r.size == 0 and (err, par) == (0, 0)
+
+
 def test_settlement_with_device_built_lists(okw):
     """tiny_settle with the habitat installed by lt_create_polyspecs instead of lt_set_habitat:
     same trajectories and settlement as the oracle with its own createPolySpecs."""
