@@ -380,10 +380,13 @@ int set_slab_t(lt_engine* e, int slot, const lt_slab* s) {
   return LT_OK;
 }
 
+int sync_perm(lt_engine* e);  // the host copy of the internal order, after a device-side re-sort
+
 // upload one per-particle array (cols columns, column-major) in the engine's
 // internal order: dst[c*n + i] = src[c*n + perm[i]]
 template <typename T>
 int put_field(lt_engine* e, DevBuf& buf, const T* src, int cols) {
+  if (src) TRY(sync_perm(e));
   const size_t n = (size_t)e->cfg.numpar;
   const size_t bytes = n * cols * sizeof(T);
   if (src) {
@@ -407,6 +410,7 @@ int put_field(lt_engine* e, DevBuf& buf, const T* src, int cols) {
 template <typename T>
 int get_field(lt_engine* e, const DevBuf& buf, T* dst, int cols) {
   if (!dst || !buf.p) return LT_OK;
+  TRY(sync_perm(e));
   const size_t n = (size_t)e->cfg.numpar;
   std::vector<T> tmp(n * cols);
   HIPCHK(e, hipMemcpyAsync(tmp.data(), buf.p, n * cols * sizeof(T), hipMemcpyDeviceToHost, e->stream));
@@ -1329,6 +1333,7 @@ int lt_get_output(lt_engine* e, lt_output* out, int32_t reset_hits) {
   if (out->hitBottom) HIPCHK(e, hipMemcpyAsync(out->hitBottom, (int*)e->out_hits.p, n * 4, hipMemcpyDeviceToHost, e->stream));
   if (out->hitLand) HIPCHK(e, hipMemcpyAsync(out->hitLand, (int*)e->out_hits.p + n, n * 4, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (out->salt || out->temp) TRY(sync_perm(e));
   if (out->salt) TRY(get_field<double>(e, e->P_Salt, out->salt, 1));
   if (out->temp) TRY(get_field<double>(e, e->P_Temp, out->temp, 1));
   return LT_OK;
@@ -1572,10 +1577,11 @@ int lt_test_div(const double* a, const double* b, double* q_fast, double* q_ref,
  * points (16); then what the fast path of k_rk computes for the same knots: YPC1 through the
  * prepared divisors and the hardware min / max (4), tensions through sigs_classify +
  * sigs_newton / sigs_secant (3), SigErr flag, HVAL at the 8 points through hval_interval_s (8;
- * the last 5 unused).  kind 5: x -> exp_core(x), lt_exp(x) (the host-libm-exact exp). */
+ * the last 5 unused).  kind 5: x -> exp_core(x), lt_exp(x) (the host-libm-exact exp).  kind 6: x -> lt_log, lt_log10,
+ * lt_pow_half, lt_cos, lt_sin, lt_sincos (sin, cos) of lt_libm.h. */
 __global__ void k_test_leaf(int kind, const double* in, double* out, int n) {
   using namespace ltd;
-  exp_table_load();
+  libm_tables_load<LM_EXP | LM_LOG | LM_POW | LM_SINCOS>();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   if (kind == 1) {
@@ -1643,11 +1649,17 @@ __global__ void k_test_leaf(int kind, const double* in, double* out, int n) {
   } else if (kind == 5) {
     out[2 * (size_t)i] = exp_core(in[i]);
     out[2 * (size_t)i + 1] = lt_exp(in[i]);
+  } else if (kind == 6) {
+    double* o = out + 7 * (size_t)i;
+    const double x = in[i];
+    o[0] = lt_log(x); o[1] = lt_log10(x); o[2] = lt_pow_half(x);
+    o[3] = lt_cos(x); o[4] = lt_sin(x);
+    lt_sincos(x, &o[5], &o[6]);
   }
 }
 int lt_test_leaf(int32_t kind, const double* in, int32_t n, int32_t in_per_item, double* out, int32_t out_per_item) {
-  if (!in || !out || n < 0 || kind < 1 || kind > 5) return LT_ERR_ARG;
-  const int expect_in[6] = {0, 7, 10, 1, 16, 1}, expect_out[6] = {0, 1, 1, 3, 37, 2};
+  if (!in || !out || n < 0 || kind < 1 || kind > 6) return LT_ERR_ARG;
+  const int expect_in[7] = {0, 7, 10, 1, 16, 1, 1}, expect_out[7] = {0, 1, 1, 3, 37, 2, 7};
   if (in_per_item != expect_in[kind] || out_per_item != expect_out[kind]) return LT_ERR_ARG;
   double *di = nullptr, *dout = nullptr;
   const size_t bi = (size_t)n * in_per_item * 8, bo = (size_t)n * out_per_item * 8;

@@ -73,7 +73,6 @@ __global__ void k_pack_positions(const double* __restrict__ par, const int* __re
 // (doubles, stride numpar); hits: hitBottom, hitLand (ints, stride numpar).
 __global__ void k_output(const StepParams P, double Earth_Radius, int Spherical, double lonmin, double latmin,
                          double* __restrict__ cols, int* __restrict__ hits, int reset_hits) {
-  exp_table_load();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.numpar) return;
   const size_t N = (size_t)P.numpar;
@@ -83,11 +82,11 @@ __global__ void k_output(const StepParams P, double Earth_Radius, int Spherical,
   double lon, lat;
   if (Spherical) {
     const double la = y * 180.0 / (Earth_Radius * P.PI) + latmin;
-    lon = x * 180.0 / (Earth_Radius * P.PI * cos(la / RCF)) + lonmin;
+    lon = x * 180.0 / (Earth_Radius * P.PI * lt_cos_g(la / RCF)) + lonmin;
     lat = y * RCF / Earth_Radius + latmin;
   } else {
     lon = x / Earth_Radius * RCF;
-    lat = 2.0 * RCF * (atan(exp_core(y / Earth_Radius)) - P.PI / 4.0);
+    lat = 2.0 * RCF * (atan(exp_core_g(y / Earth_Radius)) - P.PI / 4.0);
   }
   int status = P.P_behave[i];
   if (P.dead[i]) status = -1;

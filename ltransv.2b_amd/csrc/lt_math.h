@@ -14,7 +14,6 @@
 // comparison chain, and nothing is allocated.
 #pragma once
 #include <hip/hip_runtime.h>
-#include "lt_exp_table.h"
 
 namespace ltd {
 
@@ -75,78 +74,10 @@ LT_DEV double div_prep(double a, const Divisor& d) {
   return (a == 0.0) ? q : __builtin_fma(r, d.y, q);
 }
 
-// exp() as the CPU run of LTRANS evaluates it.  The tension-spline code branches on quantities that
-// depend on the last bit of exp (SIGS' Newton stopping tests and its 10000-iteration SigErr exit,
-// tension_module.f90:531-580), so a merely faithful exp makes a few particles per million take the
-// other branch and their trajectories drift apart over hundreds of steps.  The host libm (glibc >= 2.28
-// on an FMA-capable x86-64: the published table-driven algorithm, N = 128, degree-5 polynomial) is a
-// fixed sequence of 8 fma, 3 mul, 2 add and one table read; restated here operation for operation it
-// returns the same bits (tests/test_gpu_div.py checks 2.5e6 arguments against the host) and is ~3x
-// shorter than the device library's exp.  The 2 KB table is copied to LDS by every kernel that
-// evaluates an exp (exp_table_load(), before any early exit): the read sits on the dependency chain
-// of the Newton iteration.
-//   exp_core(x): |x| < 512 (HVAL/HPVAL: |SIG*B| <= 170; SNHCSH; the secant loop, SIG <= 85; x2lon/y2lat)
-//   lt_exp(x):   any x <= 0 the way libm's out-of-line path does it (unfused scale + scale*tmp on a
-//                2^1022-scaled value, the double-double fix-up of subnormal results, 0 below -1024) --
-//                the Newton loop starts at SIG = sqrt(10 T - 20) with T unbounded -- and the device
-//                library's exp for x >= 512, which no caller produces.
-struct ExpPair { unsigned long long tail, sbits; };
-__device__ const ExpPair g_exp_tab[128] __attribute__((aligned(16))) = LT_EXP_TABLE_INIT;
-__shared__ ExpPair s_exp_tab[128];
-
-LT_DEV void exp_table_load() {
-  for (int i = threadIdx.x; i < 128; i += blockDim.x) s_exp_tab[i] = g_exp_tab[i];
-  __syncthreads();
-}
-
-// exp(x) = scale * (1 + tmp): the polynomial part and the bits of the scale 2^(k/128)
-LT_DEV void exp_parts(double x, double& tmp, unsigned long long& sbits) {
-  const double InvLn2N = 0x1.71547652b82fep+7, Shift = 0x1.8p+52;
-  const double NegLn2hiN = -0x1.62e42fefa0000p-8, NegLn2loN = -0x1.cf79abc9e3b3ap-47;
-  const double C2 = 0x1.ffffffffffdbdp-2, C3 = 0x1.555555555543cp-3;
-  const double C4 = 0x1.55555cf172b91p-5, C5 = 0x1.1111167a4d017p-7;
-  const double z = __builtin_fma(x, InvLn2N, Shift);
-  const unsigned long long ki = (unsigned long long)__double_as_longlong(z);
-  const double kd = z - Shift;
-  double r = __builtin_fma(kd, NegLn2hiN, x);
-  r = __builtin_fma(kd, NegLn2loN, r);
-  const ExpPair e = s_exp_tab[ki & 127u];
-  const double tail = __longlong_as_double((long long)e.tail);
-  sbits = e.sbits + (ki << 45);
-  const double p23 = __builtin_fma(C3, r, C2);
-  const double t3 = r + tail;
-  const double r2 = r * r;
-  const double p45 = __builtin_fma(r, C5, C4);
-  tmp = __builtin_fma(p23, r2, t3);
-  const double r4 = r2 * r2;
-  tmp = __builtin_fma(r4, p45, tmp);
-}
-LT_DEV double exp_core(double x) {
-  double tmp;
-  unsigned long long sbits;
-  exp_parts(x, tmp, sbits);
-  const double scale = __longlong_as_double((long long)sbits);
-  return __builtin_fma(scale, tmp, scale);
-}
-LT_DEV double lt_exp(double x) {
-  if (fabs(x) < 512.0) return exp_core(x);
-  if (!(x < 0.0)) return exp(x);  // x >= 512 or NaN
-  if (x <= -1024.0) return 0.0;
-  double tmp;
-  unsigned long long sbits;
-  exp_parts(x, tmp, sbits);
-  const double scale = __longlong_as_double((long long)(sbits + (1022ull << 52)));
-  const double st = scale * tmp;
-  double y = scale + st;
-  if (y < 1.0) {  // subnormal result: round once, at the final scaling
-    double lo = scale - y + st;
-    const double hi = 1.0 + y;
-    lo = 1.0 - hi + y + lo;
-    y = (hi + lo) - 1.0;
-    if (y == 0.0) y = 0.0;
-  }
-  return 0x1p-1022 * y;
-}
+// exp, log, log10, pow(x, 0.5), sin, cos, sincos evaluated exactly as the host libm of the CPU run
+// does (the tension-spline code branches on the last bit of exp, the random-walk displacements
+// carry log / cos / pow): lt_libm.h, shared with the host-side check of tests/.
+#include "lt_libm.h"
 
 // SIGS' convexity Newton iteration (tension_module.f90:531-580) gives up after
 // 10000 evaluations (SigErr).  Each iterate is a function of the previous one

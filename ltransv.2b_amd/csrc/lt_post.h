@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void k_post(const StepParams P) {
       if (P.HTurbOn) {
         const unsigned long long di = P.rng_base + (unsigned long long)(unsigned)P.rank[P.orig[n]];
         const double devX = draw_norm(P, di), devY = draw_norm(P, di + 2);
-        const double amp = sqrt(2.0 / 1.0 * P.ConstantHTurb * P.idt);  // (2/r*KM*idt)**0.5
+        const double amp = lt_pow_half_g(2.0 / 1.0 * P.ConstantHTurb * P.idt);  // (2/r*KM*idt)**0.5: libm's pow
         TurbHx = devX * amp;
         TurbHy = devY * amp;
       }
@@ -98,8 +98,10 @@ __global__ __launch_bounds__(256) void k_post(const StepParams P) {
             if (currentspeed > (double)0.05f) {
               const double Hdistance = P.Hswimspeed * P.idt;
               const double theta = atan(cv / cu);
-              if (cu > 0.0) { XBehav = Hdistance * cos(theta); YBehav = Hdistance * sin(theta); }
-              if (cu < 0.0) { XBehav = -1.0 * Hdistance * cos(theta); YBehav = -1.0 * Hdistance * sin(theta); }
+              double sth, cth;
+              lt_sincos_g(theta, &sth, &cth);
+              if (cu > 0.0) { XBehav = Hdistance * cth; YBehav = Hdistance * sth; }
+              if (cu < 0.0) { XBehav = -1.0 * Hdistance * cth; YBehav = -1.0 * Hdistance * sth; }
               if (cu == 0 && cv >= 0.0) { XBehav = 0.0; YBehav = Hdistance; }
               if (cu == 0 && cv <= 0.0) { XBehav = 0.0; YBehav = -1.0 * Hdistance; }
               ZBehav = P_depth + P.Swimdepth;

@@ -4,6 +4,10 @@
 #pragma once
 
 // ---------------------------------------------------- field access
+// log10 of the log layer at the bottom (hydrodynamic_module.f90: the water-column profile below the
+// deepest level): rare, and out of line so that its registers are not k_rk's
+LT_DEV_NOINLINE double log10_call(double x) { return lt_log10_g(x); }
+
 template <typename SlabT>
 LT_DEV double fld(const SlabT* F, int node, int L, int k, int ps) {
   return (double)F[((size_t)(node - 1) * L + (k - 1)) * LT_SLOTS + ps];
@@ -266,7 +270,7 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
         double val = apply_interp(w, fld(F, nd.x, L, k, ps), fld(F, nd.y, L, k, ps),
                                   fld(F, nd.z, L, k, ps), fld(F, nd.w, L, k, ps));
         double ztop = level_at(qt, zeta, h, VT);
-        ws.res[s][lane] = val * log10((Zs - wzb1) / P.z0) / log10((ztop - wzb1) / P.z0);
+        ws.res[s][lane] = val * log10_call((Zs - wzb1) / P.z0) / log10_call((ztop - wzb1) / P.z0);
       }
     }
     LevCoef lc[4];
@@ -483,8 +487,10 @@ __global__ __launch_bounds__(256) void k_pre(const StepParams P) {
         if (Z > zeta[2]) Pz[2] = zeta[2] - (double)0.001f;
         const double Zpar = polintd3(P.ex0, P.ex1, P.ex2, Pz[0], Pz[1], Pz[2], P.ix1);
         wsd[(size_t)WS_PDEPTH * N] = P_depth;
-        wsd[(size_t)WS_COSA * N] = cos(P_angle);
-        wsd[(size_t)WS_SINA * N] = sin(P_angle);
+        double sa, ca;  // one sincos call in a GCC-compiled host program
+        lt_sincos_g(P_angle, &sa, &ca);
+        wsd[(size_t)WS_COSA * N] = ca;
+        wsd[(size_t)WS_SINA * N] = sa;
         wsd[(size_t)WS_ZETA0 * N] = zeta[0];
         wsd[(size_t)WS_ZETA1 * N] = zeta[1];
         wsd[(size_t)WS_ZETA2 * N] = zeta[2];
@@ -613,7 +619,7 @@ __global__ __launch_bounds__(256) void k_beh_pre(const StepParams P) {
     double E0 = 0.0;
     if (dtime > P.twistart && dtime < P.twiend) {
       const double tst = (dtime - P.twistart) * 3600.0;
-      E0 = P.Em * sin(P.PI * tst / (P.daylength * 3600.0)) * sin(P.PI * tst / (P.daylength * 3600.0));
+      E0 = P.Em * lt_sin_g(P.PI * tst / (P.daylength * 3600.0)) * lt_sin_g(P.PI * tst / (P.daylength * 3600.0));
     }
     const double P_light = E0 * lt_exp(P.Kd * P_zc);
     if (P_light < P.thresh) { random = true; thr2 = 0.5; }
@@ -803,7 +809,7 @@ LT_DEV void find_currents_ref(const StepParams& P, const double* lev, const Colu
                                   fld(F, nd.z, L, k, ps), fld(F, nd.w, L, k, ps));
         const double z1s = (s == 0) ? C.z1[0] : (s == 1) ? C.z1[1] : C.z1[2];
         double ztop = (var == 2) ? level_z(wtab, 2, zeta, C.h, P.hc, P.Vtransform) : z1s;
-        r = val * log10((Zs - C.wz1[0]) / P.z0) / log10((ztop - C.wz1[0]) / P.z0);
+        r = val * log10_call((Zs - C.wz1[0]) / P.z0) / log10_call((ztop - C.wz1[0]) / P.z0);
       } else {
         const int k0 = (var == 2) ? iii : ii;
         const double Pzs = (s == 0) ? C.Pz[0] : (s == 1) ? C.Pz[1] : C.Pz[2];

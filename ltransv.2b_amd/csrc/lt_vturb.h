@@ -17,7 +17,7 @@ LT_DEV double draw_real1(const StepParams& P, unsigned long long idx) {
 }
 LT_DEV double draw_norm(const StepParams& P, unsigned long long idx) {
   const double dev1 = draw_real3(P, idx), dev2 = draw_real3(P, idx + 1);
-  return sqrt(-2.0 * log(dev1)) * cos(2.0 * P.PI * dev2);
+  return sqrt(-2.0 * lt_log_g(dev1)) * lt_cos_g(2.0 * P.PI * dev2);  // (k_post: two deviates per particle-step)
 }
 
 // HVAL / HPVAL on a spline table in memory (element k of array a at a[k*stride]),
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void k_vt_sigs(const StepParams P) {
 struct __attribute__((packed, aligned(4))) RawWords4 { uint32_t a, b, c, d; };
 __global__ __launch_bounds__(256) void k_vt_walk(const StepParams P) {
   __shared__ uint2 rbuf[8][256];
-  exp_table_load();
+  libm_tables_load<LM_EXP | LM_LOG | LM_POW | LM_SINCOS>();
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= P.numpar) return;
   const int fl = P.ws_i[n];
@@ -538,9 +538,9 @@ __global__ __launch_bounds__(256) void k_vt_walk(const StepParams P) {
     // norm(), norm_module.f90:25-39
     const double dev1 = ((double)ltmt_temper(raw1) + 0.5) / 4294967296.0;
     const double dev2 = ((double)ltmt_temper(raw2) + 0.5) / 4294967296.0;
-    const double DEV = sqrt(-2.0 * log(dev1)) * cos(2.0 * P.PI * dev2);
+    const double DEV = sqrt(-2.0 * lt_log(dev1)) * lt_cos(2.0 * P.PI * dev2);
     // (2/r * KH3rd * deltat)**0.5 with r = 1
-    ParZc = ParZc + KprimeZc + DEV * sqrt(2.0 / 1.0 * KH3rdc * deltat);
+    ParZc = ParZc + KprimeZc + DEV * lt_pow_half(2.0 / 1.0 * KH3rdc * deltat);
   }
   wsd[(size_t)WS_TURBV * N] = P_zc - ParZc;  // :342
   if (sigerr != 0) atomicAdd(&P.counters[CNT_SIGERR], 1ull);

@@ -82,3 +82,20 @@ def test_resort_recovers_locality(monkeypatch):
     assert np.array_equal(times[(-1, "par")], times[(8, "par")])
     print(f"step time, particles in random order: {times[-1] * 1e3:.2f} ms; after a re-sort: {times[8] * 1e3:.2f} ms")
     assert times[8] < 0.8 * times[-1]
+
+
+def test_resort_then_output_columns():
+    """lt_get_output after a re-sort: the salinity / temperature columns come back in the reference's order."""
+    res = {}
+    for every in (-1, 1):
+        case = cases.build_case("tiny_salt", resort_every=every)
+        e = cases.make_engine(case, ltrans_amd.Engine, {})
+        from ltrans_amd.driver import LtransRun
+        run = LtransRun(e, case["cfg"].dt, case["cfg"].idt, case["record"])
+        run.init_hydro()
+        run.run(1, max_internal=9)
+        res[every] = e.get_output(salt_temp=True)
+        e.close()
+    for k in ("lon", "lat", "z", "salt", "temp"):
+        assert np.array_equal(res[1][k], res[-1][k]), k
+    assert np.ptp(res[1]["salt"]) > 0.0
