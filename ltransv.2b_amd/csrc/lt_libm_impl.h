@@ -260,37 +260,45 @@ LT_LM int LT_LM_NAME(lt_sc_reduce)(double x, double* a, double* da, int fma_) {
   *da = db;
   return (int)(LT_LM_ASU(t) & 3u);
 }
+// The four argument ranges of __cos / __sin end in the same two evaluations, do_cos(a, da) or
+// do_sin(a, da), with (a, da) = (x, 0), the complement to pi/2, or the reduced argument: the range
+// decides (a, da, which one, sign) first, so that lanes of different ranges share the two
+// evaluations instead of running three copies of them one after the other.
 LT_LM double LT_LM_NAME(lt_cos)(double x) {
   const unsigned k = (unsigned)(LT_LM_ASU(x) >> 32) & 0x7fffffffu;
-  if (k < 0x3e400000u) return 1.0;
-  if (k < 0x3feb6000u) return LT_LM_NAME(lt_sc_do_cos)(x, 0.0, 1);
-  if (k < 0x400368fdu) {
-    const double y = LT_SC_HP0 - fabs(x), a = y + LT_SC_HP1, da = (y - a) + LT_SC_HP1;
-    return LT_LM_NAME(lt_sc_do_sin)(a, da, 1);
+  if (k >= 0x419921FBu) return cos(x);
+  double a = x, da = 0.0;
+  int n = 1;  // odd: do_cos; bit 1: negate
+  if (k >= 0x400368fdu) {
+    n = LT_LM_NAME(lt_sc_reduce)(x, &a, &da, 1) + 1;
+  } else if (k >= 0x3feb6000u) {
+    const double y = LT_SC_HP0 - fabs(x);
+    a = y + LT_SC_HP1;
+    da = (y - a) + LT_SC_HP1;
+    n = 0;
   }
-  if (k < 0x419921FBu) {
-    double a, da;
-    const int n = LT_LM_NAME(lt_sc_reduce)(x, &a, &da, 1) + 1;
-    const double r = (n & 1) ? LT_LM_NAME(lt_sc_do_cos)(a, da, 1) : LT_LM_NAME(lt_sc_do_sin)(a, da, 1);
-    return (n & 2) ? -r : r;
-  }
-  return cos(x);
+  double r = (n & 1) ? LT_LM_NAME(lt_sc_do_cos)(a, da, 1) : LT_LM_NAME(lt_sc_do_sin)(a, da, 1);
+  if (n & 2) r = -r;
+  return (k < 0x3e400000u) ? 1.0 : r;
 }
 LT_LM double LT_LM_NAME(lt_sin)(double x) {
   const unsigned k = (unsigned)(LT_LM_ASU(x) >> 32) & 0x7fffffffu;
-  if (k < 0x3e500000u) return x;
-  if (k < 0x3feb6000u) return LT_LM_NAME(lt_sc_do_sin)(x, 0.0, 1);
-  if (k < 0x400368fdu) {
-    const double t = LT_SC_HP0 - fabs(x);
-    return copysign(LT_LM_NAME(lt_sc_do_cos)(t, LT_SC_HP1, 1), x);
+  if (k >= 0x419921FBu) return sin(x);
+  double a = x, da = 0.0;
+  int n = 0;  // even: do_sin; bit 1: negate
+  int sign_of_x = 0;
+  if (k >= 0x400368fdu) {
+    n = LT_LM_NAME(lt_sc_reduce)(x, &a, &da, 1);
+  } else if (k >= 0x3feb6000u) {
+    a = LT_SC_HP0 - fabs(x);
+    da = LT_SC_HP1;
+    n = 1;
+    sign_of_x = 1;
   }
-  if (k < 0x419921FBu) {
-    double a, da;
-    const int n = LT_LM_NAME(lt_sc_reduce)(x, &a, &da, 1);
-    const double r = (n & 1) ? LT_LM_NAME(lt_sc_do_cos)(a, da, 1) : LT_LM_NAME(lt_sc_do_sin)(a, da, 1);
-    return (n & 2) ? -r : r;
-  }
-  return sin(x);
+  double r = (n & 1) ? LT_LM_NAME(lt_sc_do_cos)(a, da, 1) : LT_LM_NAME(lt_sc_do_sin)(a, da, 1);
+  if (n & 2) r = -r;
+  if (sign_of_x) r = copysign(r, x);
+  return (k < 0x3e500000u) ? x : r;
 }
 // sin and cos of one argument as glibc's sincos (one non-FMA build)
 LT_LM void LT_LM_NAME(lt_sincos)(double x, double* sinx, double* cosx) {
