@@ -260,6 +260,36 @@ LT_LM int LT_LM_NAME(lt_sc_reduce)(double x, double* a, double* da, int fma_) {
   *da = db;
   return (int)(LT_LM_ASU(t) & 3u);
 }
+// do_cos(a, da) or do_sin(a, da) of the FMA build in one body: the table look-up, the reduced
+// argument and the two polynomials are common, only the last few operations differ (lanes of one
+// wave need both kinds at almost every call)
+LT_LM double LT_LM_NAME(lt_sc_eval)(double x, double dx, int is_cos) {
+  const double xold = x;
+  if (!is_cos && fabs(x) < LT_SC_T126) return LT_LM_NAME(lt_sc_taylor)(x * x, x, dx, 1);
+  if (is_cos ? (x < 0) : (x <= 0)) dx = -dx;
+  const double u = LT_SC_BIG + fabs(x);
+  const int k = (int)(unsigned)LT_LM_ASU(u) * 4;
+  x = fabs(x) - (u - LT_SC_BIG);
+  if (is_cos) x = x + dx;
+  const double xx = x * x;
+  const double sn = LT_SINCOS_TAB[k], ssn = LT_SINCOS_TAB[k + 1], cs = LT_SINCOS_TAB[k + 2], ccs = LT_SINCOS_TAB[k + 3];
+  const double x3 = x * xx;
+  const double ps = LT_LM_FMA(xx, LT_SC_SN5, LT_SC_SN3);
+  const double xxpc = xx * LT_LM_FMA(xx, LT_LM_FMA(xx, LT_SC_CS6, LT_SC_CS4), LT_SC_CS2);
+  if (is_cos) {
+    const double s = LT_LM_FMA(x3, ps, x);
+    double cor = LT_LM_FMA(-s, ssn, ccs);
+    cor = LT_LM_FMA(-xxpc, cs, cor);
+    cor = LT_LM_FMA(-s, sn, cor);
+    return cs + cor;
+  }
+  const double s = x + LT_LM_FMA(x3, ps, dx);
+  const double c = LT_LM_FMA(x, dx, xxpc);
+  double cor = LT_LM_FMA(s, ccs, ssn);
+  cor = LT_LM_FMA(-c, sn, cor);
+  cor = LT_LM_FMA(s, cs, cor);
+  return copysign(sn + cor, xold);
+}
 // The four argument ranges of __cos / __sin end in the same two evaluations, do_cos(a, da) or
 // do_sin(a, da), with (a, da) = (x, 0), the complement to pi/2, or the reduced argument: the range
 // decides (a, da, which one, sign) first, so that lanes of different ranges share the two
@@ -277,7 +307,7 @@ LT_LM double LT_LM_NAME(lt_cos)(double x) {
     da = (y - a) + LT_SC_HP1;
     n = 0;
   }
-  double r = (n & 1) ? LT_LM_NAME(lt_sc_do_cos)(a, da, 1) : LT_LM_NAME(lt_sc_do_sin)(a, da, 1);
+  double r = LT_LM_NAME(lt_sc_eval)(a, da, n & 1);
   if (n & 2) r = -r;
   return (k < 0x3e400000u) ? 1.0 : r;
 }
@@ -295,7 +325,7 @@ LT_LM double LT_LM_NAME(lt_sin)(double x) {
     n = 1;
     sign_of_x = 1;
   }
-  double r = (n & 1) ? LT_LM_NAME(lt_sc_do_cos)(a, da, 1) : LT_LM_NAME(lt_sc_do_sin)(a, da, 1);
+  double r = LT_LM_NAME(lt_sc_eval)(a, da, n & 1);
   if (n & 2) r = -r;
   if (sign_of_x) r = copysign(r, x);
   return (k < 0x3e500000u) ? x : r;
