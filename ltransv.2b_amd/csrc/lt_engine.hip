@@ -1578,7 +1578,7 @@ int lt_test_div(const double* a, const double* b, double* q_fast, double* q_ref,
  * prepared divisors and the hardware min / max (4), tensions through sigs_classify +
  * sigs_newton / sigs_secant (3), SigErr flag, HVAL at the 8 points through hval_interval_s (8;
  * the last 5 unused).  kind 5: x -> exp_core(x), lt_exp(x) (the host-libm-exact exp).  kind 6: x -> lt_log, lt_log10,
- * lt_pow_half, lt_cos, lt_sin, lt_sincos (sin, cos) of lt_libm.h. */
+ * lt_pow_half, lt_cos, lt_sin, lt_sincos (sin, cos), lt_atan of lt_libm.h. */
 __global__ void k_test_leaf(int kind, const double* in, double* out, int n) {
   using namespace ltd;
   libm_tables_load<LM_EXP | LM_LOG | LM_POW | LM_SINCOS>();
@@ -1650,16 +1650,17 @@ __global__ void k_test_leaf(int kind, const double* in, double* out, int n) {
     out[2 * (size_t)i] = exp_core(in[i]);
     out[2 * (size_t)i + 1] = lt_exp(in[i]);
   } else if (kind == 6) {
-    double* o = out + 7 * (size_t)i;
+    double* o = out + 8 * (size_t)i;
     const double x = in[i];
     o[0] = lt_log(x); o[1] = lt_log10(x); o[2] = lt_pow_half(x);
     o[3] = lt_cos(x); o[4] = lt_sin(x);
     lt_sincos(x, &o[5], &o[6]);
+    o[7] = lt_atan_g(x);
   }
 }
 int lt_test_leaf(int32_t kind, const double* in, int32_t n, int32_t in_per_item, double* out, int32_t out_per_item) {
   if (!in || !out || n < 0 || kind < 1 || kind > 6) return LT_ERR_ARG;
-  const int expect_in[7] = {0, 7, 10, 1, 16, 1, 1}, expect_out[7] = {0, 1, 1, 3, 37, 2, 7};
+  const int expect_in[7] = {0, 7, 10, 1, 16, 1, 1}, expect_out[7] = {0, 1, 1, 3, 37, 2, 8};
   if (in_per_item != expect_in[kind] || out_per_item != expect_out[kind]) return LT_ERR_ARG;
   double *di = nullptr, *dout = nullptr;
   const size_t bi = (size_t)n * in_per_item * 8, bo = (size_t)n * out_per_item * 8;

@@ -86,7 +86,7 @@ __global__ void k_output(const StepParams P, double Earth_Radius, int Spherical,
     lat = y * RCF / Earth_Radius + latmin;
   } else {
     lon = x / Earth_Radius * RCF;
-    lat = 2.0 * RCF * (atan(exp_core_g(y / Earth_Radius)) - P.PI / 4.0);
+    lat = 2.0 * RCF * (lt_atan_g(exp_core_g(y / Earth_Radius)) - P.PI / 4.0);
   }
   int status = P.P_behave[i];
   if (P.dead[i]) status = -1;

@@ -1,4 +1,4 @@
-// lt_libm.h -- exp, log, log10, pow(x, 0.5), sin, cos and sincos as the CPU run of LTRANS gets them.
+// lt_libm.h -- exp, log, log10, pow(x, 0.5), sin, cos, sincos and atan as the CPU run of LTRANS gets them.
 //
 // The reference calls the host libm for these, and its results branch on them: SIGS' Newton
 // iteration stops or falls into a cycle (-> SigErr -> the whole profile is read with linint) on the
@@ -18,6 +18,8 @@
 //   lt_sincos           the same algorithm compiled without FMA: a C or Fortran compiler of the GCC
 //                       family merges cos(a) and sin(a) of one argument into one sincos call, which
 //                       glibc provides in a single, non-FMA build
+//   lt_atan             the table-driven atan of the same library, FMA variant (13.5 KB table, always
+//                       read from global memory: behaviour 7's heading and y2lat only)
 // Tables: lt_exp_table.h (generated from its definition) and lt_libm_tables.h.  On the device they
 // are copied to LDS by the kernels that evaluate the functions (libm_tables_load<MASK>()); on the
 // host (tests only: the same source compiled with gcc) they are static arrays.
@@ -49,6 +51,8 @@ __device__ const ExpPair g_exp_tab[128] __attribute__((aligned(16))) = LT_EXP_TA
 __device__ const LogPair g_log_tab[128] __attribute__((aligned(16))) = LT_LOG_TAB_INIT;
 __device__ const PowLog g_pow_tab[128] = LT_POW_TAB_INIT;
 __device__ const double g_sincos_tab[440] __attribute__((aligned(16))) = LT_SINCOS_TAB_INIT;
+__device__ const double g_atan_tab[241][7] = LT_ATAN_TAB_INIT;
+#define LT_ATAN_TAB g_atan_tab
 __shared__ ExpPair s_exp_tab[128];
 __shared__ LogPair s_log_tab[128];
 __shared__ PowLog s_pow_tab[128];
@@ -73,6 +77,8 @@ static const struct ExpPair lt_h_exp_tab[128] = LT_EXP_TABLE_INIT;
 static const struct LogPair lt_h_log_tab[128] = LT_LOG_TAB_INIT;
 static const struct PowLog lt_h_pow_tab[128] = LT_POW_TAB_INIT;
 static const double lt_h_sincos_tab[440] = LT_SINCOS_TAB_INIT;
+static const double lt_h_atan_tab[241][7] = LT_ATAN_TAB_INIT;
+#define LT_ATAN_TAB lt_h_atan_tab
 #endif
 
 #if defined(__HIPCC__)

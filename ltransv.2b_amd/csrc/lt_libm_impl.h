@@ -353,3 +353,65 @@ LT_LM void LT_LM_NAME(lt_sincos)(double x, double* sinx, double* cosx) {
   *sinx = sin(x);
   *cosx = cos(x);
 }
+
+// ------------------------------------------------------------------------------------ atan
+LT_LM double LT_LM_NAME(lt_atan)(double x) {
+  const double u = (x < 0) ? -x : x;
+  const double TWO52 = 0x1p52, TWO8 = 256.0;
+  if (!(u == u)) return x + x;
+  if (u < 1.0) {
+    if (u < LT_AT_B) {
+      if (u < LT_AT_A) return x;
+      const double v = x * x;
+      double yy = LT_LM_FMA(v, LT_AT_D13, LT_AT_D11);
+      yy = LT_LM_FMA(v, yy, LT_AT_D9);
+      yy = LT_LM_FMA(v, yy, LT_AT_D7);
+      yy = LT_LM_FMA(v, yy, LT_AT_D5);
+      yy = LT_LM_FMA(v, yy, LT_AT_D3);
+      return LT_LM_FMA(x * v, yy, x);
+    }
+    const int i = (int)(LT_LM_FMA(u, TWO8, TWO52) - TWO52) - 16;
+    const double z = u - LT_ATAN_TAB[i][0];
+    double yy = LT_LM_FMA(z, LT_ATAN_TAB[i][6], LT_ATAN_TAB[i][5]);
+    yy = LT_LM_FMA(z, yy, LT_ATAN_TAB[i][4]);
+    yy = LT_LM_FMA(z, yy, LT_ATAN_TAB[i][3]);
+    yy = LT_LM_FMA(z, yy, LT_ATAN_TAB[i][2]);
+    return copysign(fabs(LT_LM_FMA(yy, z, LT_ATAN_TAB[i][1])), x);
+  }
+  if (u < LT_AT_D) {
+    const double w = 1.0 / u;
+    const double t1 = w * u;
+    const double t2 = LT_LM_FMA(u, w, -t1);
+    const int i = (int)(LT_LM_FMA(w, TWO8, TWO52) - TWO52) - 16;
+    const double e = (1.0 - t1) - t2;
+    const double z = LT_LM_FMA(e, w, w - LT_ATAN_TAB[i][0]);
+    double yy = LT_LM_FMA(z, LT_ATAN_TAB[i][6], LT_ATAN_TAB[i][5]);
+    yy = LT_LM_FMA(z, yy, LT_ATAN_TAB[i][4]);
+    yy = LT_LM_FMA(z, yy, LT_ATAN_TAB[i][3]);
+    yy = LT_LM_FMA(z, yy, LT_ATAN_TAB[i][2]);
+    const double a = LT_LM_FMA(-z, yy, LT_SC_HP1);
+    return copysign(fabs((LT_SC_HP0 - LT_ATAN_TAB[i][1]) + a), x);
+  }
+  if (u < LT_AT_E) {
+    const double w = 1.0 / u;
+    const double v = w * w;
+    const double t1 = u * w;
+    double yy = LT_LM_FMA(v, LT_AT_D13, LT_AT_D11);
+    yy = LT_LM_FMA(v, yy, LT_AT_D9);
+    yy = LT_LM_FMA(v, yy, LT_AT_D7);
+    yy = LT_LM_FMA(v, yy, LT_AT_D5);
+    yy = LT_LM_FMA(v, yy, LT_AT_D3);
+    const double wv = w * v;
+    const double t2 = LT_LM_FMA(u, w, -t1);
+    yy = wv * yy;
+    const double e = (1.0 - t1) - t2;
+    const double t3 = LT_SC_HP0 - w;
+    const double ww = e * w;
+    const double cor = (LT_SC_HP0 > fabs(w)) ? ((LT_SC_HP0 - t3) - w) : (LT_SC_HP0 - (w + t3));
+    double r = cor + LT_SC_HP1;
+    r = r - ww;
+    r = r - yy;
+    return copysign(fabs(r + t3), x);
+  }
+  return (x > 0) ? LT_SC_HP0 : -LT_SC_HP0;
+}

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void k_post(const StepParams P) {
           } else {
             if (currentspeed > (double)0.05f) {
               const double Hdistance = P.Hswimspeed * P.idt;
-              const double theta = atan(cv / cu);
+              const double theta = lt_atan_g(cv / cu);
               double sth, cth;
               lt_sincos_g(theta, &sth, &cth);
               if (cu > 0.0) { XBehav = Hdistance * cth; YBehav = Hdistance * sth; }

@@ -14,6 +14,7 @@ static double (*volatile p_log)(double) = log;
 static double (*volatile p_log10)(double) = log10;
 static double (*volatile p_cos)(double) = cos;
 static double (*volatile p_sin)(double) = sin;
+static double (*volatile p_atan)(double) = atan;
 static double (*volatile p_pow)(double, double) = pow;
 static void (*volatile p_sincos)(double, double *, double *) = sincos;
 
@@ -66,5 +67,12 @@ int main(int argc, char **argv) {
     }
     printf("cos %ld %ld\nsin %ld %ld\nsincos %ld %ld\n", badc, n, bads, n, badsc, n);
   }
+  bad = 0;
+  for (long i = 0; i < n; i++) {
+    const double x = (i % 4 == 0) ? urand(-1.0, 1.0) : (i % 4 == 1) ? lrand(1e-13, 1e5) : (i % 4 == 2) ? urand(-20.0, 20.0)
+                   : -lrand(1e-3, 1e17);
+    if (!same(lt_atan(x), p_atan(x))) bad++;
+  }
+  printf("atan %ld %ld\n", bad, n);
   return 0;
 }

@@ -1,4 +1,4 @@
-"""The kernels' own exp / log / log10 / pow(x, 0.5) / sin / cos / sincos (ltransv.2b_amd/csrc/lt_libm.h)
+"""The kernels' own exp / log / log10 / pow(x, 0.5) / sin / cos / sincos / atan (ltransv.2b_amd/csrc/lt_libm.h)
 return the bits the host libm returns: the reference calls the host libm, and its results branch on the
 last bit of these functions.  tests/test_libm_host.py checks the same source
 compiled for the host; this is the device."""
@@ -23,9 +23,9 @@ def hip_lib():
 
 def _dev(lib, x):
     x = np.ascontiguousarray(x, dtype=np.float64)
-    out = np.empty((x.size, 7))
+    out = np.empty((x.size, 8))
     rc = lib.lt_test_leaf(C.c_int32(6), x.ctypes.data_as(C.c_void_p), C.c_int32(x.size), C.c_int32(1),
-                          out.ctypes.data_as(C.c_void_p), C.c_int32(7))
+                          out.ctypes.data_as(C.c_void_p), C.c_int32(8))
     assert rc == 0
     return out
 
@@ -85,3 +85,13 @@ def test_sin_cos_sincos(hip_lib):
         hs[i], hc[i] = s.value, c.value
     _check("sincos (sin)", o[:, 5], hs)
     _check("sincos (cos)", o[:, 6], hc)
+
+
+def test_atan(hip_lib):
+    rng = np.random.default_rng(23)
+    n = 300_000
+    x = np.concatenate([rng.uniform(-1.0, 1.0, n), rng.uniform(-20.0, 20.0, n),
+                        np.exp(rng.uniform(np.log(1e-13), np.log(1e17), n)) * rng.choice([-1.0, 1.0], n),
+                        np.array([0.0, -0.0, 1.0, -1.0, 0.0625, 16.0, 1e300, -1e300, np.inf, -np.inf])])
+    o = _dev(hip_lib, x)
+    _check("atan", o[:, 7], _host(math.atan, x))

@@ -1,5 +1,5 @@
 """ltransv.2b_amd/csrc/lt_libm.h compiled for the host (the same source the kernels compile) against
-the host libm: exp, log, log10, pow(x, 0.5), cos, sin, sincos must return identical bits on millions
+the host libm: exp, log, log10, pow(x, 0.5), cos, sin, sincos, atan must return identical bits on millions
 of arguments.  This pins the restatement (operation order, FMA placement, tables) without a GPU; the
 device build is checked by tests/test_gpu_libm.py."""
 import os
@@ -28,7 +28,7 @@ def test_lt_libm_matches_host_libm(tmp_path):
         if line.strip():
             name, bad, n = line.split()
             seen[name] = (int(bad), int(n))
-    assert set(seen) == {"exp", "log", "log10", "pow_half", "cos", "sin", "sincos"}
+    assert set(seen) == {"exp", "log", "log10", "pow_half", "cos", "sin", "sincos", "atan"}
     wrong = {k: v for k, v in seen.items() if v[0] != 0}
     if wrong:
         # every function wrong by a little = another libm; a single one wrong = a bug here
