@@ -59,11 +59,13 @@ def test_turbulence_skips_unreleased_particles(oracle):
     assert _next_draws(oracle, *hip["rng"]) == _next_draws(oracle, *ora["rng"])
 
 
-def test_turbulence_sharded_windows(oracle):
-    """two shards with lt_set_rng_window reproduce the unsharded run (multi-GPU path)."""
+@pytest.mark.parametrize("resort_every", [-1, 1])
+def test_turbulence_sharded_windows(oracle, resort_every):
+    """two shards with lt_set_rng_window reproduce the unsharded run (multi-GPU path), also when
+    every shard re-sorts its particles between steps"""
     from ltrans_amd import sharding
     from ltrans_amd.driver import LtransRun
-    case = cases.build_case("tiny_turb")
+    case = cases.build_case("tiny_turb", resort_every=resort_every)
     N = case["cfg"].numpar
     full = _run(case, {}, 1, 4)
     engines, runs = [], []
