@@ -834,11 +834,13 @@ LT_DEV void find_currents_ref(const StepParams& P, const double* lev, const Colu
 template <typename SlabT>
 __global__ __launch_bounds__(256) void k_rk_slow(const StepParams P) {
   __shared__ double lev[6 * LT_LEV_STRIDE];
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  // almost every block has nothing to redo: decide that before staging the tables
+  const bool mine = (n < P.numpar) && ((P.ws_i[n] & FL_SLOW) != 0);
+  if (!__syncthreads_or(mine ? 1 : 0)) return;
   for (int i = threadIdx.x; i < 6 * LT_LEV_STRIDE; i += blockDim.x) lev[i] = P.lev[i];
   exp_table_load();
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= P.numpar) return;
-  if (!(P.ws_i[n] & FL_SLOW)) return;
+  if (!mine) return;
   const size_t N = (size_t)P.numpar;
   double* wsd = P.ws_d + n;
   const double X = P.par[(size_t)pX * N + n], Y = P.par[(size_t)pY * N + n];
