@@ -49,8 +49,8 @@ extern "C" {
 #define LT_ERR_ARG           -1  /* NULL / out-of-range argument                   */
 #define LT_ERR_ABI           -2  /* struct_size / abi_version mismatch             */
 #define LT_ERR_STATE         -3  /* call order: grid / slabs / particles missing   */
-#define LT_ERR_UNSUPPORTED   -4  /* namelist option outside the implemented path:
-                                    FreeSlip, SaltTempOn, Behavior other than 0 / 6  */
+#define LT_ERR_UNSUPPORTED   -4  /* namelist value outside the reference's own range
+                                    (Behavior not in 0..7)                          */
 #define LT_ERR_DEVICE        -5  /* HIP runtime error (see lt_last_error)          */
 #define LT_ERR_SLAB_NOT_F32  -6  /* slab_storage = F32 but a value is not a float  */
 #define LT_ERR_NOMEM         -7
@@ -121,7 +121,8 @@ typedef struct lt_config {
   int32_t ErrorFlag;          /* 0 stop, 1 return to previous, 2 kill, 3 set out       */
   int32_t SaltTempOn;         /* P_Salt / P_Temp at the particle (LTRANS.f90:1062-1076) */
   int32_t TrackCollisions;
-  int32_t FreeSlip;           /* unsupported (must be 0)                               */
+  int32_t FreeSlip;           /* free-slip substitution at land nodes (hydrodynamic_module.f90:1934-1994,
+                                 2329-2520); needs the masks in lt_grid                   */
   /* build-specific (not in LTRANS.data) */
   int32_t slab_storage;       /* LT_SLAB_F32 / LT_SLAB_F64                             */
   int32_t device;             /* HIP device ordinal, -1 = current device               */
@@ -139,7 +140,7 @@ typedef struct lt_grid {
   const double  *vx, *vy;        /* (v_nodes)                                       */
   const double  *depth;          /* (rho_nodes) positive down    :38,116            */
   const double  *rho_angle;      /* (rho_nodes)                  :58,123            */
-  const int32_t *rho_mask, *u_mask, *v_mask; /* may be NULL (FreeSlip only)         */
+  const int32_t *rho_mask, *u_mask, *v_mask; /* FreeSlip and lt_slab_prefetch; else may be NULL */
   const int32_t *RE, *UE, *VE;   /* (4,elements) node ids        :49,117-119        */
   const int32_t *r_Adjacent;     /* (rho_elements,10) self first, 0-terminated :54  */
   const int32_t *u_Adjacent;     /* (u_elements,10)                                 */

@@ -90,6 +90,10 @@ struct StepParams {
   double swimstart, swimfast, sink;
   // behaviours 1-5, 7 and SaltTempOn (behavior_module.f90:181-551, LTRANS.f90:1062-1076)
   int dt, SaltTempOn;
+  // free slip (hydrodynamic_module.f90:1934-1994, 2329-2520): per element, bit k = node k+1 is water;
+  // fsVU: per U element, v_mask at the U element's node ids (the reference's v-grid diagonal cases)
+  int FreeSlip;
+  const unsigned char *fsR, *fsU, *fsV, *fsVU;
   double Sgradient, Hswimspeed, Swimdepth, twistart, twiend, daylength, Em, Kd, thresh;
   const void *S, *T;                 // salinity / temperature slabs [rho node][us][LT_SLOTS]
   double *timer, *P_Sprev, *P_zprev, *P_Salt, *P_Temp;

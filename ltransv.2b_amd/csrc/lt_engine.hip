@@ -47,7 +47,7 @@ struct lt_engine {
   // grid
   bool have_grid = false, have_bounds = false, have_habitat = false, have_particles = false;
   int rho_nodes = 0, u_nodes = 0, v_nodes = 0, rho_elements = 0, u_elements = 0, v_elements = 0;
-  DevBuf rnode, unode, vnode, RE, UE, VE, rAdj, uAdj, vAdj, lev;
+  DevBuf rnode, unode, vnode, RE, UE, VE, rAdj, uAdj, vAdj, lev, fsR, fsU, fsV, fsVU;
   // slabs
   DevBuf U, V, W, Kh, zeta, S, T, staging, flags;
   bool slab_set[4] = {false, false, false, false};
@@ -268,6 +268,9 @@ void fill_params(lt_engine* e, StepParams& P) {
   P.rank = (const int*)e->rank.p; P.orig = (const int*)e->orig.p;
   P.vt_x = (double*)e->vt_x.p; P.vt_y = (double*)e->vt_y.p; P.vt_yp = (double*)e->vt_yp.p; P.vt_sig = (double*)e->vt_sig.p;
   P.ele_ok = (unsigned char*)e->ele_ok.p;
+  P.FreeSlip = c.FreeSlip ? 1 : 0;
+  P.fsR = (const unsigned char*)e->fsR.p; P.fsU = (const unsigned char*)e->fsU.p;
+  P.fsV = (const unsigned char*)e->fsV.p; P.fsVU = (const unsigned char*)e->fsVU.p;
   P.block_active = (unsigned int*)e->block_active.p;
   P.ws_d = (double*)e->ws_d.p;
   P.ws_i = (int*)e->ws_i.p;
@@ -662,7 +665,6 @@ int lt_create(const lt_config* cfg, lt_engine** out) {
   if (cfg->numpar < 0 || cfg->us < 5 || cfg->ws != cfg->us + 1 || cfg->ws > LT_LEV_STRIDE ||
       cfg->idt <= 0 || cfg->Vtransform < 1 || cfg->Vtransform > 3)
     return LT_ERR_ARG;
-  if (cfg->FreeSlip) return LT_ERR_UNSUPPORTED;
   if (cfg->Behavior < 0 || cfg->Behavior > 7) return LT_ERR_UNSUPPORTED;
   if (cfg->slab_storage != LT_SLAB_F32 && cfg->slab_storage != LT_SLAB_F64) return LT_ERR_ARG;
   lt_engine* e = new (std::nothrow) lt_engine();
@@ -719,7 +721,7 @@ int lt_destroy(lt_engine* e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   DevBuf* bufs[] = {&e->rnode, &e->unode, &e->vnode, &e->RE, &e->UE, &e->VE, &e->rAdj, &e->uAdj,
-                    &e->vAdj, &e->lev, &e->U, &e->V, &e->W, &e->Kh, &e->zeta, &e->staging, &e->stage_rom, &e->rmask, &e->umask, &e->vmask,
+                    &e->vAdj, &e->lev, &e->fsR, &e->fsU, &e->fsV, &e->fsVU, &e->U, &e->V, &e->W, &e->Kh, &e->zeta, &e->staging, &e->stage_rom, &e->rmask, &e->umask, &e->vmask,
                     &e->flags, &e->bnd, &e->land, &e->bx, &e->by, &e->hx, &e->hy, &e->hid,
                     &e->seg_ptr, &e->seg_ids, &e->pm_ptr, &e->pm_ids, &e->pi_ptr, &e->pi_ids,
                     &e->polys, &e->holes, &e->polyspecs, &e->holespecs, &e->maxbdis, &e->maxhdis,
@@ -824,6 +826,34 @@ int lt_set_grid(lt_engine* e, const lt_grid* g) {
   HIPCHK(e, hipMemsetAsync(e->Kh.p, 0, e->Kh.bytes, e->stream));
   HIPCHK(e, hipMemsetAsync(e->zeta.p, 0, e->zeta.bytes, e->stream));
   e->have_masks = g->rho_mask && g->u_mask && g->v_mask;
+  if (e->cfg.FreeSlip) {
+    // the masks of every element's nodes, as the free-slip substitution reads them
+    // (hydrodynamic_module.f90:1934-1994, 2329-2520): bit k = node k+1 is water
+    if (!e->have_masks) return fail(e, LT_ERR_ARG, "lt_set_grid: FreeSlip needs rho_mask, u_mask, v_mask");
+    auto codes = [](const int32_t* E, int ne, const int32_t* mask, int nmask) {
+      std::vector<unsigned char> c((size_t)ne);
+      for (int i = 0; i < ne; i++) {
+        unsigned m = 0;
+        for (int k = 0; k < 4; k++) {
+          const int id = E[(size_t)i * 4 + k];
+          // (v_mask indexed with a U node id beyond its end -- the reference reads past the array -- counts as water)
+          const int w = (id >= 1 && id <= nmask) ? (mask[id - 1] != 0) : 1;
+          m |= (unsigned)w << k;
+        }
+        c[(size_t)i] = (unsigned char)m;
+      }
+      return c;
+    };
+    const auto cr = codes(g->RE, g->rho_elements, g->rho_mask, g->rho_nodes);
+    const auto cu = codes(g->UE, g->u_elements, g->u_mask, g->u_nodes);
+    const auto cv = codes(g->VE, g->v_elements, g->v_mask, g->v_nodes);
+    const auto cvu = codes(g->UE, g->u_elements, g->v_mask, g->v_nodes);
+    TRY(upload(e, e->fsR, cr.data(), cr.size()));
+    TRY(upload(e, e->fsU, cu.data(), cu.size()));
+    TRY(upload(e, e->fsV, cv.data(), cv.size()));
+    TRY(upload(e, e->fsVU, cvu.data(), cvu.size()));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+  }
   if (e->have_masks) {  // m_r, m_u, m_v of updateHydro's mask multiply (lt_slab_prefetch, masked = 0)
     TRY(upload(e, e->rmask, g->rho_mask, (size_t)g->rho_nodes * 4));
     TRY(upload(e, e->umask, g->u_mask, (size_t)g->u_nodes * 4));

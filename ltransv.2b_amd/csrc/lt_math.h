@@ -876,6 +876,39 @@ LT_DEV QuadWeights quad_weights(double xp, double yp, const double (&x)[4], cons
   return w;
 }
 
+// The free-slip substitution of getInterp (hydrodynamic_module.f90:1934-1994) and interp (:2329-2520):
+// values on land nodes of the element are replaced by values of its water nodes before the
+// interpolation.  m: bit k = node k+1 is water.  kind 0: rho grid.  kind 1: interp's u-grid branch,
+// which tests umasksum.EQ.1 where "one land node" is meant (:2408).  kind 2: interp's v-grid branch,
+// whose two diagonal cases read v_mask at the U element's node ids (:2500-2503; d: those four masks).
+LT_DEV void freeslip_sub(int kind, unsigned m, unsigned d, double& v1, double& v2, double& v3, double& v4) {
+  m &= 15u;
+  if (m == 15u) return;
+  const int sum = __popc(m);
+  const bool l1 = !(m & 1u), l2 = !(m & 2u), l3 = !(m & 4u), l4 = !(m & 8u);
+  if (sum == ((kind == 1) ? 1 : 3)) {
+    if (l1) v1 = 0.5 * (v2 + v4);
+    else if (l2) v2 = 0.5 * (v1 + v3);
+    else if (l3) v3 = 0.5 * (v2 + v4);
+    else if (l4) v4 = 0.5 * (v1 + v3);
+  } else if (sum == 2) {
+    if (l1 && l2) { v1 = v4; v2 = v3; }
+    else if (l2 && l3) { v2 = v1; v3 = v4; }
+    else if (l3 && l4) { v3 = v2; v4 = v1; }
+    else if (l4 && l1) { v4 = v3; v1 = v2; }
+    else {
+      const unsigned a = (kind == 2) ? (d & 15u) : m;
+      if (!(a & 1u) && !(a & 4u)) { v1 = v4; v3 = v2; }
+      else if (!(a & 8u) && !(a & 2u)) { v4 = v1; v2 = v3; }
+    }
+  } else if (sum == 1 && kind != 1) {
+    if (m & 1u) { v2 = v1; v3 = v1; v4 = v1; }
+    else if (m & 2u) { v1 = v2; v3 = v2; v4 = v2; }
+    else if (m & 4u) { v1 = v3; v2 = v3; v4 = v3; }
+    else { v1 = v4; v2 = v4; v3 = v4; }
+  }
+}
+
 // interp() value formula, hydrodynamic_module.f90:2530-2561
 // apply_interp for values whose node order was already rotated to (3,4,1,2) when the weights
 // are those of the second triangle (regime 2): both triangle forms are v1+(v2-v1)t+(v3-v1)u

@@ -464,8 +464,14 @@ __global__ __launch_bounds__(256) void k_pre(const StepParams P) {
                 r4 = P.rnode[rn.w - 1];
         double qx[4] = {r1.x, r2.x, r3.x, r4.x}, qy[4] = {r1.y, r2.y, r3.y, r4.y};
         const QuadWeights w0 = quad_weights(X, Y, qx, qy);
-        const double P_depth = -1.0 * apply_getinterp(w0, r1.depth, r2.depth, r3.depth, r4.depth);
-        const double P_angle = apply_getinterp(w0, r1.angle, r2.angle, r3.angle, r4.angle);
+        // (free slip: the values on the element's land nodes are replaced first, :1934-1994)
+        const unsigned fsm = P.FreeSlip ? P.fsR[er - 1] : 15u;
+        auto gi = [&](double a, double b, double c, double d) -> double {
+          if (fsm != 15u) freeslip_sub(0, fsm, 15u, a, b, c, d);
+          return apply_getinterp(w0, a, b, c, d);
+        };
+        const double P_depth = -1.0 * gi(r1.depth, r2.depth, r3.depth, r4.depth);
+        const double P_angle = gi(r1.angle, r2.angle, r3.angle, r4.angle);
         using Z4 = typename SlabTraits<SlabT>::zeta4;
         const Z4* zt = (const Z4*)P.zeta;
         Z4 z1 = zt[rn.x - 1], z2 = zt[rn.y - 1], z3 = zt[rn.z - 1], z4 = zt[rn.w - 1];
@@ -473,9 +479,9 @@ __global__ __launch_bounds__(256) void k_pre(const StepParams P) {
           return (double)((s == 0) ? v.x : (s == 1) ? v.y : (s == 2) ? v.z : v.w);
         };
         double zeta[3], Pz[3];
-        zeta[0] = apply_getinterp(w0, pick(z1, P.tb), pick(z2, P.tb), pick(z3, P.tb), pick(z4, P.tb));
-        zeta[1] = apply_getinterp(w0, pick(z1, P.tc), pick(z2, P.tc), pick(z3, P.tc), pick(z4, P.tc));
-        zeta[2] = apply_getinterp(w0, pick(z1, P.tf), pick(z2, P.tf), pick(z3, P.tf), pick(z4, P.tf));
+        zeta[0] = gi(pick(z1, P.tb), pick(z2, P.tb), pick(z3, P.tb), pick(z4, P.tb));
+        zeta[1] = gi(pick(z1, P.tc), pick(z2, P.tc), pick(z3, P.tc), pick(z4, P.tc));
+        zeta[2] = gi(pick(z1, P.tf), pick(z2, P.tf), pick(z3, P.tf), pick(z4, P.tf));
         // vertical clamps :900-922
         if (Z < P_depth) {
           Z = P_depth + (double)0.001f;
@@ -518,7 +524,7 @@ __global__ __launch_bounds__(256) void k_pre(const StepParams P) {
 // transcription (used once or twice per particle-step, only with behaviours 4,5,7 / SaltTempOn)
 template <typename SlabT>
 LT_DEV double wcts_itpi_rho(const StepParams& P, const double* lev, const Column& C, int4 rn,
-                            const QuadWeights& w, const SlabT* F, int deplvl) {
+                            const QuadWeights& w, const SlabT* F, int deplvl, unsigned fsm) {
   double Pv[3];
 #pragma unroll 1
   for (int s = 0; s < 3; s++) {
@@ -527,8 +533,10 @@ LT_DEV double wcts_itpi_rho(const StepParams& P, const double* lev, const Column
 #pragma unroll
     for (int l = 0; l < 4; l++) {
       az[l] = level_z(lev, deplvl + l, C.zeta[s], C.h, P.hc, P.Vtransform);
-      av[l] = apply_interp(w, fld(F, rn.x, P.us, deplvl + l, ps), fld(F, rn.y, P.us, deplvl + l, ps),
-                           fld(F, rn.z, P.us, deplvl + l, ps), fld(F, rn.w, P.us, deplvl + l, ps));
+      double f1 = fld(F, rn.x, P.us, deplvl + l, ps), f2 = fld(F, rn.y, P.us, deplvl + l, ps);
+      double f3 = fld(F, rn.z, P.us, deplvl + l, ps), f4 = fld(F, rn.w, P.us, deplvl + l, ps);
+      if (fsm != 15u) freeslip_sub(0, fsm, 15u, f1, f2, f3, f4);
+      av[l] = apply_interp(w, f1, f2, f3, f4);
     }
     int dummy = 0;
     Pv[s] = spline4_eval(az, av, C.Pz[s], dummy);
@@ -594,10 +602,11 @@ __global__ __launch_bounds__(256) void k_beh_pre(const StepParams P) {
     const Quad q = load_quad_rho(P.rnode, rn);
     const QuadWeights w = quad_weights(X, Y, q.x, q.y);
     const int deplvl = level_window(lev, P.us, Zpar, C.zeta[0], C.zeta[1], C.zeta[2], C.h, P.hc, P.Vtransform);
-    P_S = wcts_itpi_rho<SlabT>(P, lev, C, rn, w, (const SlabT*)P.S, deplvl);
+    const unsigned fsm = P.FreeSlip ? P.fsR[P.P_r_element[n] - 1] : 15u;
+    P_S = wcts_itpi_rho<SlabT>(P, lev, C, rn, w, (const SlabT*)P.S, deplvl, fsm);
     if (P.SaltTempOn) {
       P.P_Salt[n] = P_S;
-      P.P_Temp[n] = wcts_itpi_rho<SlabT>(P, lev, C, rn, w, (const SlabT*)P.T, deplvl);
+      P.P_Temp[n] = wcts_itpi_rho<SlabT>(P, lev, C, rn, w, (const SlabT*)P.T, deplvl, fsm);
     }
   }
   bool directed = false, random = false;
@@ -710,6 +719,13 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_rk(const StepParams P) 
   // the RK stages keep the elements of the start position (LTRANS.f90:990-1053)
   int er = 1, eu = 1, ev_ = 1;
   if (act) { er = P.P_r_element[n]; eu = P.P_u_element[n]; ev_ = P.P_v_element[n]; }
+  // free slip: an element with a land node has its values substituted before every interpolation
+  // (:1934-1994, 2329-2520); those few particles take the straight transcription of k_rk_slow
+  bool act_fast = act;
+  if (P.FreeSlip && act && ((P.fsR[er - 1] & P.fsU[eu - 1] & P.fsV[ev_ - 1]) != 15u)) {
+    slow = true;
+    act_fast = false;
+  }
 #pragma unroll 1
   for (int st = 0; st < 4; st++) {
     const int version = (st == 0) ? 1 : (st == 3) ? 3 : 2;
@@ -717,7 +733,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_rk(const StepParams P) 
     // (h made opaque per stage: otherwise every h-dependent level coefficient is hoisted
     // out of the stage loop and held in registers for the whole kernel)
     asm volatile("" : "+v"(h));
-    find_currents<SlabT, VT>(P, lev, ws, act, n, er, eu, ev_, h, dv, Xs, Ys, Zs, version, Uad, Vad, Wad, sigerr_count, slow);
+    find_currents<SlabT, VT>(P, lev, ws, act_fast, n, er, eu, ev_, h, dv, Xs, Ys, Zs, version, Uad, Vad, Wad, sigerr_count, slow);
     if (st == 0) { sumU = Uad; sumV = Vad; sumW = Wad; }
     else if (st == 3) { sumU = sumU + Uad; sumV = sumV + Vad; sumW = sumW + Wad; }
     else { sumU = sumU + 2.0 * Uad; sumV = sumV + 2.0 * Vad; sumW = sumW + 2.0 * Wad; }
@@ -777,7 +793,8 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_rk(const StepParams P) 
 template <typename SlabT>
 LT_DEV void find_currents_ref(const StepParams& P, const double* lev, const Column& C, int4 rn,
                               int4 un, int4 vn, double Xs, double Ys, double Zs, int version,
-                              double& Uad, double& Vad, double& Wad) {
+                              double& Uad, double& Vad, double& Wad, unsigned fsr, unsigned fsu,
+                              unsigned fsv, unsigned fsvu) {
   const double* rtab = lev;
   const double* wtab = lev + 3 * LT_LEV_STRIDE;
   const double ixv = (version == 1) ? P.ix0 : (version == 2) ? P.ix1 : P.ix2;
@@ -797,6 +814,8 @@ LT_DEV void find_currents_ref(const StepParams& P, const double* lev, const Colu
     const SlabT* F = (const SlabT*)((var == 0) ? P.U : (var == 1) ? P.V : P.W);
     const int L = (var == 2) ? P.ws : P.us;
     const double* tab = (var == 2) ? wtab : rtab;
+    const unsigned fsm = (var == 0) ? fsu : (var == 1) ? fsv : fsr;  // free slip: water nodes of the element
+    const int fskind = (var == 0) ? 1 : (var == 1) ? 2 : 0;
     double Pv0 = 0.0, Pv1 = 0.0, Pv2 = 0.0;
 #pragma unroll 1
     for (int s = 0; s < 3; s++) {
@@ -805,8 +824,10 @@ LT_DEV void find_currents_ref(const StepParams& P, const double* lev, const Colu
       double r;
       if (loglayer) {
         const int k = (var == 2) ? 2 : 1;
-        double val = apply_interp(w, fld(F, nd.x, L, k, ps), fld(F, nd.y, L, k, ps),
-                                  fld(F, nd.z, L, k, ps), fld(F, nd.w, L, k, ps));
+        double f1 = fld(F, nd.x, L, k, ps), f2 = fld(F, nd.y, L, k, ps), f3 = fld(F, nd.z, L, k, ps),
+               f4 = fld(F, nd.w, L, k, ps);
+        if (fsm != 15u) freeslip_sub(fskind, fsm, fsvu, f1, f2, f3, f4);
+        double val = apply_interp(w, f1, f2, f3, f4);
         const double z1s = (s == 0) ? C.z1[0] : (s == 1) ? C.z1[1] : C.z1[2];
         double ztop = (var == 2) ? level_z(wtab, 2, zeta, C.h, P.hc, P.Vtransform) : z1s;
         r = val * log10_call((Zs - C.wz1[0]) / P.z0) / log10_call((ztop - C.wz1[0]) / P.z0);
@@ -817,8 +838,10 @@ LT_DEV void find_currents_ref(const StepParams& P, const double* lev, const Colu
 #pragma unroll
         for (int l = 0; l < 4; l++) {
           az[l] = level_z(tab, k0 + l, zeta, C.h, P.hc, P.Vtransform);
-          av[l] = apply_interp(w, fld(F, nd.x, L, k0 + l, ps), fld(F, nd.y, L, k0 + l, ps),
-                               fld(F, nd.z, L, k0 + l, ps), fld(F, nd.w, L, k0 + l, ps));
+          double f1 = fld(F, nd.x, L, k0 + l, ps), f2 = fld(F, nd.y, L, k0 + l, ps),
+                 f3 = fld(F, nd.z, L, k0 + l, ps), f4 = fld(F, nd.w, L, k0 + l, ps);
+          if (fsm != 15u) freeslip_sub(fskind, fsm, fsvu, f1, f2, f3, f4);
+          av[l] = apply_interp(w, f1, f2, f3, f4);
         }
         int dummy = 0;
         r = spline4_eval(az, av, Pzs, dummy);
@@ -848,6 +871,11 @@ __global__ __launch_bounds__(256) void k_rk_slow(const StepParams P) {
   const double cosA = wsd[(size_t)WS_COSA * N], sinA = wsd[(size_t)WS_SINA * N];
   const int4 rn = P.RE[P.P_r_element[n] - 1], un = P.UE[P.P_u_element[n] - 1],
              vn = P.VE[P.P_v_element[n] - 1];
+  unsigned fsr = 15u, fsu = 15u, fsv = 15u, fsvu = 15u;
+  if (P.FreeSlip) {
+    fsr = P.fsR[P.P_r_element[n] - 1]; fsu = P.fsU[P.P_u_element[n] - 1];
+    fsv = P.fsV[P.P_v_element[n] - 1]; fsvu = P.fsVU[P.P_u_element[n] - 1];
+  }
   Column C;
   C.h = -1.0 * wsd[(size_t)WS_PDEPTH * N];
 #pragma unroll
@@ -872,7 +900,7 @@ __global__ __launch_bounds__(256) void k_rk_slow(const StepParams P) {
   for (int st = 0; st < 4; st++) {
     const int version = (st == 0) ? 1 : (st == 3) ? 3 : 2;
     double Uad, Vad, Wad;
-    find_currents_ref<SlabT>(P, lev, C, rn, un, vn, Xs, Ys, Zs, version, Uad, Vad, Wad);
+    find_currents_ref<SlabT>(P, lev, C, rn, un, vn, Xs, Ys, Zs, version, Uad, Vad, Wad, fsr, fsu, fsv, fsvu);
     if (st == 0) { sumU = Uad; sumV = Vad; sumW = Wad; }
     else if (st == 3) { sumU = sumU + Uad; sumV = sumV + Vad; sumW = sumW + Wad; }
     else { sumU = sumU + 2.0 * Uad; sumV = sumV + 2.0 * Vad; sumW = sumW + 2.0 * Wad; }

@@ -250,9 +250,12 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
   }
   const SlabT* K = (const SlabT*)P.Kh;
   const int pslot[3] = {P.tb, P.tc, P.tf};
+  const unsigned fsm = (P.FreeSlip && act) ? P.fsR[P.P_r_element[n] - 1] : 15u;  // free slip, :1934-1994
   auto KH = [&](int s, int i) -> double {  // Pwc_KH{b,c,f}(i) :102-108
-    return apply_getinterp(w0, fld(K, rn.x, ws, i, pslot[s]), fld(K, rn.y, ws, i, pslot[s]),
-                           fld(K, rn.z, ws, i, pslot[s]), fld(K, rn.w, ws, i, pslot[s]));
+    double f1 = fld(K, rn.x, ws, i, pslot[s]), f2 = fld(K, rn.y, ws, i, pslot[s]);
+    double f3 = fld(K, rn.z, ws, i, pslot[s]), f4 = fld(K, rn.w, ws, i, pslot[s]);
+    if (fsm != 15u) freeslip_sub(0, fsm, 15u, f1, f2, f3, f4);
+    return apply_getinterp(w0, f1, f2, f3, f4);
   };
   const Divisor dvh = prep_div((VT == 2) ? P.hc + h : h);  // every level depth divides by it
   auto WZ = [&](int s, int i) -> double {  // Pwc_wz{b,c,f}(i)
@@ -294,8 +297,9 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
     const double xj = NEWX(s, j);
     while (!(wzhi[s] > xj) && jlo[s] < ws - 1) {
       jlo[s] += 1;
-      const double kb = apply_getinterp(w0, (double)rawn[s][0], (double)rawn[s][1], (double)rawn[s][2],
-                                        (double)rawn[s][3]);
+      double g1 = (double)rawn[s][0], g2 = (double)rawn[s][1], g3 = (double)rawn[s][2], g4 = (double)rawn[s][3];
+      if (fsm != 15u) freeslip_sub(0, fsm, 15u, g1, g2, g3, g4);
+      const double kb = apply_getinterp(w0, g1, g2, g3, g4);
       LINE(s, wzhi[s], WZ(s, jlo[s] + 1), khhi[s], kb);
       if (jlo[s] + 2 <= ws) RAW(s, jlo[s] + 2);
     }

@@ -62,6 +62,14 @@ CASES = {
     # uniform drift into the west/south coast and the island: many reflections
     "tiny_reflect": dict(grid=(24, 16, 8), islands=[(10, 12, 6, 8)], numpar=768, near_land=0.6,
                          drift=(-0.35, -0.25), cfg=dict(Behavior=0)),
+    # free slip (hydrodynamic_module.f90:1934-1994, 2329-2520): many particles in elements with land nodes
+    "tiny_fs_adv": dict(grid=(24, 16, 8), islands=[(10, 12, 6, 8)], numpar=768, near_land=0.6,
+                        drift=(-0.2, -0.15), cfg=dict(Behavior=0, FreeSlip=1)),
+    "tiny_fs_turb": dict(grid=(24, 16, 8), islands=[(10, 12, 6, 8)], numpar=512, near_land=0.6,
+                         cfg=dict(Behavior=0, FreeSlip=1, HTurbOn=1, VTurbOn=1, ConstantHTurb=1.0)),
+    "tiny_fs_salt": dict(grid=(24, 16, 8), islands=[(10, 12, 6, 8)], numpar=512, near_land=0.6,
+                         cfg=dict(Behavior=5, FreeSlip=1, SaltTempOn=1, swimstart=0.0, swimslow=0.002, swimfast=0.004,
+                                  Sgradient=0.3)),
     # open eastern boundary, drift towards it: particles leave through open ocean
     "tiny_open": dict(grid=(24, 16, 8), islands=[], numpar=512, near_land=0.0, open_east=True,
                       drift=(0.45, 0.05), cfg=dict(Behavior=0, OpenOceanBoundary=1)),

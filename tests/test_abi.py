@@ -76,7 +76,7 @@ def test_create_rejects_bad_abi_and_unsupported_options():
     cfg = ltrans_amd.LtConfig(numpar=4, us=8, ws=9)
     cfg.struct_size = 12
     assert lib.lt_create(C.byref(cfg), C.byref(h)) == -2          # LT_ERR_ABI
-    for kw in (dict(FreeSlip=1), dict(Behavior=8), dict(Behavior=-1)):
+    for kw in (dict(Behavior=8), dict(Behavior=-1)):
         cfg = ltrans_amd.LtConfig(numpar=4, us=8, ws=9, **kw)
         assert lib.lt_create(C.byref(cfg), C.byref(h)) == -4      # LT_ERR_UNSUPPORTED
     cfg = ltrans_amd.LtConfig(numpar=4, us=8, ws=10)
