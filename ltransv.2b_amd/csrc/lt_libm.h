@@ -41,6 +41,11 @@ static inline double lt_lm_asd(unsigned long long u) { double d; memcpy(&d, &u, 
 #define LT_LM_ASD(u) lt_lm_asd(u)
 #endif
 #define LT_LM_FMA(a, b, c) __builtin_fma((a), (b), (c))
+// every fused operation of these functions is written as LT_LM_FMA; nothing else may be contracted
+// (the build passes -ffp-contract=off as well)
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
 
 struct ExpPair { unsigned long long tail, sbits; };
 struct LogPair { double invc, logc; };
