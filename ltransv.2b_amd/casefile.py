@@ -58,6 +58,10 @@ def read_result(path):
         for k in ("P_r_element", "P_u_element", "P_v_element", "err_code", "hitBottom", "hitLand",
                   "dead", "oob", "settle"):
             out[k] = np.frombuffer(fh.read(4 * n), dtype=np.int32)
+        rest = fh.read()
+        if len(rest) == 8 * 5 * n:      # the print-step columns of lt_get_output
+            cols = np.frombuffer(rest, dtype=np.float64).reshape(5, n)
+            out.update(lon=cols[0], lat=cols[1], z=cols[2], age=cols[3], status=cols[4])
     return out
 
 

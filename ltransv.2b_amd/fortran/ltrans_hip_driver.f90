@@ -12,7 +12,8 @@
 ! file written by ltrans_amd.casefile (the arrays are exactly those initGrid,
 ! createBounds, setEle_all and initHydro produce).
 !
-! usage: ltrans_hip_driver <LTRANS.data> <case.bin> <out.bin> [n_external] [max_internal]
+! usage: ltrans_hip_driver <LTRANS.data> <case.bin> <out.bin> [n_external] [max_internal] [pipeline]
+!   pipeline = 1: updateHydro through lt_slab_prefetch / lt_slab_commit instead of lt_set_slab
 program ltrans_hip_driver
   use iso_c_binding
   use ltrans_hip
@@ -79,13 +80,16 @@ program ltrans_hip_driver
   type(lt_slab) :: slab
   type(lt_step_stats) :: st
   double precision :: ex(3), ix(3)
-  integer :: p, it, stepT, stepIT, t_b, t_c, t_f, stepf, n, nargs, n_external, max_internal, ios
+  integer :: p, it, stepT, stepIT, t_b, t_c, t_f, stepf, n, nargs, n_external, max_internal, ios, pipeline
+  type(lt_rom_record) :: rec
+  type(lt_output) :: outp
+  real(c_double), allocatable, target :: o_lon(:), o_lat(:), o_z(:), o_age(:), o_status(:)
   integer(c_int64_t) :: total_errors
   character(len=512) :: nmlfile, casefile, outfile, arg
 
   nargs = command_argument_count()
   if (nargs < 3) then
-    write(*,*) 'usage: ltrans_hip_driver <LTRANS.data> <case.bin> <out.bin> [n_external] [max_internal]'
+    write(*,*) 'usage: ltrans_hip_driver <LTRANS.data> <case.bin> <out.bin> [n_external] [max_internal] [pipeline]'
     stop 2
   endif
   call get_command_argument(1, nmlfile)
@@ -93,6 +97,10 @@ program ltrans_hip_driver
   call get_command_argument(3, outfile)
   n_external = -1
   max_internal = -1
+  pipeline = 0
+  if (nargs >= 6) then
+    call get_command_argument(6, arg); read(arg, *) pipeline
+  endif
   if (nargs >= 4) then
     call get_command_argument(4, arg); read(arg, *) n_external
   endif
@@ -252,8 +260,20 @@ program ltrans_hip_driver
       stepf = stepf + 1
       if (stepf > nrec) stop 'case file holds too few history records'
       read(2) zeta, Uvel, Vvel, Wvel, Kh
-      call lt_check(lt_set_slab(eng, t_f, slab), eng, 'lt_set_slab')
-      call lt_check(lt_set_time_slots(eng, t_b, t_c, t_f), eng, 'lt_set_time_slots')
+      if (pipeline == 0) then
+        call lt_check(lt_set_slab(eng, t_f, slab), eng, 'lt_set_slab')
+        call lt_check(lt_set_time_slots(eng, t_b, t_c, t_f), eng, 'lt_set_time_slots')
+      else
+        ! the same record handed over as updateHydro holds it (rom*f arrays are node-numbered already;
+        ! the case file's values carry the mask multiply), copied and scattered asynchronously
+        rec%struct_size = int(c_sizeof(rec), c_int32_t); rec%dtype = LT_ROM_F64
+        rec%vi = vi; rec%uj = uj; rec%ui = vi - 1; rec%vj = uj - 1
+        rec%masked = 1; rec%has_window = 0; rec%window = 0
+        rec%romZ = c_loc(zeta); rec%romU = c_loc(Uvel); rec%romV = c_loc(Vvel); rec%romW = c_loc(Wvel)
+        rec%romKH = c_loc(Kh); rec%romS = c_null_ptr; rec%romT = c_null_ptr
+        call lt_check(lt_slab_prefetch(eng, rec), eng, 'lt_slab_prefetch')
+        call lt_check(lt_slab_commit(eng, t_b, t_c, t_f), eng, 'lt_slab_commit')
+      endif
     endif
     ex = 0.0
     ex(1) = (p-2)*dt
@@ -281,6 +301,13 @@ program ltrans_hip_driver
   open(3, file=trim(outfile), access='stream', form='unformatted', status='replace', action='write')
   write(3) int(numpar, c_int32_t), int(stepT*stepIT, c_int32_t)
   write(3) par, P_r_element, P_u_element, P_v_element, err_code, hitBottom, hitLand, dead, oob, settle
+  ! printOutput (LTRANS.f90:1617): lon / lat / depth / age / status converted on the device
+  allocate(o_lon(numpar), o_lat(numpar), o_z(numpar), o_age(numpar), o_status(numpar))
+  outp%lon = c_loc(o_lon); outp%lat = c_loc(o_lat); outp%z = c_loc(o_z); outp%age = c_loc(o_age)
+  outp%status = c_loc(o_status); outp%salt = c_null_ptr; outp%temp = c_null_ptr
+  outp%hitBottom = c_null_ptr; outp%hitLand = c_null_ptr
+  call lt_check(lt_get_output(eng, outp, 0_c_int32_t), eng, 'lt_get_output')
+  write(3) o_lon, o_lat, o_z, o_age, o_status
   close(3)
   write(*,'(A,I0,A,I0,A,I0)') 'ltrans_hip_driver: ', numpar, ' particles, ', stepT*stepIT, &
         ' internal steps, particle errors: ', total_errors

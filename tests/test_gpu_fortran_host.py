@@ -16,8 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DRIVER = os.path.join(ROOT, "ltransv.2b_amd", "fortran", "ltrans_hip_driver")
 
 
-@pytest.mark.parametrize("name", ["tiny_adv", "tiny_sink"])
-def test_fortran_driver_matches_python_driver(tmp_path, name):
+@pytest.mark.parametrize("name,pipeline", [("tiny_adv", 0), ("tiny_sink", 0), ("tiny_adv", 1)])
+def test_fortran_driver_matches_python_driver(tmp_path, name, pipeline):
     if not os.path.exists(DRIVER):
         pytest.skip("Fortran harness not built (flang absent at build time)")
     case = cases.build_case(name)
@@ -26,11 +26,19 @@ def test_fortran_driver_matches_python_driver(tmp_path, name):
     casefile.write_case(tmp_path / "case.bin", case["g"], case["geo"], case["bounds"], case["parts"],
                         [case["record"](r) for r in range(n_ext + 1)], case["cfg"].numpar)
     r = subprocess.run([DRIVER, str(tmp_path / "LTRANS.data"), str(tmp_path / "case.bin"),
-                        str(tmp_path / "out.bin"), str(n_ext), str(n_int)], capture_output=True, text=True)
+                        str(tmp_path / "out.bin"), str(n_ext), str(n_int), str(pipeline)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     f = casefile.read_result(tmp_path / "out.bin")
+    assert "setEle_all on the device: 0 particles located differently" in r.stdout
     p = cases.run_case(case, ltrans_amd.Engine, {}, n_external=n_ext, max_internal=n_int)
     assert f["steps"] == n_ext * n_int
     assert np.array_equal(f["par"], p["par"])
     for k in ("P_r_element", "P_u_element", "P_v_element", "err_code", "hitBottom", "hitLand"):
         assert np.array_equal(f[k], p[k]), k
+    # the print step through lt_get_output, from Fortran
+    e = cases.make_engine(cases.build_case(name), ltrans_amd.Engine, {})
+    e.set_particles(**{k: p[k] for k in ("par", "P_r_element", "P_u_element", "P_v_element", "dead", "oob", "settle")})
+    o = e.get_output()
+    e.close()
+    for k in ("lon", "lat", "z", "age", "status"):
+        assert np.array_equal(f[k], o[k]), k
