@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DRIVER = os.path.join(ROOT, "ltransv.2b_amd", "fortran", "ltrans_hip_driver")
 
 
-@pytest.mark.parametrize("name,pipeline", [("tiny_adv", 0), ("tiny_sink", 0), ("tiny_adv", 1)])
+@pytest.mark.parametrize("name,pipeline", [("tiny_adv", 0), ("tiny_sink", 0), ("tiny_adv", 1), ("tiny_turb", 1)])
 def test_fortran_driver_matches_python_driver(tmp_path, name, pipeline):
     if not os.path.exists(DRIVER):
         pytest.skip("Fortran harness not built (flang absent at build time)")
