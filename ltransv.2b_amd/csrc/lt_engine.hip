@@ -97,7 +97,7 @@ struct lt_engine {
   DevBuf counters;
   unsigned long long* h_counters = nullptr;  // pinned
   lt_step_stats stats{};
-  bool stats_valid = true;
+  bool stats_valid = true, counters_fetched = true;
   // optional HIP-event timing of the step kernel (lt_profile_*)
   bool prof_on = false;
   std::vector<hipEvent_t> prof_ev;  // pairs (start, stop)
@@ -1814,7 +1814,7 @@ static int step_prepare(lt_engine* e, const double* ex3, const double* ix3, int3
     }
     P.pns0 = ns[0]; P.pns1 = ns[1]; P.pns2 = ns[2];
   }
-  HIPCHK(e, hipMemsetAsync(e->counters.p, 0, CNT_COUNT * sizeof(unsigned long long), e->stream));
+  // (the step's counters are cleared by k_pre, the first kernel of the step)
   const unsigned blocks = (unsigned)((e->cfg.numpar + 255) / 256);
   const bool beh_draws = e->cfg.Behavior >= 1 && e->cfg.Behavior <= 5;
   const bool beh_pre = beh_draws || e->cfg.Behavior == 7 || e->cfg.SaltTempOn;
@@ -1932,9 +1932,17 @@ int lt_step(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32
     hipLaunchKernelGGL(k_post, dim3(blocks), dim3(256), 0, e->stream, P);
     HIPCHK(e, hipGetLastError());
   }
+  e->stats_valid = false;  // the step's counters stay on the device until somebody asks (fetch_counters)
+  e->counters_fetched = false;
+  return LT_OK;
+}
+
+static int fetch_counters(lt_engine* e) {
+  if (e->counters_fetched) return LT_OK;
   HIPCHK(e, hipMemcpyAsync(e->h_counters, e->counters.p, CNT_COUNT * sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, e->stream));
-  e->stats_valid = false;
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  e->counters_fetched = true;
   return LT_OK;
 }
 
@@ -1948,6 +1956,7 @@ int lt_sync(lt_engine* e) {
 int lt_get_stats(lt_engine* e, lt_step_stats* out) {
   if (!e || !out) return LT_ERR_ARG;
   TRY(lt_sync(e));
+  TRY(fetch_counters(e));
   if (!e->stats_valid) {
     e->stats.active = (int64_t)e->h_counters[CNT_ACTIVE];
     e->stats.errors = (int64_t)e->h_counters[CNT_ERRORS];
@@ -1971,6 +1980,7 @@ int lt_diag(unsigned long long* out) {
 int lt_get_counters(lt_engine* e, uint64_t* out8) {
   if (!e || !out8) return LT_ERR_ARG;
   TRY(lt_sync(e));
+  TRY(fetch_counters(e));
   for (int i = 0; i < CNT_COUNT; i++) out8[i] = e->h_counters[i];
   return LT_OK;
 }

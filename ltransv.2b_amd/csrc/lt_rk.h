@@ -409,6 +409,8 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
 template <typename SlabT>
 __global__ __launch_bounds__(256) void k_pre(const StepParams P) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  // the step's diagnostic counters (SigErr, errors, ...): later kernels of the step add to them
+  if (blockIdx.x == 0 && threadIdx.x < CNT_COUNT) P.counters[threadIdx.x] = 0ull;
   unsigned c_active = 0;
   if (n < P.numpar) {
     const size_t N = (size_t)P.numpar;
