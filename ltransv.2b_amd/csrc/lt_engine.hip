@@ -1608,7 +1608,8 @@ int lt_test_div(const double* a, const double* b, double* q_fast, double* q_ref,
  * prepared divisors and the hardware min / max (4), tensions through sigs_classify +
  * sigs_newton / sigs_secant (3), SigErr flag, HVAL at the 8 points through hval_interval_s (8;
  * the last 5 unused).  kind 5: x -> exp_core(x), lt_exp(x) (the host-libm-exact exp).  kind 6: x -> lt_log, lt_log10,
- * lt_pow_half, lt_cos, lt_sin, lt_sincos (sin, cos), lt_atan of lt_libm.h. */
+ * lt_pow_half, lt_cos, lt_sin, lt_sincos (sin, cos), lt_atan of lt_libm.h.  kind 7: the free-slip
+ * substitution, rows (kind, water mask m, v-grid diagonal mask d, v1..v4) -> v1..v4. */
 __global__ void k_test_leaf(int kind, const double* in, double* out, int n) {
   using namespace ltd;
   libm_tables_load<LM_EXP | LM_LOG | LM_POW | LM_SINCOS>();
@@ -1686,11 +1687,17 @@ __global__ void k_test_leaf(int kind, const double* in, double* out, int n) {
     o[3] = lt_cos(x); o[4] = lt_sin(x);
     lt_sincos(x, &o[5], &o[6]);
     o[7] = lt_atan_g(x);
+  } else if (kind == 7) {  // free-slip substitution: rows (kind, m, d, v1..v4) -> v1..v4
+    const double* r = in + (size_t)i * 7;
+    double v1 = r[3], v2 = r[4], v3 = r[5], v4 = r[6];
+    freeslip_sub((int)r[0], (unsigned)r[1], (unsigned)r[2], v1, v2, v3, v4);
+    double* o = out + 4 * (size_t)i;
+    o[0] = v1; o[1] = v2; o[2] = v3; o[3] = v4;
   }
 }
 int lt_test_leaf(int32_t kind, const double* in, int32_t n, int32_t in_per_item, double* out, int32_t out_per_item) {
-  if (!in || !out || n < 0 || kind < 1 || kind > 6) return LT_ERR_ARG;
-  const int expect_in[7] = {0, 7, 10, 1, 16, 1, 1}, expect_out[7] = {0, 1, 1, 3, 37, 2, 8};
+  if (!in || !out || n < 0 || kind < 1 || kind > 7) return LT_ERR_ARG;
+  const int expect_in[8] = {0, 7, 10, 1, 16, 1, 1, 7}, expect_out[8] = {0, 1, 1, 3, 37, 2, 8, 4};
   if (in_per_item != expect_in[kind] || out_per_item != expect_out[kind]) return LT_ERR_ARG;
   double *di = nullptr, *dout = nullptr;
   const size_t bi = (size_t)n * in_per_item * 8, bo = (size_t)n * out_per_item * 8;

@@ -102,6 +102,7 @@ void   lto_intersect_reflect(const lto_engine *e, double Xpos, double Ypos,
                              double nXpos, double nYpos, double *fix, double *fiy,
                              double *frx, double *fry, int *intersectf,
                              int *skipbound, int *isWater);
+void   lto_freeslip_sub(int kind, const int32_t *m, const int32_t *d, double *v);
 void   lto_mbounds(const lto_engine *e, double Ypos, double Xpos, int *inbounds);
 void   lto_ibounds(const lto_engine *e, int *in_island, double claty, double clongx,
                    double *island);

@@ -38,3 +38,22 @@ def test_freeslip_needs_masks():
     e = ltrans_amd.Engine(case["cfg"])
     with pytest.raises(ltrans_amd.LtError):
         e.set_grid(geo)
+
+
+def test_substitution_table_on_the_device():
+    """every mask combination of the three variants through the device function, against the
+    independent restatement of tests/test_freeslip.py"""
+    import ctypes as C
+    import test_freeslip as tf
+    lib = ltrans_amd.load_hip_library()
+    lib.lt_test_leaf.restype = C.c_int
+    v0 = [9.0, 2.0, 7.0, 4.0]
+    rows = np.array([[k, m, d] + v0 for k, m, d in tf._all_cases()], dtype=np.float64)
+    out = np.empty((rows.shape[0], 4))
+    rc = lib.lt_test_leaf(C.c_int32(7), rows.ctypes.data_as(C.c_void_p), C.c_int32(rows.shape[0]), C.c_int32(7),
+                          out.ctypes.data_as(C.c_void_p), C.c_int32(4))
+    assert rc == 0
+    for (k, m, d), got in zip(tf._all_cases(), out):
+        mm = [(m >> b) & 1 for b in range(4)]
+        dd = [(d >> b) & 1 for b in range(4)]
+        assert list(got) == tf._py_sub(k, mm, dd, v0), (k, mm, dd)
