@@ -15,7 +15,7 @@ _vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
 
 def build_oracle():
     srcs = [os.path.join(ORACLE_DIR, f) for f in
-            ("ltrans_oracle.c", "ltrans_oracle.h", "ltrans_oracle_engine.inc")]
+            ("ltrans_oracle.c", "ltrans_oracle.h", "ltrans_oracle_engine.inc", "ltrans_oracle_init.inc")]
     if (not os.path.exists(ORACLE_SO)
             or os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(s) for s in srcs)):
         subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "-B", "liboracle"])
