@@ -187,3 +187,22 @@ def test_locate_full_size(okw):
     print(f"lt_locate_particles: 1M particles x 3 grids in {dt * 1e3:.0f} ms (host side included); "
           f"lt_build_adjacency x 3 grids of ~130k elements in {dt_adj * 1e3:.0f} ms")
     assert dt < 5.0
+
+
+def test_adjacency_overflow_and_list_capacity(okw):
+    import ctypes as C
+    g, geo, hip, ora, hab = _engines(okw, 40, 32, [(10, 14, 6, 9)], settle=True,
+                                     polygons=[(6000.0, 5000.0, 2500.0, 12)])
+    E = np.ones((4, 11), dtype=np.int32, order="F")
+    E[1:, :] = np.arange(2, 35, dtype=np.int32).reshape(3, 11)
+    with pytest.raises(ltrans_amd.LtError):
+        hip.build_adjacency(E, 20)
+    # lt_get_polyspecs with id arrays that are too small: an error, and the ptr arrays tell the size
+    hip.create_polyspecs(hab)
+    ptr = np.zeros(geo["rho_elements"] + 1, dtype=np.int32)
+    ids = np.zeros(1, dtype=np.int32)
+    f = hip.lib.lt_get_polyspecs
+    f.restype = C.c_int
+    rc = f(hip._h, None, None, ptr.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p), C.c_int32(1), None, None,
+           C.c_int32(0))
+    assert rc == -1 and ptr[-1] > 1

@@ -133,3 +133,12 @@ def test_polyspecs_rejects_ids_outside_the_declared_range(okw):
     hab["maxpolyid"] = hab["minpolyid"]                        # three polygons, range of one
     with pytest.raises(ltrans_amd.LtError):
         e.create_polyspecs(hab)
+
+
+def test_adjacency_overflow_is_reported(okw):
+    """eleven elements that all share node 1: the reference would write r_Adjacent(i,11)"""
+    case, e = _grid_engine(okw)
+    E = np.ones((4, 11), dtype=np.int32, order="F")
+    E[1:, :] = np.arange(2, 35, dtype=np.int32).reshape(3, 11)
+    with pytest.raises(ltrans_amd.LtError):
+        e.build_adjacency(E, 20)
