@@ -347,10 +347,13 @@ def locate_elements(g, geo, x, y, kind):
     return ele
 
 
-def make_particles(g, geo, bounds, numpar, seed=12345, margin_cells=3, near_land=0.0, dob=0.0):
+def make_particles(g, geo, bounds, numpar, seed=12345, margin_cells=3, near_land=0.0, dob=0.0,
+                   coast_band=None):
     """Initial particles: uniform over the interior >= margin_cells from the rim
     and away from islands, depth uniform in (-0.9 h, -0.5 m); ``near_land`` =
-    fraction seeded 0.7-2.5 cells from the west/south rim to force reflections.
+    fraction seeded 0.7-2.5 cells from the west/south rim to force reflections
+    (``coast_band=(lo, hi)``: that fraction lo..hi metres inside the west/south
+    boundary line itself, so that a few steps of drift reach it).
     Returns the arrays of lt_set_particles (par(numpar,13), P_*_element) with the
     elements already located (setEle_all stand-in)."""
     rng = np.random.default_rng(seed)
@@ -371,8 +374,24 @@ def make_particles(g, geo, bounds, numpar, seed=12345, margin_cells=3, near_land
         ys = (mc + rng.uniform(0.0, 1.0, k) * (uj - 1 - 2 * mc)) * dy
         side = rng.integers(0, 2, k)
         band = 0.7 + 1.8 * rng.uniform(0.0, 1.0, k)
-        xs = np.where(near & (side == 0), band * dx, xs)
-        ys = np.where(near & (side == 1), band * dy, ys)
+        if coast_band is None:
+            xs = np.where(near & (side == 0), band * dx, xs)
+            ys = np.where(near & (side == 1), band * dy, ys)
+        else:
+            # the boundary runs through the u points (0, j) in the west and the v points (i, 0)
+            # in the south (create_bounds): interpolate it at the particle and step inside
+            off = coast_band[0] + (coast_band[1] - coast_band[0]) * rng.uniform(0.0, 1.0, k)
+            fj = np.clip(ys / dy, mc, uj - 1 - mc)
+            j0 = np.floor(fj).astype(int)
+            xb = g["x_u"][0, j0] + (fj - j0) * (g["x_u"][0, j0 + 1] - g["x_u"][0, j0])
+            yw = g["y_u"][0, j0] + (fj - j0) * (g["y_u"][0, j0 + 1] - g["y_u"][0, j0])
+            fi = np.clip(xs / dx, mc, vi - 1 - mc)
+            i0 = np.floor(fi).astype(int)
+            yb = g["y_v"][i0, 0] + (fi - i0) * (g["y_v"][i0 + 1, 0] - g["y_v"][i0, 0])
+            xsouth = g["x_v"][i0, 0] + (fi - i0) * (g["x_v"][i0 + 1, 0] - g["x_v"][i0, 0])
+            west, south = near & (side == 0), near & (side == 1)
+            xs = np.where(west, xb + off, np.where(south, xsouth, xs))
+            ys = np.where(west, yw, np.where(south, yb + off, ys))
         gi = np.clip(np.floor(xs / dx).astype(int), 0, vi - 2)
         gj = np.clip(np.floor(ys / dy).astype(int), 0, uj - 2)
         ok = np.ones(k, dtype=bool)

@@ -1,0 +1,151 @@
+"""BASELINE.json configs[3] and configs[4] on the device: the 1024x512x50 grid (us = 50,
+ws = 51), one rank's shard of the 10M particles (1.25M), RK4 + HTurb + VTurb, and the same
+with boundary reflection (islands, drift into the coast), behaviour 6 (constant sinking),
+settlement on habitat polygons and mortality.
+
+  * a 20k-particle sample of each configuration against the oracle, a few steps: integers
+    identical, (x,y,z) within BASELINE.json's 1e-6 (ver_turb_module.f90:65-95,120-194 --
+    the 4*ws = 204-knot profile; LTRANS.f90:934-951 -- the 50/51-level columns),
+  * a full 1.25M-particle shard through the size-independent properties the path offers:
+    two half shards with their windows of the serial random stream reproduce the single
+    engine bit for bit; the run is deterministic; the internal particle order is immaterial.
+"""
+import numpy as np
+import pytest
+
+import ltrans_amd
+import oracle_lib
+from ltrans_amd import roms_synth as rs
+from ltrans_amd.driver import LtransRun
+
+pytestmark = pytest.mark.gpu
+
+GRID = (1024, 512, 50)
+SHARD = 1_250_000
+SAMPLE = 20_000
+ISLANDS = [(200, 215, 100, 140), (600, 640, 300, 310), (820, 830, 80, 90), (400, 402, 400, 460)]
+CFG4 = dict(HTurbOn=1, VTurbOn=1, ConstantHTurb=1.0, Behavior=0, TrackCollisions=1)
+CFG5 = dict(HTurbOn=1, VTurbOn=1, ConstantHTurb=1.0, Behavior=6, sink=-0.0003, swimstart=0.0,
+            settlementon=1, holesExist=1, pediage=600.0, mortality=1, deadage=1500.0, TrackCollisions=1)
+
+
+@pytest.fixture(scope="module")
+def world():
+    vi, uj, us = GRID
+    g = rs.make_grid(vi, uj, us, islands=ISLANDS)
+    geo = rs.build_geometry(g)
+    bounds = rs.create_bounds(g)
+    # a fifth of the particles 5-120 m inside the west / south coast line, uniform drift into it
+    parts = rs.make_particles(g, geo, bounds, SHARD, seed=777, near_land=0.2, coast_band=(5.0, 120.0))
+    # particles of every age up to 1200 s (released before t = 0), so that mortality (deadage) and
+    # competency (pediage) are reached by a part of them during the few steps of a test
+    age = (np.arange(SHARD) % 1201).astype(np.float64)
+    parts["par"][:, 11] = age
+    parts["par"][:, 10] = -age - 1.0
+    Lx, Ly = (vi - 1) * g["dx"], (uj - 1) * g["dy"]
+    polys = [(Lx * fx, Ly * fy, 0.02 * Lx, 14) for fx in (0.15, 0.35, 0.55, 0.75) for fy in (0.2, 0.5, 0.8)]
+    polys += [(2500.0 + 9000.0 * k, 1800.0, 2400.0, 11) for k in range(12)]      # along the south coast
+    habitat = rs.make_habitat(g, geo, polys, [(0, Lx * 0.15, Ly * 0.2, 0.006 * Lx, 8)])
+    recs = {}
+
+    def record(r):
+        if r not in recs:
+            recs[r] = rs.make_record(g, geo, r, with_kh=True, drift=(-0.2, -0.15))
+        return recs[r]
+
+    return dict(g=g, geo=geo, bounds=bounds, parts=parts, record=record, us=us, habitat=habitat)
+
+
+def _engine(world, idx, cfgkw, kw=None):
+    n = idx.size
+    cfg = ltrans_amd.LtConfig(numpar=n, us=world["us"], ws=world["us"] + 1, dt=3600, idt=120, ErrorFlag=1, **cfgkw)
+    e = ltrans_amd.Engine(cfg, **(kw or {}))
+    e.set_grid(world["geo"])
+    e.set_bounds(world["bounds"])
+    if cfg.settlementon:
+        e.set_habitat(world["habitat"])
+    parts = {k: (v[idx] if v.ndim == 1 else np.asfortranarray(v[idx])) for k, v in world["parts"].items()}
+    e.set_particles(**parts, **rs.behaviour_state(cfg, n))
+    run = LtransRun(e, cfg.dt, cfg.idt, world["record"])
+    run.init_hydro()
+    return e, run
+
+
+def _steps(pairs, nsteps, fields=("par",)):
+    """all (engine, run) pairs together through the first nsteps internal steps of p = 2"""
+    p = 2
+    ex = pairs[0][1].external_times(p)
+    for it in range(1, nsteps + 1):
+        ix = pairs[0][1].internal_times(ex, it)
+        if len(pairs) > 1:
+            counts = [e.count_active(ix) for e, _ in pairs]
+            for r, (e, _) in enumerate(pairs):
+                e.set_rng_window(sum(counts[:r]), sum(counts))
+        for e, _ in pairs:
+            e.update_particles(ex, ix, p, it)
+    outs = [e.get_particles(fields=fields) for e, _ in pairs]
+    return {k: np.concatenate([o[k] for o in outs]) for k in fields}
+
+
+INT_FIELDS = ("P_r_element", "P_u_element", "P_v_element", "err_code", "hitBottom", "hitLand", "dead", "oob",
+              "settle", "endpoly")
+
+
+def _sample_vs_oracle(world, cfgkw, nsteps):
+    # the first SAMPLE particles hold the near-land fifth of the shard's first 100k: take a mix
+    idx = np.concatenate([np.arange(0, SAMPLE // 2), np.arange(600_000, 600_000 + SAMPLE // 2)])
+    fields = ("par",) + INT_FIELDS
+    hip = [_engine(world, idx, cfgkw)]
+    rh = _steps(hip, nsteps, fields)
+    sh = hip[0][0].stats()
+    hip[0][0].close()
+    orc = [_engine(world, idx, cfgkw, kw=dict(lib=oracle_lib.load_oracle(), prefix="lto_"))]
+    ro = _steps(orc, nsteps, fields)
+    so = orc[0][0].stats()
+    orc[0][0].close()
+    rel = np.max(np.abs(rh["par"][:, :3] - ro["par"][:, :3]) / np.maximum(np.abs(ro["par"][:, :3]), 1.0))
+    assert rel <= 1e-6, rel                                   # BASELINE.json's tolerance
+    for k in INT_FIELDS:
+        assert np.array_equal(rh[k], ro[k]), k
+    assert np.array_equal(rh["par"][:, 9:], ro["par"][:, 9:])      # status, DOB, age, lifespan
+    assert sh["active"] == so["active"]
+    return rh, ro, rel
+
+
+def test_config4_sample_against_the_oracle(world):
+    rh, ro, rel = _sample_vs_oracle(world, CFG4, 4)
+    print(f"config 4 sample: max rel err {rel:.3e}; land hits {int(ro['hitLand'].sum())}")
+    assert np.abs(ro["par"][:, 2] - ro["par"][:, 8]).max() > 0.0
+
+
+def test_config5_sample_against_the_oracle(world):
+    rh, ro, rel = _sample_vs_oracle(world, CFG5, 7)
+    print(f"config 5 sample: max rel err {rel:.3e}; land hits {int(ro['hitLand'].sum())}, bottom hits "
+          f"{int(ro['hitBottom'].sum())}, settled {int(ro['settle'].sum())}, dead {int(ro['dead'].sum())}")
+    # the case must exercise what configs[4] names: reflections, sinking to the bottom, settlement, mortality
+    assert int(ro["hitLand"].sum()) > 100
+    assert int(ro["settle"].sum()) > 0
+    assert int(ro["dead"].sum()) > 100
+
+
+@pytest.mark.parametrize("cfgkw", [CFG4, CFG5], ids=["config4", "config5"])
+def test_full_shard_properties(world, cfgkw, monkeypatch):
+    idx = np.arange(SHARD)
+    fields = ("par",) + INT_FIELDS
+    one = [_engine(world, idx, cfgkw)]
+    ref = _steps(one, 3, fields)
+    one[0][0].close()
+    assert np.isfinite(ref["par"]).all()
+    assert (ref["err_code"] == 0).mean() > 0.99
+    two = [_engine(world, idx[:SHARD // 2], cfgkw), _engine(world, idx[SHARD // 2:], cfgkw)]
+    got = _steps(two, 3, fields)
+    for e, _ in two:
+        e.close()
+    for k in fields:
+        assert np.array_equal(got[k], ref[k]), k
+    monkeypatch.setenv("LT_NO_SORT", "1")
+    c = [_engine(world, idx, cfgkw)]
+    rc = _steps(c, 3, fields)
+    c[0][0].close()
+    for k in fields:
+        assert np.array_equal(rc[k], ref[k]), k
