@@ -52,6 +52,14 @@ struct PipIndex {
 // Physical time slots of a slab: the three records in use (back / centre / forward) and a
 // spare one that the next record is prefetched into while steps run (lt_slab_prefetch).
 #define LT_SLOTS 4
+// Two slab layouts.  The velocity fields U, V, W, which k_rk gathers 4-level windows of, are
+// stored [node][slot][level] ("level-fastest", LT_LAYOUT_LEVFAST): the window of one time slot
+// is 16 contiguous bytes (fp32 storage) = ONE lane access of the vector L1, where the
+// [node][level][slot] layout of the other fields (Kh, salinity, temperature: read a whole
+// level of all slots at a time) needs four.  k_rk is bound by the number of lane accesses
+// the L1 can take per cycle, not by bytes.
+#define LT_LAYOUT_SLOTFAST 0
+#define LT_LAYOUT_LEVFAST 1
 
 struct StepParams {
   // ---- particle state (device copies of the reference's arrays)

@@ -348,12 +348,12 @@ void build_pip_index(const double* py, int npts, F same_poly, PipIndex& I, HostI
 }
 
 template <typename SlabT>
-int scatter_field(lt_engine* e, const double* src, DevBuf& dst, int nodes, int L, int slot) {
+int scatter_field(lt_engine* e, const double* src, DevBuf& dst, int nodes, int L, int slot, int levfast = 0) {
   size_t total = (size_t)nodes * L;
   HIPCHK(e, hipMemcpyAsync(e->staging.p, src, total * 8, hipMemcpyHostToDevice, e->stream));
   unsigned blocks = (unsigned)((total + 255) / 256);
   hipLaunchKernelGGL((k_slab_scatter<SlabT>), dim3(blocks), dim3(256), 0, e->stream,
-                     (const double*)e->staging.p, (SlabT*)dst.p, nodes, L, e->phys[slot], (int*)e->flags.p);
+                     (const double*)e->staging.p, (SlabT*)dst.p, nodes, L, e->phys[slot], (int*)e->flags.p, levfast);
   HIPCHK(e, hipGetLastError());
   return LT_OK;
 }
@@ -365,9 +365,9 @@ int set_slab_t(lt_engine* e, int slot, const lt_slab* s) {
   hipLaunchKernelGGL((k_zeta_scatter<SlabT>), dim3((e->rho_nodes + 255) / 256), dim3(256), 0, e->stream,
                      (const double*)e->staging.p, (SlabT*)e->zeta.p, e->rho_nodes, e->phys[slot], (int*)e->flags.p);
   HIPCHK(e, hipGetLastError());
-  TRY(scatter_field<SlabT>(e, s->Uvel, e->U, e->u_nodes, us, slot));
-  TRY(scatter_field<SlabT>(e, s->Vvel, e->V, e->v_nodes, us, slot));
-  TRY(scatter_field<SlabT>(e, s->Wvel, e->W, e->rho_nodes, ws, slot));
+  TRY(scatter_field<SlabT>(e, s->Uvel, e->U, e->u_nodes, us, slot, LT_LAYOUT_LEVFAST));
+  TRY(scatter_field<SlabT>(e, s->Vvel, e->V, e->v_nodes, us, slot, LT_LAYOUT_LEVFAST));
+  TRY(scatter_field<SlabT>(e, s->Wvel, e->W, e->rho_nodes, ws, slot, LT_LAYOUT_LEVFAST));
   if (s->Kh) TRY(scatter_field<SlabT>(e, s->Kh, e->Kh, e->rho_nodes, ws, slot));
   if (s->salt && e->S.p) TRY(scatter_field<SlabT>(e, s->salt, e->S, e->rho_nodes, us, slot));
   if (s->temp && e->T.p) TRY(scatter_field<SlabT>(e, s->temp, e->T, e->rho_nodes, us, slot));
@@ -576,10 +576,11 @@ int rng_ensure(lt_engine* e, uint64_t first, uint64_t last, hipStream_t gen_stre
 // then straight-line code in the hot loop)
 template <typename SlabT>
 void launch_rk_t(lt_engine* e, const StepParams& P, unsigned blocks) {
+  const unsigned rkblocks = (unsigned)(((size_t)blocks * 256 + LT_RK_BLOCK - 1) / LT_RK_BLOCK);
   switch (e->cfg.Vtransform) {
-    case 1: hipLaunchKernelGGL((k_rk<SlabT, 1, LT_RK_WAVES>), dim3(blocks), dim3(256), 0, e->stream, P); break;
-    case 2: hipLaunchKernelGGL((k_rk<SlabT, 2, LT_RK_WAVES>), dim3(blocks), dim3(256), 0, e->stream, P); break;
-    default: hipLaunchKernelGGL((k_rk<SlabT, 3, LT_RK_WAVES>), dim3(blocks), dim3(256), 0, e->stream, P); break;
+    case 1: hipLaunchKernelGGL((k_rk<SlabT, 1, LT_RK_WAVES>), dim3(rkblocks), dim3(LT_RK_BLOCK), 0, e->stream, P); break;
+    case 2: hipLaunchKernelGGL((k_rk<SlabT, 2, LT_RK_WAVES>), dim3(rkblocks), dim3(LT_RK_BLOCK), 0, e->stream, P); break;
+    default: hipLaunchKernelGGL((k_rk<SlabT, 3, LT_RK_WAVES>), dim3(rkblocks), dim3(LT_RK_BLOCK), 0, e->stream, P); break;
   }
 }
 // the first consumer of the step's random words waits for the generators
@@ -621,6 +622,7 @@ struct RomField {
   int n1, n2, L;           // array extents (i, j, level)
   int i1, i2, j1, j2;      // window, 1-based inclusive
   size_t off;              // element offset of the packed window in the staging buffers
+  int levfast;             // destination layout (lt_device.h)
   size_t count() const { return (size_t)(i2 - i1 + 1) * (j2 - j1 + 1) * L; }
 };
 
@@ -647,7 +649,7 @@ void launch_rom_scatter(lt_engine* e, const RomField& f, int pslot) {
   if (!total) return;
   hipLaunchKernelGGL((k_rom_scatter<SlabT, HostT>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      e->copy_stream, (const HostT*)e->stage_rom.p + f.off, (SlabT*)f.dst->p, f.mask, f.n1,
-                     f.i1, f.i2 - f.i1 + 1, f.j1, f.j2 - f.j1 + 1, f.L, pslot, (int*)e->flags.p + 1);
+                     f.i1, f.i2 - f.i1 + 1, f.j1, f.j2 - f.j1 + 1, f.L, pslot, (int*)e->flags.p + 1, f.levfast);
 }
 }  // namespace
 
@@ -1412,14 +1414,14 @@ int lt_slab_prefetch(lt_engine* e, const lt_rom_record* r) {
   const int* mu = r->masked ? nullptr : (const int*)e->umask.p;
   const int* mv = r->masked ? nullptr : (const int*)e->vmask.p;
   RomField f[7] = {
-      {r->romZ, mr, &e->zeta, r->vi, r->uj, 1, w[0], w[1], w[2], w[3], 0},
-      {r->romU, mu, &e->U, r->ui, r->uj, us, w[4], w[5], w[6], w[7], 0},
-      {r->romV, mv, &e->V, r->vi, r->vj, us, w[8], w[9], w[10], w[11], 0},
-      {r->romW, mr, &e->W, r->vi, r->uj, ws, w[0], w[1], w[2], w[3], 0}};
+      {r->romZ, mr, &e->zeta, r->vi, r->uj, 1, w[0], w[1], w[2], w[3], 0, 0},
+      {r->romU, mu, &e->U, r->ui, r->uj, us, w[4], w[5], w[6], w[7], 0, LT_LAYOUT_LEVFAST},
+      {r->romV, mv, &e->V, r->vi, r->vj, us, w[8], w[9], w[10], w[11], 0, LT_LAYOUT_LEVFAST},
+      {r->romW, mr, &e->W, r->vi, r->uj, ws, w[0], w[1], w[2], w[3], 0, LT_LAYOUT_LEVFAST}};
   int nf = 4;
-  if (r->romKH) f[nf++] = {r->romKH, mr, &e->Kh, r->vi, r->uj, ws, w[0], w[1], w[2], w[3], 0};
-  if (r->romS && e->S.p) f[nf++] = {r->romS, mr, &e->S, r->vi, r->uj, us, w[0], w[1], w[2], w[3], 0};
-  if (r->romT && e->T.p) f[nf++] = {r->romT, mr, &e->T, r->vi, r->uj, us, w[0], w[1], w[2], w[3], 0};
+  if (r->romKH) f[nf++] = {r->romKH, mr, &e->Kh, r->vi, r->uj, ws, w[0], w[1], w[2], w[3], 0, 0};
+  if (r->romS && e->S.p) f[nf++] = {r->romS, mr, &e->S, r->vi, r->uj, us, w[0], w[1], w[2], w[3], 0, 0};
+  if (r->romT && e->T.p) f[nf++] = {r->romT, mr, &e->T, r->vi, r->uj, us, w[0], w[1], w[2], w[3], 0, 0};
   size_t total = 0;
   for (int i = 0; i < nf; i++) { f[i].off = total; total += (f[i].count() + 3) & ~(size_t)3; }
   const size_t es = (r->dtype == LT_ROM_F32) ? 4 : 8;
@@ -1605,8 +1607,8 @@ int lt_test_div(const double* a, const double* b, double* q_fast, double* q_ref,
  * kind 4: a 4-knot spline, rows (x1..4, y1..4, t1..8) -> 37 values: the reference-shaped
  * YPC1 (4), SIGS tensions (3, zeros after a SigErr), SigErr count, HVAL and HPVAL at the 8
  * points (16); then what the fast path of k_rk computes for the same knots: YPC1 through the
- * prepared divisors and the hardware min / max (4), tensions through sigs_classify +
- * sigs_newton / sigs_secant (3), SigErr flag, HVAL at the 8 points through hval_interval_s (8;
+ * prepared divisors and the branch-free sign-flip forms on the hardware min / max (4), tensions through sigs_classify +
+ * sigs_newton / sigs_secant (3), SigErr flag, HVAL at the 8 points through hval_cubic_d (zero tension) or hval_interval_s (8;
  * the last 5 unused).  kind 5: x -> exp_core(x), lt_exp(x) (the host-libm-exact exp).  kind 6: x -> lt_log, lt_log10,
  * lt_pow_half, lt_cos, lt_sin, lt_sincos (sin, cos), lt_atan of lt_libm.h.  kind 7: the free-slip
  * substitution, rows (kind, water mask m, v-grid diagonal mask d, v1..v4) -> v1..v4. */
@@ -1654,10 +1656,10 @@ __global__ void k_test_leaf(int kind, const double* in, double* out, int n) {
     const Divisor d12 = prep_div(DX1 + DX2), d23 = prep_div(DX2 + DX3);
     double SL[3], YF[4], SF[3] = {0.0, 0.0, 0.0};
     SL[0] = div_prep(Y[1] - Y[0], d1); SL[1] = div_prep(Y[2] - Y[1], d2); SL[2] = div_prep(Y[3] - Y[2], d3);
-    YF[0] = ypc1_end_f(SL[0], SL[0] + div_prep(DX1 * (SL[0] - SL[1]), d12));
-    YF[1] = ypc1_mid_f(DX1, DX2, d12, SL[0], SL[1]);
-    YF[2] = ypc1_mid_f(DX2, DX3, d23, SL[1], SL[2]);
-    YF[3] = ypc1_end_f(SL[2], SL[2] + div_prep(DX3 * (SL[2] - SL[1]), d23));
+    YF[0] = ypc1_end_b(SL[0], SL[0] + div_prep(DX1 * (SL[0] - SL[1]), d12));
+    YF[1] = ypc1_mid_b(DX1, DX2, d12, SL[0], SL[1]);
+    YF[2] = ypc1_mid_b(DX2, DX3, d23, SL[1], SL[2]);
+    YF[3] = ypc1_end_b(SL[2], SL[2] + div_prep(DX3 * (SL[2] - SL[1]), d23));
     bool anyfail = false;
     for (int iv = 0; iv < 3; iv++) {
       double sg = 0.0, T = 0.0;
@@ -1675,7 +1677,9 @@ __global__ void k_test_leaf(int kind, const double* in, double* out, int n) {
       const double T = r[8 + k];
       int I = (T < X[1]) ? 1 : (T < X[2]) ? 2 : 3;
       if (T > X[3]) I = 3;
-      o[32 + k] = hval_interval_s(T, X[I - 1], X[I], Y[I - 1], YF[I - 1], YF[I], SL[I - 1], SF[I - 1]);
+      const Divisor dI = (I == 1) ? d1 : (I == 2) ? d2 : d3;
+      o[32 + k] = (SF[I - 1] == 0.0) ? hval_cubic_d(T, X[I - 1], dI, Y[I - 1], YF[I - 1], YF[I], SL[I - 1])
+                                     : hval_interval_s(T, X[I - 1], X[I], Y[I - 1], YF[I - 1], YF[I], SL[I - 1], SF[I - 1]);
     }
   } else if (kind == 5) {
     out[2 * (size_t)i] = exp_core(in[i]);

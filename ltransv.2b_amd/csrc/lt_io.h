@@ -3,11 +3,12 @@
 #pragma once
 
 // ------------------------------------------------------ slab upload
-// staging (node,level) column-major doubles -> [node][level][slot] SlabT.
+// staging (node,level) column-major doubles -> [node][level][slot] SlabT (or [node][slot][level]
+// when levfast: the velocity fields, lt_device.h).
 // flags[0] is set when a value is not exactly representable in SlabT.
 template <typename SlabT>
 __global__ void k_slab_scatter(const double* __restrict__ src, SlabT* __restrict__ dst, int nodes,
-                               int L, int slot, int* flags) {
+                               int L, int slot, int* flags, int levfast) {
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t total = (size_t)nodes * L;
   if (idx >= total) return;
@@ -18,7 +19,8 @@ __global__ void k_slab_scatter(const double* __restrict__ src, SlabT* __restrict
   double v = src[node + (size_t)nodes * k];
   SlabT c = (SlabT)v;
   if ((double)c != v && !(v != v)) atomicOr(flags, 1);
-  dst[idx * LT_SLOTS + slot] = c;
+  if (levfast) dst[(node * LT_SLOTS + slot) * L + k] = c;
+  else dst[idx * LT_SLOTS + slot] = c;
 }
 
 template <typename SlabT>
@@ -38,7 +40,7 @@ __global__ void k_zeta_scatter(const double* __restrict__ src, SlabT* __restrict
 template <typename SlabT, typename HostT>
 __global__ void k_rom_scatter(const HostT* __restrict__ src, SlabT* __restrict__ dst,
                               const int* __restrict__ mask, int n1, int i1, int wi, int j1, int wj, int L,
-                              int pslot, int* flags) {
+                              int pslot, int* flags, int levfast) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t cells = (size_t)wi * wj;
   if (idx >= cells * L) return;
@@ -51,7 +53,8 @@ __global__ void k_rom_scatter(const HostT* __restrict__ src, SlabT* __restrict__
   if (mask) v = v * (double)mask[node];
   const SlabT c = (SlabT)v;
   if ((double)c != v && !(v != v)) atomicOr(flags, 1);
-  dst[(node * L + k) * LT_SLOTS + pslot] = c;
+  if (levfast) dst[(node * LT_SLOTS + pslot) * L + k] = c;
+  else dst[(node * L + k) * LT_SLOTS + pslot] = c;
 }
 
 // xyz(numpar,3) column-major in the REFERENCE particle order <- par(:,1:3)

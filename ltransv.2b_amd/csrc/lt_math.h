@@ -70,8 +70,16 @@ LT_DEV Divisor prep_div(double b) {
 LT_DEV double div_prep(double a, const Divisor& d) {
   const double q = a * d.y;
   const double r = __builtin_fma(-d.b, q, a);
-  // a zero numerator: q already is the zero of the right sign, the correction would lose it
-  return (a == 0.0) ? q : __builtin_fma(r, d.y, q);
+  // The corrected quotient has the sign of q (the correction is a fraction of an ulp of q) unless the
+  // numerator is a zero: then q already is the zero of the right sign and the correction would lose
+  // it.  Taking the sign of q covers both (one v_bfi instead of a compare and two selects).
+  return __builtin_copysign(__builtin_fma(r, d.y, q), q);
+}
+// the divisor -b: every step of prep_div is odd in b, so this is prep_div(-b) bit for bit
+LT_DEV Divisor neg_div(const Divisor& d) {
+  Divisor n;
+  n.b = -d.b; n.y = -d.y;
+  return n;
 }
 
 // exp, log, log10, pow(x, 0.5), sin, cos, sincos evaluated exactly as the host libm of the CPU run
@@ -361,6 +369,43 @@ LT_DEV double ypc1_mid_f(double DXIM1, double DXI, const Divisor& dsum, double S
   if (ASIM1 > ASI) SGN = fsign1(SIM1);
   const double lim = 3.0 * __builtin_fmin(ASIM1, ASI);
   return (SGN > 0.0) ? __builtin_fmin(__builtin_fmax(0.0, T), lim) : __builtin_fmax(__builtin_fmin(0.0, T), -lim);
+}
+
+// The same formulas without a branch on the sign: with sb the sign bit of the slope that decides,
+//   SGN > 0:  min(max(0, T), lim)            SGN < 0:  max(min(0, T), -lim) = -min(max(0, -T), lim)
+// i.e. flip T by sb, clamp to [0, lim], flip back (a sign flip is exact).  The hardware min / max
+// are issued directly: the operands are results of arithmetic (never signalling NaNs), so the
+// canonicalising v_max x,x the compiler puts in front of llvm.minnum / maxnum is dead weight.
+// Same values as the forms above except, again, for the sign of a zero result.
+LT_DEV double vmax0(double x) {
+  double r;
+  asm("v_max_f64 %0, %1, 0" : "=v"(r) : "v"(x));
+  return r;
+}
+LT_DEV double vmin2(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+LT_DEV double vmax2(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+LT_DEV double flipsign(double x, unsigned sb) {  // sb = 0 or 0x80000000
+  return __hiloint2double(__double2hiint(x) ^ (int)sb, __double2loint(x));
+}
+LT_DEV double ypc1_end_b(double SI, double T) {
+  const unsigned sb = (unsigned)__double2hiint(SI) & 0x80000000u;
+  const double lim = 3.0 * fabs(SI);
+  return flipsign(vmin2(vmax0(flipsign(T, sb)), lim), sb);
+}
+LT_DEV double ypc1_mid_b(double DXIM1, double DXI, const Divisor& dsum, double SIM1, double SI) {
+  const double T = div_prep(DXIM1 * SI + DXI * SIM1, dsum);
+  const double ASIM1 = fabs(SIM1), ASI = fabs(SI);
+  const unsigned sb = (unsigned)((ASIM1 > ASI) ? __double2hiint(SIM1) : __double2hiint(SI)) & 0x80000000u;
+  const double lim = 3.0 * vmin2(ASIM1, ASI);
+  return flipsign(vmin2(vmax0(flipsign(T, sb)), lim), sb);
 }
 
 // YPC1 for N = 4.  ier != 0 when the abscissae are not strictly increasing.
@@ -746,6 +791,17 @@ LT_DEV double hval_interval_s(double T, double X1, double X2, double Y1, double 
   }
 }
 
+// The zero-tension (cubic) form of HVAL alone, with U / DX through the interval's prepared divisor:
+// what pass A of k_rk evaluates at once when the interval's tension is known to be zero.
+LT_DEV double hval_cubic_d(double T, double X1, const Divisor& dDX, double Y1, double YP1, double YP2, double S) {
+  const double U = T - X1;
+  const double B2 = div_prep(U, dDX);
+  const double B1 = 1.0 - B2;
+  const double D1 = S - YP1;
+  const double D2 = YP2 - S;
+  return Y1 + U * (YP1 + B2 * (D1 + B1 * (D1 - D2)));
+}
+
 // ------------------------------------------------------------ GRIDCELL_MOD
 // gridcell for ONE element (checkele form), gridcell_module.f90:26-257.
 // qx/qy: the four corners in element order.  Returns true when the reference
@@ -838,6 +894,32 @@ struct QuadWeights {
   int node_hit;  // regime 4: last matching node (1..4), as :2543-2546 overwrite in order
 };
 
+// the point is in neither triangle (hydrodynamic_module.f90:1718-1738 = :2540-2563): on a node, or
+// inverse-distance weights
+LT_DEV void quad_weights_outside(QuadWeights& w, double xp, double yp, double x1, double x2, double x3, double x4,
+                                 double y1, double y2, double y3, double y4) {
+  bool n1 = (xp == x1 && yp == y1), n2 = (xp == x2 && yp == y2), n3 = (xp == x3 && yp == y3),
+       n4 = (xp == x4 && yp == y4);
+  if (n1 || n2 || n3 || n4) {
+    w.regime = 4;
+    if (n1) { w.W1 = 1.0; w.node_hit = 1; }
+    if (n2) { w.W2 = 1.0; w.node_hit = 2; }
+    if (n3) { w.W3 = 1.0; w.node_hit = 3; }
+    if (n4) { w.W4 = 1.0; w.node_hit = 4; }
+  } else {
+    double Dis1 = 1. / (sqrt((x1 - xp) * (x1 - xp) + (y1 - yp) * (y1 - yp)));
+    double Dis2 = 1. / (sqrt((x2 - xp) * (x2 - xp) + (y2 - yp) * (y2 - yp)));
+    double Dis3 = 1. / (sqrt((x3 - xp) * (x3 - xp) + (y3 - yp) * (y3 - yp)));
+    double Dis4 = 1. / (sqrt((x4 - xp) * (x4 - xp) + (y4 - yp) * (y4 - yp)));
+    double TDis = Dis1 + Dis2 + Dis3 + Dis4;
+    w.W1 = Dis1 / TDis;
+    w.W2 = Dis2 / TDis;
+    w.W3 = Dis3 / TDis;
+    w.W4 = Dis4 / TDis;
+    w.regime = 3;
+  }
+}
+
 LT_DEV QuadWeights quad_weights(double xp, double yp, const double (&x)[4], const double (&y)[4]) {
   QuadWeights w;
   w.W1 = w.W2 = w.W3 = w.W4 = 0.0;
@@ -850,28 +932,32 @@ LT_DEV QuadWeights quad_weights(double xp, double yp, const double (&x)[4], cons
     w.t = ((xp - x3) * (y1 - y3) + (y3 - yp) * (x1 - x3)) / ((x4 - x3) * (y1 - y3) - (y4 - y3) * (x1 - x3));
     w.u = ((xp - x3) * (y4 - y3) + (y3 - yp) * (x4 - x3)) / ((x1 - x3) * (y4 - y3) - (y1 - y3) * (x4 - x3));
     w.regime = 2;
-    if (w.t < 0. || w.u < 0. || (w.t + w.u) > 1.0) {
-      bool n1 = (xp == x1 && yp == y1), n2 = (xp == x2 && yp == y2), n3 = (xp == x3 && yp == y3),
-           n4 = (xp == x4 && yp == y4);
-      if (n1 || n2 || n3 || n4) {
-        w.regime = 4;
-        if (n1) { w.W1 = 1.0; w.node_hit = 1; }
-        if (n2) { w.W2 = 1.0; w.node_hit = 2; }
-        if (n3) { w.W3 = 1.0; w.node_hit = 3; }
-        if (n4) { w.W4 = 1.0; w.node_hit = 4; }
-      } else {
-        double Dis1 = 1. / (sqrt((x1 - xp) * (x1 - xp) + (y1 - yp) * (y1 - yp)));
-        double Dis2 = 1. / (sqrt((x2 - xp) * (x2 - xp) + (y2 - yp) * (y2 - yp)));
-        double Dis3 = 1. / (sqrt((x3 - xp) * (x3 - xp) + (y3 - yp) * (y3 - yp)));
-        double Dis4 = 1. / (sqrt((x4 - xp) * (x4 - xp) + (y4 - yp) * (y4 - yp)));
-        double TDis = Dis1 + Dis2 + Dis3 + Dis4;
-        w.W1 = Dis1 / TDis;
-        w.W2 = Dis2 / TDis;
-        w.W3 = Dis3 / TDis;
-        w.W4 = Dis4 / TDis;
-        w.regime = 3;
-      }
-    }
+    if (w.t < 0. || w.u < 0. || (w.t + w.u) > 1.0) quad_weights_outside(w, xp, yp, x1, x2, x3, x4, y1, y2, y3, y4);
+  }
+  return w;
+}
+
+// quad_weights for k_rk's fast path: the two denominators of a triangle are (x2-x1)(y3-y1) - (y2-y1)(x3-x1)
+// and (x3-x1)(y2-y1) - (y3-y1)(x2-x1) -- the same two rounded products subtracted in the other order,
+// i.e. exactly the negative of each other -- so one refined reciprocal serves both quotients
+// (prep_div / div_prep: bit-identical to `/` for operands of ordinary magnitude, here metres).
+LT_DEV QuadWeights quad_weights_f(double xp, double yp, const double (&x)[4], const double (&y)[4]) {
+  QuadWeights w;
+  w.W1 = w.W2 = w.W3 = w.W4 = 0.0;
+  w.node_hit = 0;
+  const double x1 = x[0], x2 = x[1], x3 = x[2], x4 = x[3], y1 = y[0], y2 = y[1], y3 = y[2], y4 = y[3];
+  {
+    const Divisor d = prep_div((x2 - x1) * (y3 - y1) - (y2 - y1) * (x3 - x1));
+    w.t = div_prep((xp - x1) * (y3 - y1) + (y1 - yp) * (x3 - x1), d);
+    w.u = div_prep((xp - x1) * (y2 - y1) + (y1 - yp) * (x2 - x1), neg_div(d));
+  }
+  w.regime = 1;
+  if (w.t < 0. || w.u < 0. || (w.t + w.u) > 1.0) {
+    const Divisor d = prep_div((x4 - x3) * (y1 - y3) - (y4 - y3) * (x1 - x3));
+    w.t = div_prep((xp - x3) * (y1 - y3) + (y3 - yp) * (x1 - x3), d);
+    w.u = div_prep((xp - x3) * (y4 - y3) + (y3 - yp) * (x4 - x3), neg_div(d));
+    w.regime = 2;
+    if (w.t < 0. || w.u < 0. || (w.t + w.u) > 1.0) quad_weights_outside(w, xp, yp, x1, x2, x3, x4, y1, y2, y3, y4);
   }
   return w;
 }

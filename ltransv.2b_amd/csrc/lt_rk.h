@@ -12,6 +12,16 @@ template <typename SlabT>
 LT_DEV double fld(const SlabT* F, int node, int L, int k, int ps) {
   return (double)F[((size_t)(node - 1) * L + (k - 1)) * LT_SLOTS + ps];
 }
+// the velocity fields U, V, W: [node][slot][level] (lt_device.h)
+template <typename SlabT>
+LT_DEV double fldv(const SlabT* F, int node, int L, int k, int ps) {
+  return (double)F[((size_t)(node - 1) * LT_SLOTS + ps) * L + (k - 1)];
+}
+// four consecutive levels of one (node, slot) of a velocity field: one 16-byte access for
+// fp32 storage (aligned to the element only: a window starts at any level)
+template <typename SlabT> struct Win4;
+template <> struct __attribute__((packed, aligned(4))) Win4<float> { float v[4]; };
+template <> struct __attribute__((packed, aligned(8))) Win4<double> { double v[4]; };
 
 // the per-particle context that find_currents needs (registers)
 struct Column {
@@ -84,10 +94,16 @@ __device__ unsigned long long g_tim[8];
 #endif
 // One variable's three time slots are queued, then iterated (pass B), then combined in
 // time (pass C): at most 3 x 64 evaluation intervals and 6 x 64 check intervals.  The
-// evaluation queue holds the worst case; a check interval that finds the queue full
-// (never seen: ~1 % of them are candidates) sends its particle-step to k_rk_slow.
-#define LT_CHK_CAP 256
-#define LT_EV_CAP 192
+// evaluation queue takes two slots' worst case: before a slot that might not fit, what is
+// queued is iterated (an early pass B; ~23 % of the fits queue an evaluation interval).  A
+// check interval that finds its queue full (~1 % of them are candidates: 5 per variable
+// and wave) sends its particle-step to k_rk_slow.
+#ifndef LT_CHK_CAP
+#define LT_CHK_CAP 64
+#endif
+#ifndef LT_EV_CAP
+#define LT_EV_CAP 128
+#endif
 struct WaveScratch {
   double chk[LT_CHK_CAP][2];         // num, den of T = MAX(D1/D2, D2/D1)
   unsigned short chk_owner[LT_CHK_CAP];  // lane | slot9 << 6
@@ -192,16 +208,19 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
   ws.errmask[lane] = 0;
   TICK(0);
   // ---------------- pass A: fit without iterating, queue what must iterate.
+  // Written as straight-line code over ALL lanes: a lane without a spline to fit (not tracked,
+  // below z0, log layer) runs the same arithmetic on safe dummy operands (element 1, levels
+  // 1..4, h = 1) and is masked only where something leaves the lane -- the queues and the
+  // result.  Divergent branches cost this kernel more than the arithmetic they skip: every
+  // `if` on a lane condition is an exec-mask save / restore and a branch in the scalar stream
+  // of a wave that has one other wave to overlap with.
   // Memory latency is taken off the critical path by asking early: the node ids of the
   // NEXT variable's element, and the 4x4 field values + zeta + depth of the NEXT time
   // slot, are requested before the arithmetic of the current one (same registers: the
   // raw values are dead once the horizontal interpolation has produced Y).
-  int4 nd_next = make_int4(1, 1, 1, 1);
-  if (act && !zero) nd_next = P.UE[eu - 1];
+  int4 nd_next = P.UE[eu - 1];
   double zt = 0.0, pz = 0.0;
   SlabT raw[16];
-#pragma unroll
-  for (int i = 0; i < 16; i++) raw[i] = (SlabT)0;
 #pragma unroll 1
   for (int var = 0; var < 3; var++) {
     const int4 nd = nd_next;
@@ -210,142 +229,131 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
     const double* tab = (var == 2) ? wtab : rtab;
     const int k0 = (var == 2) ? iii : ii;
     int nchk = 0, nev = 0;  // wave-uniform task counts of this variable
-    // The 16 field values (4 nodes x 4 levels) of a time slot, its zeta and its depth are
-    // requested one slot ahead of their use, into the registers the previous slot's values
-    // just left (they are dead once the horizontal interpolation has produced Y).
-    const SlabT *b0 = F, *b1 = F, *b2 = F, *b3 = F;
-    if (spl) {
-      b0 = F + ((size_t)(nd.x - 1) * L + (k0 - 1)) * LT_SLOTS;
-      b1 = F + ((size_t)(nd.y - 1) * L + (k0 - 1)) * LT_SLOTS;
-      b2 = F + ((size_t)(nd.z - 1) * L + (k0 - 1)) * LT_SLOTS;
-      b3 = F + ((size_t)(nd.w - 1) * L + (k0 - 1)) * LT_SLOTS;
-    }
+    // The 16 field values (4 nodes x 4 levels) of a time slot -- one 16-byte access per node in
+    // the level-fastest layout -- its zeta and its depth are requested one slot ahead of their
+    // use, into the registers the previous slot's values just left.
+    const SlabT* b0 = F + (size_t)(nd.x - 1) * LT_SLOTS * L + (k0 - 1);
+    const SlabT* b1 = F + (size_t)(nd.y - 1) * LT_SLOTS * L + (k0 - 1);
+    const SlabT* b2 = F + (size_t)(nd.z - 1) * LT_SLOTS * L + (k0 - 1);
+    const SlabT* b3 = F + (size_t)(nd.w - 1) * LT_SLOTS * L + (k0 - 1);
     auto request = [&](int s) {
       const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
+      const int o = ps * L;
+      const Win4<SlabT> q0 = *(const Win4<SlabT>*)(b0 + o), q1 = *(const Win4<SlabT>*)(b1 + o);
+      const Win4<SlabT> q2 = *(const Win4<SlabT>*)(b2 + o), q3 = *(const Win4<SlabT>*)(b3 + o);
 #pragma unroll
       for (int l = 0; l < 4; l++) {
-        raw[4 * l + 0] = b0[LT_SLOTS * l + ps]; raw[4 * l + 1] = b1[LT_SLOTS * l + ps];
-        raw[4 * l + 2] = b2[LT_SLOTS * l + ps]; raw[4 * l + 3] = b3[LT_SLOTS * l + ps];
+        raw[4 * l + 0] = q0.v[l]; raw[4 * l + 1] = q1.v[l];
+        raw[4 * l + 2] = q2.v[l]; raw[4 * l + 3] = q3.v[l];
       }
       zt = wsd[(size_t)(WS_ZETA0 + s) * N];
       pz = wsd[(size_t)(WS_PZ0 + s) * N];
     };
-    if (spl) request(0);
-    QuadWeights w;
-    w.regime = 1; w.node_hit = 0; w.t = w.u = w.W1 = w.W2 = w.W3 = w.W4 = 0.0;
-    if (act && !zero) {
-      Quad q;
-      if (var == 2) q = load_quad_rho(P.rnode, nd);
-      else if (var == 0) q = load_quad_xy(P.unode, nd);
-      else q = load_quad_xy(P.vnode, nd);
-      if (var == 0) nd_next = P.VE[ev_ - 1];
-      else if (var == 1) nd_next = P.RE[er - 1];
-      w = quad_weights(Xs, Ys, q.x, q.y);
-    }
+    request(0);
+    Quad q;
+    if (var == 2) q = load_quad_rho(P.rnode, nd);
+    else if (var == 0) q = load_quad_xy(P.unode, nd);
+    else q = load_quad_xy(P.vnode, nd);
+    if (var == 0) nd_next = P.VE[ev_ - 1];
+    else if (var == 1) nd_next = P.RE[er - 1];
+    const QuadWeights w = quad_weights_f(Xs, Ys, q.x, q.y);
     // The second-triangle form (regime 2) is the first-triangle form on the nodes (3,4,1):
     // v3+(v4-v3)t+(v1-v3)u.  Instead of selecting the operands at every one of the 12
     // interpolations of this variable, the node order itself is rotated once: the values of
     // slot 0 (already requested) with one select each on the stored type, the base pointers
     // for the two later requests.  Regimes 3 / 4 (inverse distance, on a node) keep (1,2,3,4).
-    const bool rot = spl && (w.regime == 2);
-    if (rot) {
+    {
+      const bool rot = (w.regime == 2);
 #pragma unroll
       for (int l = 0; l < 4; l++) {
         const SlabT r0 = raw[4 * l + 0], r1 = raw[4 * l + 1];
-        raw[4 * l + 0] = raw[4 * l + 2]; raw[4 * l + 1] = raw[4 * l + 3];
-        raw[4 * l + 2] = r0; raw[4 * l + 3] = r1;
+        raw[4 * l + 0] = rot ? raw[4 * l + 2] : r0; raw[4 * l + 1] = rot ? raw[4 * l + 3] : r1;
+        raw[4 * l + 2] = rot ? r0 : raw[4 * l + 2]; raw[4 * l + 3] = rot ? r1 : raw[4 * l + 3];
       }
       const SlabT *t0 = b0, *t1 = b1;
-      b0 = b2; b1 = b3; b2 = t0; b3 = t1;
+      b0 = rot ? b2 : b0; b1 = rot ? b3 : b1; b2 = rot ? t0 : b2; b3 = rot ? t1 : b3;
     }
     TICK(1);
-    if (loglayer) {
-      // log layer :1493-1522: level 1 of u,v; level 2 of w
-      const int k = (var == 2) ? 2 : 1;
-      const LevCoef qt = level_coef_d((var == 2) ? wtab : rtab, k, h, P.hc, VT, dv);
-#pragma unroll
-      for (int s = 0; s < 3; s++) {
-        const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
-        const double zeta = wsd[(size_t)(WS_ZETA0 + s) * N];
-        double val = apply_interp(w, fld(F, nd.x, L, k, ps), fld(F, nd.y, L, k, ps),
-                                  fld(F, nd.z, L, k, ps), fld(F, nd.w, L, k, ps));
-        double ztop = level_at(qt, zeta, h, VT);
-        ws.res[s][lane] = val * log10_call((Zs - wzb1) / P.z0) / log10_call((ztop - wzb1) / P.z0);
-      }
-    }
     LevCoef lc[4];
-    if (spl) {
 #pragma unroll
-      for (int l = 0; l < 4; l++) lc[l] = level_coef_d(tab, k0 + l, h, P.hc, VT, dv);
-    }
+    for (int l = 0; l < 4; l++) lc[l] = level_coef_d(tab, k0 + l, h, P.hc, VT, dv);
 #pragma unroll 1
     for (int s = 0; s < 3; s++) {
       const int slot9 = var * 3 + s;
-      double YP[4], SL[3];
-      double x1 = 0.0, x2 = 0.0, y1 = 0.0, p1 = 0.0, p2 = 0.0, Sv = 0.0, Pzs = 0.0;
-      int I = 1;
-      bool ok = spl;
-      if (spl) {
-        const double zeta = zt;
-        Pzs = pz;
-        double X[4], Y[4];
+      if (nev + 64 > LT_EV_CAP) {  // wave-uniform: the next slot might not fit
+        run_tasks(ws, (nchk < LT_CHK_CAP) ? nchk : LT_CHK_CAP, nev, lane);
+        nchk = 0; nev = 0;
+      }
+      const double zeta = zt, Pzs = pz;
+      double X[4], Y[4];
+#pragma unroll
+      for (int l = 0; l < 4; l++) {
+        X[l] = level_at(lc[l], zeta, h, VT);
+        const double v1 = (double)raw[4 * l + 0], v2 = (double)raw[4 * l + 1], v3 = (double)raw[4 * l + 2];
+        Y[l] = v1 + (v2 - v1) * w.t + (v3 - v1) * w.u;
+      }
+      if (w.regime >= 3) {  // the stage position has left the start element (a few % of the lanes)
 #pragma unroll
         for (int l = 0; l < 4; l++) {
-          X[l] = level_at(lc[l], zeta, h, VT);
-          Y[l] = apply_interp_rot(w, (double)raw[4 * l + 0], (double)raw[4 * l + 1],
-                                  (double)raw[4 * l + 2], (double)raw[4 * l + 3]);
+          const double v1 = (double)raw[4 * l + 0], v2 = (double)raw[4 * l + 1], v3 = (double)raw[4 * l + 2],
+                       v4 = (double)raw[4 * l + 3];
+          if (w.regime == 3) Y[l] = w.W1 * v1 + w.W2 * v2 + w.W3 * v3 + w.W4 * v4;
+          else Y[l] = (w.node_hit == 1) ? v1 : (w.node_hit == 2) ? v2 : (w.node_hit == 3) ? v3 : v4;
         }
-        if (s < 2) request(s + 1);
-        const double DX1 = X[1] - X[0], DX2 = X[2] - X[1], DX3 = X[3] - X[2];
-        ok = (DX1 > 0.0) && (DX2 > 0.0) && (DX3 > 0.0);
-        if (!ok) degenerate |= (1u << slot9);
-        // YPC1 (tension_module.f90:852-977) with the chord slopes kept for SIGS/HVAL
-        // (seven quotients over five divisors: the reciprocals are prepared once)
-        const Divisor d1 = prep_div(DX1), d2 = prep_div(DX2), d3 = prep_div(DX3);
-        const Divisor d12 = prep_div(DX1 + DX2), d23 = prep_div(DX2 + DX3);
-        SL[0] = div_prep(Y[1] - Y[0], d1);
-        SL[1] = div_prep(Y[2] - Y[1], d2);
-        SL[2] = div_prep(Y[3] - Y[2], d3);
-        YP[0] = ypc1_end_f(SL[0], SL[0] + div_prep(DX1 * (SL[0] - SL[1]), d12));
-        YP[1] = ypc1_mid_f(DX1, DX2, d12, SL[0], SL[1]);
-        YP[2] = ypc1_mid_f(DX2, DX3, d23, SL[1], SL[2]);
-        YP[3] = ypc1_end_f(SL[2], SL[2] + div_prep(DX3 * (SL[2] - SL[1]), d23));
-        I = (Pzs < X[1]) ? 1 : (Pzs < X[2]) ? 2 : 3;
-        if (Pzs > X[3]) I = 3;
-        x1 = (I == 1) ? X[0] : (I == 2) ? X[1] : X[2];
-        x2 = (I == 1) ? X[1] : (I == 2) ? X[2] : X[3];
-        y1 = (I == 1) ? Y[0] : (I == 2) ? Y[1] : Y[2];
-        p1 = (I == 1) ? YP[0] : (I == 2) ? YP[1] : YP[2];
-        p2 = (I == 1) ? YP[1] : (I == 2) ? YP[2] : YP[3];
-        Sv = (I == 1) ? SL[0] : (I == 2) ? SL[1] : SL[2];
       }
+      if (s < 2) request(s + 1);
+      const double DX1 = X[1] - X[0], DX2 = X[2] - X[1], DX3 = X[3] - X[2];
+      const bool ok = spl && (DX1 > 0.0) && (DX2 > 0.0) && (DX3 > 0.0);
+      degenerate |= (spl && !ok) ? (1u << slot9) : 0u;
+      // YPC1 (tension_module.f90:852-977) with the chord slopes kept for SIGS/HVAL
+      // (seven quotients over five divisors: the reciprocals are prepared once)
+      const Divisor d1 = prep_div(DX1), d2 = prep_div(DX2), d3 = prep_div(DX3);
+      const Divisor d12 = prep_div(DX1 + DX2), d23 = prep_div(DX2 + DX3);
+      double YP[4], SL[3];
+      SL[0] = div_prep(Y[1] - Y[0], d1);
+      SL[1] = div_prep(Y[2] - Y[1], d2);
+      SL[2] = div_prep(Y[3] - Y[2], d3);
+      YP[0] = ypc1_end_b(SL[0], SL[0] + div_prep(DX1 * (SL[0] - SL[1]), d12));
+      YP[1] = ypc1_mid_b(DX1, DX2, d12, SL[0], SL[1]);
+      YP[2] = ypc1_mid_b(DX2, DX3, d23, SL[1], SL[2]);
+      YP[3] = ypc1_end_b(SL[2], SL[2] + div_prep(DX3 * (SL[2] - SL[1]), d23));
+      // the evaluation interval :1044-1053 (extrapolates with the end intervals)
+      // (for strictly increasing knots "T > X(4) -> interval 3" is implied; other windows are redone by k_rk_slow)
+      const bool i1 = (Pzs < X[1]);
+      const bool i2 = !i1 && (Pzs < X[2]);
+      const int I = i1 ? 1 : i2 ? 2 : 3;
+      const double x1 = i1 ? X[0] : i2 ? X[1] : X[2];
+      const double x2 = i1 ? X[1] : i2 ? X[2] : X[3];
+      const double y1 = i1 ? Y[0] : i2 ? Y[1] : Y[2];
+      const double p1 = i1 ? YP[0] : i2 ? YP[1] : YP[2];
+      const double p2 = i1 ? YP[1] : i2 ? YP[2] : YP[3];
+      const double Sv = i1 ? SL[0] : i2 ? SL[1] : SL[2];
+      Divisor dI;
+      dI.b = i1 ? d1.b : i2 ? d2.b : d3.b;
+      dI.y = i1 ? d1.y : i2 ? d2.y : d3.y;
       TICK(2);
       // SIGS (tension_module.f90:448-776), screened without divisions or loops.
       // Only the evaluation interval's tension is used by HVAL; the other two
       // matter only through SigErr, which only the convexity Newton iteration
       // can raise, so they are queued just when they are Newton candidates.
-      bool evdone = false;
+      const bool c0 = ok && sigs_candidate_test(SL[0], YP[0], YP[1]);
+      const bool c1 = ok && sigs_candidate_test(SL[1], YP[1], YP[2]);
+      const bool c2 = ok && sigs_candidate_test(SL[2], YP[2], YP[3]);
+      // the two non-evaluation intervals: I=1 -> (2,3), I=2 -> (1,3), I=3 -> (1,2)
+      const bool ca = i1 ? c1 : c0, cb = (I == 3) ? c1 : c2;
+      // the evaluation interval: done here when its tension is known to be ZERO (the cubic form);
+      // everything else (an iteration, or the rare known SBIG) goes to pass B
       double sigI = 0.0;
-      {
-        const bool c0 = ok && sigs_candidate_test(SL[0], YP[0], YP[1]);
-        const bool c1 = ok && sigs_candidate_test(SL[1], YP[1], YP[2]);
-        const bool c2 = ok && sigs_candidate_test(SL[2], YP[2], YP[3]);
-        // the two non-evaluation intervals: I=1 -> (2,3), I=2 -> (1,3), I=3 -> (1,2)
-        const bool ca = (I == 1) ? c1 : c0, cb = (I == 3) ? c1 : c2;
-        double na = 0.0, da = 0.0, nb = 0.0, db = 0.0;
-        if (ca) {  // ~1 % of the intervals: the operands of T = MAX(D1/D2, D2/D1)
+      const bool evknown = sigs_eval_known(Sv, p1, p2, sigI);
+      const bool neede = ok && !(evknown && sigI == 0.0);
+      const unsigned long long mc = __ballot(ca || cb), me = __ballot(neede);
+      const unsigned long long below = (1ull << lane) - 1ull;
+      if (mc) {  // ~1 % of the intervals are candidates: the operands of T = MAX(D1/D2, D2/D1)
+        const unsigned long long ma = __ballot(ca), mb = __ballot(cb);
+        if (ca) {
+          double na, da;
           if (I == 1) (void)sigs_candidate(SL[1], YP[1], YP[2], na, da);
           else (void)sigs_candidate(SL[0], YP[0], YP[1], na, da);
-        }
-        if (cb) {
-          if (I == 3) (void)sigs_candidate(SL[1], YP[1], YP[2], nb, db);
-          else (void)sigs_candidate(SL[2], YP[2], YP[3], nb, db);
-        }
-        if (ok) evdone = sigs_eval_known(Sv, p1, p2, sigI);
-        const bool neede = ok && !evdone;
-        const unsigned long long ma = __ballot(ca), mb = __ballot(cb), me = __ballot(neede);
-        const unsigned long long below = (1ull << lane) - 1ull;
-        if (ca) {
           const int idx = nchk + __popcll(ma & below);
           if (idx < LT_CHK_CAP) {
             ws.chk[idx][0] = na; ws.chk[idx][1] = da;
@@ -354,6 +362,9 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
         }
         nchk += __popcll(ma);
         if (cb) {
+          double nb, db;
+          if (I == 3) (void)sigs_candidate(SL[1], YP[1], YP[2], nb, db);
+          else (void)sigs_candidate(SL[2], YP[2], YP[3], nb, db);
           const int idx = nchk + __popcll(mb & below);
           if (idx < LT_CHK_CAP) {
             ws.chk[idx][0] = nb; ws.chk[idx][1] = db;
@@ -361,21 +372,37 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
           } else degenerate |= (1u << slot9);
         }
         nchk += __popcll(mb);
-        if (neede) {
-          const int idx = nev + __popcll(me & below);
-          double* e = ws.ev[idx];
-          e[0] = x1; e[1] = x2; e[2] = y1; e[3] = p1; e[4] = p2; e[5] = Sv; e[6] = Pzs;
-          ws.ev_owner[idx] = (unsigned short)(lane | (slot9 << 6));
-        }
-        nev += __popcll(me);
-#ifdef LT_RK_TIMING
-        { const unsigned long long mk = __ballot(evdone && sigI != 0.0);
-          if (lane == 0) { ws.tim[6] += __popcll(me); ws.tim[7] += __popcll(mk); } }
-#endif
       }
-      // HVAL now when the evaluation interval's tension is already known
-      if (evdone) ws.res[s][lane] = hval_interval_s(Pzs, x1, x2, y1, p1, p2, Sv, sigI);
+      if (neede) {
+        const int idx = nev + __popcll(me & below);
+        double* e = ws.ev[idx];
+        e[0] = x1; e[1] = x2; e[2] = y1; e[3] = p1; e[4] = p2; e[5] = Sv; e[6] = Pzs;
+        ws.ev_owner[idx] = (unsigned short)(lane | (slot9 << 6));
+      }
+      nev += __popcll(me);
+#ifdef LT_RK_TIMING
+      if (lane == 0) ws.tim[6] += __popcll(me);
+#endif
+      // HVAL of the zero-tension case, stored by every lane (pass B overwrites the queued ones,
+      // the log layer below the others that do not fit a spline)
+      ws.res[s][lane] = hval_cubic_d(Pzs, x1, dI, y1, p1, p2, Sv);
+      (void)x2;
       TICK(3);
+    }
+    if (loglayer) {
+      // log layer :1493-1522: level 1 of u,v; level 2 of w
+      const int k = (var == 2) ? 2 : 1;
+      const LevCoef qt = level_coef_d((var == 2) ? wtab : rtab, k, h, P.hc, VT, dv);
+      const QuadWeights wl = quad_weights(Xs, Ys, q.x, q.y);
+#pragma unroll
+      for (int s = 0; s < 3; s++) {
+        const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
+        const double zeta = wsd[(size_t)(WS_ZETA0 + s) * N];
+        double val = apply_interp(wl, fldv(F, nd.x, L, k, ps), fldv(F, nd.y, L, k, ps),
+                                  fldv(F, nd.z, L, k, ps), fldv(F, nd.w, L, k, ps));
+        double ztop = level_at(qt, zeta, h, VT);
+        ws.res[s][lane] = val * log10_call((Zs - wzb1) / P.z0) / log10_call((ztop - wzb1) / P.z0);
+      }
     }
     // ---------------- pass B: everything of this variable that iterates
     run_tasks(ws, (nchk < LT_CHK_CAP) ? nchk : LT_CHK_CAP, nev, lane);
@@ -692,10 +719,14 @@ __global__ __launch_bounds__(256) void k_beh_pre(const StepParams P) {
   P.ws_i[n] = fl;
 }
 
+#ifndef LT_RK_BLOCK
+#define LT_RK_BLOCK 256
+#endif
 template <typename SlabT, int VT, int WAVES_PER_SIMD>
-__global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_rk(const StepParams P) {
+__global__ __launch_bounds__(LT_RK_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES_PER_SIMD, WAVES_PER_SIMD)))
+void k_rk(const StepParams P) {
   __shared__ double lev[6 * LT_LEV_STRIDE];
-  __shared__ WaveScratch wsc[4];
+  __shared__ WaveScratch wsc[LT_RK_BLOCK / 64];
   for (int i = threadIdx.x; i < 6 * LT_LEV_STRIDE; i += blockDim.x) lev[i] = P.lev[i];
   exp_table_load();
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -826,8 +857,8 @@ LT_DEV void find_currents_ref(const StepParams& P, const double* lev, const Colu
       double r;
       if (loglayer) {
         const int k = (var == 2) ? 2 : 1;
-        double f1 = fld(F, nd.x, L, k, ps), f2 = fld(F, nd.y, L, k, ps), f3 = fld(F, nd.z, L, k, ps),
-               f4 = fld(F, nd.w, L, k, ps);
+        double f1 = fldv(F, nd.x, L, k, ps), f2 = fldv(F, nd.y, L, k, ps), f3 = fldv(F, nd.z, L, k, ps),
+               f4 = fldv(F, nd.w, L, k, ps);
         if (fsm != 15u) freeslip_sub(fskind, fsm, fsvu, f1, f2, f3, f4);
         double val = apply_interp(w, f1, f2, f3, f4);
         const double z1s = (s == 0) ? C.z1[0] : (s == 1) ? C.z1[1] : C.z1[2];
@@ -840,8 +871,8 @@ LT_DEV void find_currents_ref(const StepParams& P, const double* lev, const Colu
 #pragma unroll
         for (int l = 0; l < 4; l++) {
           az[l] = level_z(tab, k0 + l, zeta, C.h, P.hc, P.Vtransform);
-          double f1 = fld(F, nd.x, L, k0 + l, ps), f2 = fld(F, nd.y, L, k0 + l, ps),
-                 f3 = fld(F, nd.z, L, k0 + l, ps), f4 = fld(F, nd.w, L, k0 + l, ps);
+          double f1 = fldv(F, nd.x, L, k0 + l, ps), f2 = fldv(F, nd.y, L, k0 + l, ps),
+                 f3 = fldv(F, nd.z, L, k0 + l, ps), f4 = fldv(F, nd.w, L, k0 + l, ps);
           if (fsm != 15u) freeslip_sub(fskind, fsm, fsvu, f1, f2, f3, f4);
           av[l] = apply_interp(w, f1, f2, f3, f4);
         }
