@@ -1982,9 +1982,9 @@ int lt_get_stats(lt_engine* e, lt_step_stats* out) {
 #ifdef LT_RK_TIMING
 int lt_diag(unsigned long long* out) {
   hipDeviceSynchronize();
-  hipMemcpyFromSymbol(out, HIP_SYMBOL(ltd::g_tim), 64);
-  unsigned long long z[8] = {0};
-  hipMemcpyToSymbol(HIP_SYMBOL(ltd::g_tim), z, 64);
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(ltd::g_tim), 128);
+  unsigned long long z[16] = {0};
+  hipMemcpyToSymbol(HIP_SYMBOL(ltd::g_tim), z, 128);
   return 0;
 }
 #endif

@@ -609,7 +609,7 @@ LT_DEV bool sigs_candidate(double S, double S1, double S2, double& num, double& 
 LT_DEV bool sigs_candidate_test(double S, double S1, double S2) {
   const double D1 = S - S1, D2 = S2 - S;
   const double a = fabs(D1), b = fabs(D2);
-  return (D1 * D2 > 0.0) && (__builtin_fmax(a, b) > 2.0 * __builtin_fmin(a, b));
+  return (D1 * D2 > 0.0) & (__builtin_fmax(a, b) > 2.0 * __builtin_fmin(a, b));
 }
 
 // Screening of the EVALUATION interval: true = its tension factor is known
@@ -633,9 +633,23 @@ LT_DEV bool sigs_eval_known(double S, double S1, double S2, double& sigma) {
   return (D0 <= 0.0 || S * T0 >= 0.0);
 }
 
+// The same screening as one boolean expression without branches (every comparison is evaluated):
+// true = the evaluation interval's tension factor is known to be ZERO, the only case pass A of
+// k_rk evaluates at once.  (Known SBIG -- rare -- and everything that iterates go to pass B.)
+LT_DEV bool sigs_eval_zero(double S, double S1, double S2) {
+  const double D1 = S - S1, D2 = S2 - S, D1D2 = D1 * D2;
+  const bool inf_t = ((D1D2 == 0.0) & (S1 != S2)) | ((S == 0.0) & (S1 * S2 > 0.0));
+  const double a = fabs(D1), b = fabs(D2);
+  const bool conv_zero = (D1D2 == 0.0) | (__builtin_fmax(a, b) <= 2.0 * __builtin_fmin(a, b));
+  const double T0 = 3.0 * S - S1 - S2;
+  const double D0 = T0 * T0 - S1 * S2;
+  const bool nconv_zero = (S1 * S < 0.0) | (S2 * S < 0.0) | (D0 <= 0.0) | (S * T0 >= 0.0);
+  return !inf_t & ((D1D2 >= 0.0) ? conv_zero : nconv_zero);
+}
+
 // convexity Newton iteration, tension_module.f90:531-580.  Returns the tension
 // factor; failed = true when the iteration count exceeds 10000 (SigErr).
-LT_DEV double sigs_newton(double T, bool& failed) {
+LT_DEV double sigs_newton(double T, bool& failed, int* nit_out = nullptr) {
   const double SBIG = LT_SBIG, RTOL = LT_SIGS_RTOL, FTOL = 0.0;
   double TP1 = T + 1.0;
   double SIG = sqrt(10.0 * T - 20.0);
@@ -643,6 +657,7 @@ LT_DEV double sigs_newton(double T, bool& failed) {
   failed = false;
   NewtonCycle cyc(SIG);
   for (;;) {
+    if (nit_out) *nit_out = NIT + 1;
     double T1, FP;
     if (SIG <= .5) {
       double SINHM, COSHM, COSHMM;

@@ -81,7 +81,7 @@ LT_DEV double level_at(const LevCoef& q, double zeta, double h, int Vtransform) 
 #ifdef LT_RK_TIMING
 // development aid: wave time per section, accumulated in the wave's LDS scratch and
 // added to g_tim once at the end of the kernel
-__device__ unsigned long long g_tim[8];
+__device__ unsigned long long g_tim[16];
 #define TICK(slot) do { const unsigned long long t_ = __builtin_readcyclecounter(); if ((threadIdx.x & 63) == 0) ws.tim[slot] += t_ - tprev_; tprev_ = __builtin_readcyclecounter(); } while (0)
 #define TICK_INIT unsigned long long tprev_ = __builtin_readcyclecounter()
 #else
@@ -92,14 +92,16 @@ __device__ unsigned long long g_tim[8];
 #endif
 #define TICK_INIT do { } while (0)
 #endif
-// One variable's three time slots are queued, then iterated (pass B), then combined in
-// time (pass C): at most 3 x 64 evaluation intervals and 6 x 64 check intervals.  The
-// evaluation queue takes two slots' worst case: before a slot that might not fit, what is
-// queued is iterated (an early pass B; ~23 % of the fits queue an evaluation interval).  A
-// check interval that finds its queue full (~1 % of them are candidates: 5 per variable
-// and wave) sends its particle-step to k_rk_slow.
+// The nine (variable, slot) fits of a STAGE share the queues: whenever 64 evaluation intervals
+// are waiting (and the next slot might not fit) one full round of pass B takes the last 64;
+// what is left at the end of the stage goes with the check intervals into the last round(s).
+// ~23 % of the fits queue an evaluation interval, i.e. ~147 per stage and wave: two full
+// rounds and a partial one, where a pass B per variable ran 4 rounds at 57 % of the lanes.
+// A check interval that finds its queue full (~1 % of them are candidates: 15 per stage and
+// wave; the queue is emptied with every full round and whenever it is half full) sends its
+// particle-step to k_rk_slow.
 #ifndef LT_CHK_CAP
-#define LT_CHK_CAP 64
+#define LT_CHK_CAP 128
 #endif
 #ifndef LT_EV_CAP
 #define LT_EV_CAP 128
@@ -109,10 +111,10 @@ struct WaveScratch {
   unsigned short chk_owner[LT_CHK_CAP];  // lane | slot9 << 6
   double ev[LT_EV_CAP][7];           // x1,x2,y1,p1,p2,S,Pz
   unsigned short ev_owner[LT_EV_CAP];
-  double res[3][64];                 // H(P_z) per (slot, lane) of the current variable
+  double res[9][64];                 // H(P_z) per (variable * 3 + slot, lane) of the current stage
   unsigned int errmask[64];          // bit (variable*3+slot): SigErr / degenerate window
 #ifdef LT_RK_TIMING
-  unsigned long long tim[8];
+  unsigned long long tim[16];
 #endif
 };
 
@@ -120,13 +122,13 @@ struct WaveScratch {
 // intervals and check intervals share the batches, so the wave runs ONE Newton loop per
 // batch whatever the mix (a separate loop for the few check intervals cost as much as the
 // one for the evaluation intervals).
-LT_DEV void run_tasks(WaveScratch& ws, int nchk, int nev, int lane) {
+LT_DEV void run_tasks(WaveScratch& ws, int nchk, int nev, int lane, int first) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const int total = nev + nchk;
 #pragma unroll 1
-  for (int t = lane; t < total; t += 64) {
+  for (int t = first + lane; t < total; t += 64) {
     const bool is_ev = t < nev;
     const double* e = ws.ev[is_ev ? t : 0];
     const int tc = is_ev ? 0 : (t - nev);
@@ -142,9 +144,26 @@ LT_DEV void run_tasks(WaveScratch& ws, int nchk, int nev, int lane) {
       kind = (T > 2.0) ? SIGK_NEWTON : SIGK_DONE;
     }
     bool failed = false;
+#ifdef LT_RK_TIMING
+    int nit = 0;
+    if (kind == SIGK_NEWTON) sg = sigs_newton(T, failed, &nit);
+#else
     if (kind == SIGK_NEWTON) sg = sigs_newton(T, failed);
+#endif
     else if (kind == SIGK_SECANT) sg = sigs_secant(e[5], e[3], e[4]);  // rare
-    if (is_ev) ws.res[(o >> 6) % 3][o & 63] = hval_interval_s(e[6], e[0], e[1], e[2], e[3], e[4], e[5], sg);
+#ifdef LT_RK_TIMING
+    {
+      int mx = nit;
+      for (int off = 32; off > 0; off >>= 1) { int o2 = __shfl_xor(mx, off, 64); mx = (o2 > mx) ? o2 : mx; }
+      int sm = nit;
+      for (int off = 32; off > 0; off >>= 1) sm += __shfl_xor(sm, off, 64);
+      const unsigned long long mn = __ballot(kind == SIGK_NEWTON), msec = __ballot(kind == SIGK_SECANT);
+      const unsigned long long mlow = __ballot(is_ev && fabs(sg) > 1e-9 && fabs(sg) <= .5), mhigh = __ballot(is_ev && fabs(sg) > .5);
+      if (lane == 0) { ws.tim[8] += 1; ws.tim[9] += mx; ws.tim[10] += sm; ws.tim[11] += __popcll(mn); ws.tim[12] += __popcll(msec);
+                       ws.tim[13] += __popcll(mlow); ws.tim[14] += __popcll(mhigh); ws.tim[15] += (total - t + lane < 64) ? (total - t + lane) : 64; }
+    }
+#endif
+    if (is_ev) ws.res[o >> 6][o & 63] = hval_interval_s(e[6], e[0], e[1], e[2], e[3], e[4], e[5], sg);
     if (failed) atomicOr(&ws.errmask[o & 63], 1u << (o >> 6));
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -219,6 +238,7 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
   // slot, are requested before the arithmetic of the current one (same registers: the
   // raw values are dead once the horizontal interpolation has produced Y).
   int4 nd_next = P.UE[eu - 1];
+  int nchk = 0, nev = 0;  // wave-uniform task counts of this stage
   double zt = 0.0, pz = 0.0;
   SlabT raw[16];
 #pragma unroll 1
@@ -228,7 +248,6 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
     const int L = (var == 2) ? P.ws : P.us;
     const double* tab = (var == 2) ? wtab : rtab;
     const int k0 = (var == 2) ? iii : ii;
-    int nchk = 0, nev = 0;  // wave-uniform task counts of this variable
     // The 16 field values (4 nodes x 4 levels) of a time slot -- one 16-byte access per node in
     // the level-fastest layout -- its zeta and its depth are requested one slot ahead of their
     // use, into the registers the previous slot's values just left.
@@ -273,6 +292,9 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
       const SlabT *t0 = b0, *t1 = b1;
       b0 = rot ? b2 : b0; b1 = rot ? b3 : b1; b2 = rot ? t0 : b2; b3 = rot ? t1 : b3;
     }
+#ifdef LT_RK_TIMING
+    { const unsigned long long m3 = __ballot(spl && w.regime >= 3); if (lane == 0) ws.tim[7] += __popcll(m3) + ((m3 != 0) ? (1ull << 32) : 0ull); }
+#endif
     TICK(1);
     LevCoef lc[4];
 #pragma unroll
@@ -280,9 +302,15 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
 #pragma unroll 1
     for (int s = 0; s < 3; s++) {
       const int slot9 = var * 3 + s;
-      if (nev + 64 > LT_EV_CAP) {  // wave-uniform: the next slot might not fit
-        run_tasks(ws, (nchk < LT_CHK_CAP) ? nchk : LT_CHK_CAP, nev, lane);
-        nchk = 0; nev = 0;
+      if (nev + 64 > LT_EV_CAP || nchk + 64 > LT_CHK_CAP) {
+        // wave-uniform: the next slot might not fit -> one full round: the check intervals waiting
+        // and the last 64 - nchk evaluation intervals
+        const int room = (nchk < 64) ? 64 - nchk : 0;
+        const int take = (nev < room) ? nev : room;
+        run_tasks(ws, nchk, nev, lane, nev - take);
+        nev -= take;
+        nchk = 0;
+        TICK(4);
       }
       const double zeta = zt, Pzs = pz;
       double X[4], Y[4];
@@ -303,8 +331,8 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
       }
       if (s < 2) request(s + 1);
       const double DX1 = X[1] - X[0], DX2 = X[2] - X[1], DX3 = X[3] - X[2];
-      const bool ok = spl && (DX1 > 0.0) && (DX2 > 0.0) && (DX3 > 0.0);
-      degenerate |= (spl && !ok) ? (1u << slot9) : 0u;
+      const bool ok = spl & (DX1 > 0.0) & (DX2 > 0.0) & (DX3 > 0.0);
+      degenerate |= (spl & !ok) ? (1u << slot9) : 0u;
       // YPC1 (tension_module.f90:852-977) with the chord slopes kept for SIGS/HVAL
       // (seven quotients over five divisors: the reciprocals are prepared once)
       const Divisor d1 = prep_div(DX1), d2 = prep_div(DX2), d3 = prep_div(DX3);
@@ -320,7 +348,7 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
       // the evaluation interval :1044-1053 (extrapolates with the end intervals)
       // (for strictly increasing knots "T > X(4) -> interval 3" is implied; other windows are redone by k_rk_slow)
       const bool i1 = (Pzs < X[1]);
-      const bool i2 = !i1 && (Pzs < X[2]);
+      const bool i2 = !i1 & (Pzs < X[2]);
       const int I = i1 ? 1 : i2 ? 2 : 3;
       const double x1 = i1 ? X[0] : i2 ? X[1] : X[2];
       const double x2 = i1 ? X[1] : i2 ? X[2] : X[3];
@@ -336,17 +364,15 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
       // Only the evaluation interval's tension is used by HVAL; the other two
       // matter only through SigErr, which only the convexity Newton iteration
       // can raise, so they are queued just when they are Newton candidates.
-      const bool c0 = ok && sigs_candidate_test(SL[0], YP[0], YP[1]);
-      const bool c1 = ok && sigs_candidate_test(SL[1], YP[1], YP[2]);
-      const bool c2 = ok && sigs_candidate_test(SL[2], YP[2], YP[3]);
+      const bool c0 = sigs_candidate_test(SL[0], YP[0], YP[1]) & ok;
+      const bool c1 = sigs_candidate_test(SL[1], YP[1], YP[2]) & ok;
+      const bool c2 = sigs_candidate_test(SL[2], YP[2], YP[3]) & ok;
       // the two non-evaluation intervals: I=1 -> (2,3), I=2 -> (1,3), I=3 -> (1,2)
       const bool ca = i1 ? c1 : c0, cb = (I == 3) ? c1 : c2;
       // the evaluation interval: done here when its tension is known to be ZERO (the cubic form);
       // everything else (an iteration, or the rare known SBIG) goes to pass B
-      double sigI = 0.0;
-      const bool evknown = sigs_eval_known(Sv, p1, p2, sigI);
-      const bool neede = ok && !(evknown && sigI == 0.0);
-      const unsigned long long mc = __ballot(ca || cb), me = __ballot(neede);
+      const bool neede = ok & !sigs_eval_zero(Sv, p1, p2);
+      const unsigned long long mc = __ballot(ca | cb), me = __ballot(neede);
       const unsigned long long below = (1ull << lane) - 1ull;
       if (mc) {  // ~1 % of the intervals are candidates: the operands of T = MAX(D1/D2, D2/D1)
         const unsigned long long ma = __ballot(ca), mb = __ballot(cb);
@@ -385,7 +411,7 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
 #endif
       // HVAL of the zero-tension case, stored by every lane (pass B overwrites the queued ones,
       // the log layer below the others that do not fit a spline)
-      ws.res[s][lane] = hval_cubic_d(Pzs, x1, dI, y1, p1, p2, Sv);
+      ws.res[slot9][lane] = hval_cubic_d(Pzs, x1, dI, y1, p1, p2, Sv);
       (void)x2;
       TICK(3);
     }
@@ -401,22 +427,25 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
         double val = apply_interp(wl, fldv(F, nd.x, L, k, ps), fldv(F, nd.y, L, k, ps),
                                   fldv(F, nd.z, L, k, ps), fldv(F, nd.w, L, k, ps));
         double ztop = level_at(qt, zeta, h, VT);
-        ws.res[s][lane] = val * log10_call((Zs - wzb1) / P.z0) / log10_call((ztop - wzb1) / P.z0);
+        ws.res[var * 3 + s][lane] = val * log10_call((Zs - wzb1) / P.z0) / log10_call((ztop - wzb1) / P.z0);
       }
     }
-    // ---------------- pass B: everything of this variable that iterates
-    run_tasks(ws, (nchk < LT_CHK_CAP) ? nchk : LT_CHK_CAP, nev, lane);
-    TICK(4);
-    // ---------------- pass C: time interpolation :1534-1598 / hydrodynamic_module.f90:2653-2670
-    if (act && !zero) {
-      const double Pv0 = ws.res[0][lane], Pv1 = ws.res[1][lane], Pv2 = ws.res[2][lane];
+  }
+  // ---------------- pass B: what is left of this stage
+  run_tasks(ws, (nchk < LT_CHK_CAP) ? nchk : LT_CHK_CAP, nev, lane, 0);
+  TICK(4);
+  // ---------------- pass C: time interpolation :1534-1598 / hydrodynamic_module.f90:2653-2670
+  if (act && !zero) {
+#pragma unroll
+    for (int var = 0; var < 3; var++) {
+      const double Pv0 = ws.res[var * 3 + 0][lane], Pv1 = ws.res[var * 3 + 1][lane], Pv2 = ws.res[var * 3 + 2][lane];
       double e1 = Pv0, e2 = Pv1, e3 = Pv2;
       if (P.p == 1) { e2 = Pv0; e3 = Pv1; }
       const double val = polintd3(P.ex0, P.ex1, P.ex2, e1, e2, e3, ixv);
       if (var == 0) Uad = val; else if (var == 1) Vad = val; else Wad = val;
     }
-    TICK(5);
   }
+  TICK(5);
   if (act && !zero) {
     const unsigned em = ws.errmask[lane];
     if (em) sigerr_count += __popc(em);
@@ -746,7 +775,7 @@ void k_rk(const StepParams P) {
   bool slow = false;
   WaveScratch& ws = wsc[threadIdx.x >> 6];
 #ifdef LT_RK_TIMING
-  if ((threadIdx.x & 63) < 8) ws.tim[threadIdx.x & 63] = 0;
+  if ((threadIdx.x & 63) < 16) ws.tim[threadIdx.x & 63] = 0;
 #endif
   const Divisor dv = prep_div((VT == 2) ? P.hc + h : h);  // every level depth divides by it
   // the RK stages keep the elements of the start position (LTRANS.f90:990-1053)
@@ -804,7 +833,7 @@ void k_rk(const StepParams P) {
     }
   }
 #ifdef LT_RK_TIMING
-  if ((threadIdx.x & 63) < 8) atomicAdd(&g_tim[threadIdx.x & 63], ws.tim[threadIdx.x & 63]);
+  if ((threadIdx.x & 63) < 16) atomicAdd(&g_tim[threadIdx.x & 63], ws.tim[threadIdx.x & 63]);
 #endif
   if (act) {
     double* wso = P.ws_d + n;
