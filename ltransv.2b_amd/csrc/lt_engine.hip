@@ -577,10 +577,11 @@ int rng_ensure(lt_engine* e, uint64_t first, uint64_t last, hipStream_t gen_stre
 template <typename SlabT>
 void launch_rk_t(lt_engine* e, const StepParams& P, unsigned blocks) {
   const unsigned rkblocks = (unsigned)(((size_t)blocks * 256 + LT_RK_BLOCK - 1) / LT_RK_BLOCK);
+  static const unsigned dynlds = getenv("LT_RK_DYNLDS") ? (unsigned)atoi(getenv("LT_RK_DYNLDS")) : 0u;  // occupancy experiments
   switch (e->cfg.Vtransform) {
-    case 1: hipLaunchKernelGGL((k_rk<SlabT, 1, LT_RK_WAVES>), dim3(rkblocks), dim3(LT_RK_BLOCK), 0, e->stream, P); break;
-    case 2: hipLaunchKernelGGL((k_rk<SlabT, 2, LT_RK_WAVES>), dim3(rkblocks), dim3(LT_RK_BLOCK), 0, e->stream, P); break;
-    default: hipLaunchKernelGGL((k_rk<SlabT, 3, LT_RK_WAVES>), dim3(rkblocks), dim3(LT_RK_BLOCK), 0, e->stream, P); break;
+    case 1: hipLaunchKernelGGL((k_rk<SlabT, 1, LT_RK_WAVES>), dim3(rkblocks), dim3(LT_RK_BLOCK), dynlds, e->stream, P); break;
+    case 2: hipLaunchKernelGGL((k_rk<SlabT, 2, LT_RK_WAVES>), dim3(rkblocks), dim3(LT_RK_BLOCK), dynlds, e->stream, P); break;
+    default: hipLaunchKernelGGL((k_rk<SlabT, 3, LT_RK_WAVES>), dim3(rkblocks), dim3(LT_RK_BLOCK), dynlds, e->stream, P); break;
   }
 }
 // the first consumer of the step's random words waits for the generators

@@ -50,6 +50,7 @@ enum { pX = 0, pY, pZ, pnX, pnY, pnZ, ppX, ppY, ppZ, pStatus, pDOB, pAge, pLifes
 enum { WS_PDEPTH = 0, WS_COSA, WS_SINA, WS_ZETA0, WS_ZETA1, WS_ZETA2, WS_PZ0, WS_PZ1, WS_PZ2,
        WS_ZPAR, WS_SUMU, WS_SUMV, WS_SUMW, WS_TURBV,
        WS_PS, WS_BTHR1, WS_BTHR2,  // behaviour: salinity at the particle, thresholds of the two draws
+       WS_MINPD, WS_MAXPD,         // minpartdepth / maxpartdepth of the RK stages (LTRANS.f90:981-987)
        WS_NDOUBLE };
 // FL_BEH_DIRECTED / FL_BEH_RANDOM: what k_beh_pre decided the behaviour will draw (one deviate
 // compared with WS_BTHR1; then two deviates, the first compared with WS_BTHR2)

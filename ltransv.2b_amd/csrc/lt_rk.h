@@ -23,6 +23,10 @@ template <typename SlabT> struct Win4;
 template <> struct __attribute__((packed, aligned(4))) Win4<float> { float v[4]; };
 template <> struct __attribute__((packed, aligned(8))) Win4<double> { double v[4]; };
 
+// what a stage of k_rk needs first and what the step to the next stage needs: requested before the
+// last round of pass B of the stage before, so that the round covers their latency
+struct StageIn { double zb, zc, zf; int4 nd0; int ii, iii; };   // zetas, node ids of the u element, last windows
+struct StageTail { double X, Y, Zpar, cosA, sinA, minpd, maxpd; };
 // the per-particle context that find_currents needs (registers)
 struct Column {
   double zeta[3];   // zetab, zetac, zetaf at the particle (roles b,c,f)
@@ -178,7 +182,8 @@ LT_DEV void run_tasks(WaveScratch& ws, int nchk, int nev, int lane, int first) {
 template <typename SlabT, int VT>
 LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& ws, bool act, int n,
                           int er, int eu, int ev_, double h, const Divisor& dv, double Xs, double Ys, double Zs, int version,
-                          double& Uad, double& Vad, double& Wad, int& sigerr_count, bool& slow) {
+                          double& Uad, double& Vad, double& Wad, int& sigerr_count, bool& slow,
+                          StageIn& SI, StageTail& ST, bool first_stage, bool last_stage) {
   const double* rtab = lev;
   const double* wtab = lev + 3 * LT_LEV_STRIDE;
   const int lane = threadIdx.x & 63;
@@ -191,7 +196,7 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
   int ii = 1, iii = 1;
   double wzb1 = 0.0;
   if (act) {
-    const double zb = wsd[(size_t)WS_ZETA0 * N], zc = wsd[(size_t)WS_ZETA1 * N], zf = wsd[(size_t)WS_ZETA2 * N];
+    const double zb = SI.zb, zc = SI.zc, zf = SI.zf;
     const LevCoef w1 = level_coef_d(wtab, 1, h, P.hc, VT, dv);
     const LevCoef r1 = level_coef_d(rtab, 1, h, P.hc, VT, dv);
     wzb1 = level_at(w1, zb, h, VT);
@@ -200,25 +205,36 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
     loglayer = !zero && ((Zs < level_at(r1, zb, h, VT)) || (Zs < level_at(r1, zc, h, VT)) ||
                          (Zs < level_at(r1, zf, h, VT)));
     if (!zero && !loglayer) {
-      // lowest 4-level windows :1451-1467 by bisection on the monotone level depths
-      int lo = 3, hi = P.us - 1;
-      while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        LevCoef q = level_coef_d(rtab, mid, h, P.hc, VT, dv);
-        bool below = (Zs < level_at(q, zb, h, VT)) || (Zs < level_at(q, zc, h, VT)) ||
-                     (Zs < level_at(q, zf, h, VT));
-        if (below) hi = mid; else lo = mid + 1;
+      // lowest 4-level windows :1451-1467: lo = the lowest level in [3, L-1] with Zs below it at any of the
+      // three times (the level depths increase with the level), found by bisection at the first stage and,
+      // at the later stages, by walking from the window of the stage before (the stage depths of a step
+      // differ by centimetres: almost always the same window, i.e. two probes instead of five per table)
+      auto below = [&](const double* tab, int k) -> bool {
+        const LevCoef q = level_coef_d(tab, k, h, P.hc, VT, dv);
+        return (Zs < level_at(q, zb, h, VT)) | (Zs < level_at(q, zc, h, VT)) | (Zs < level_at(q, zf, h, VT));
+      };
+      int lo, lw;
+      if (first_stage) {
+        lo = 3;
+        int hi = P.us - 1;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (below(rtab, mid)) hi = mid; else lo = mid + 1;
+        }
+        lw = 3; hi = P.ws - 1;
+        while (lw < hi) {
+          const int mid = (lw + hi) >> 1;
+          if (below(wtab, mid)) hi = mid; else lw = mid + 1;
+        }
+      } else {
+        lo = SI.ii + 2; lw = SI.iii + 2;
+        while (lo > 3 && below(rtab, lo - 1)) lo--;
+        while (lo < P.us - 1 && !below(rtab, lo)) lo++;
+        while (lw > 3 && below(wtab, lw - 1)) lw--;
+        while (lw < P.ws - 1 && !below(wtab, lw)) lw++;
       }
-      ii = lo - 2;
-      lo = 3; hi = P.ws - 1;
-      while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        LevCoef q = level_coef_d(wtab, mid, h, P.hc, VT, dv);
-        bool below = (Zs < level_at(q, zb, h, VT)) || (Zs < level_at(q, zc, h, VT)) ||
-                     (Zs < level_at(q, zf, h, VT));
-        if (below) hi = mid; else lo = mid + 1;
-      }
-      iii = lo - 2;
+      ii = lo - 2; iii = lw - 2;
+      SI.ii = ii; SI.iii = iii;
     }
   }
   const bool spl = act && !zero && !loglayer;  // this lane fits splines
@@ -237,7 +253,7 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
   // NEXT variable's element, and the 4x4 field values + zeta + depth of the NEXT time
   // slot, are requested before the arithmetic of the current one (same registers: the
   // raw values are dead once the horizontal interpolation has produced Y).
-  int4 nd_next = P.UE[eu - 1];
+  int4 nd_next = SI.nd0;
   int nchk = 0, nev = 0;  // wave-uniform task counts of this stage
   double zt = 0.0, pz = 0.0;
   SlabT raw[16];
@@ -302,12 +318,14 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
 #pragma unroll 1
     for (int s = 0; s < 3; s++) {
       const int slot9 = var * 3 + s;
-      if (nev + 64 > LT_EV_CAP || nchk + 64 > LT_CHK_CAP) {
-        // wave-uniform: the next slot might not fit -> one full round: the check intervals waiting
-        // and the last 64 - nchk evaluation intervals
-        const int room = (nchk < 64) ? 64 - nchk : 0;
+      while (nev + 64 > LT_EV_CAP || nchk + 64 > LT_CHK_CAP) {
+        // wave-uniform: the next slot (up to 64 evaluation and 128 check intervals) might not fit -> one
+        // full round: the check intervals waiting and the last 64 - nchk evaluation intervals (a second
+        // round if the check intervals alone filled the first)
+        const int nc = (nchk < LT_CHK_CAP) ? nchk : LT_CHK_CAP;  // (entries beyond the capacity were not stored)
+        const int room = (nc < 64) ? 64 - nc : 0;
         const int take = (nev < room) ? nev : room;
-        run_tasks(ws, nchk, nev, lane, nev - take);
+        run_tasks(ws, nc, nev, lane, nev - take);
         nev -= take;
         nchk = 0;
         TICK(4);
@@ -430,6 +448,18 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
         ws.res[var * 3 + s][lane] = val * log10_call((Zs - wzb1) / P.z0) / log10_call((ztop - wzb1) / P.z0);
       }
     }
+  }
+  // what the step to the next stage and the next stage itself need first (coalesced per-particle
+  // constants, the node ids of the u element) is requested here: the round below covers the latency
+  // (also at the last stage, where nothing uses them: a conditional assignment would keep the old
+  // values alive -- 26 registers -- through all of pass A)
+  {
+    ST.X = P.par[(size_t)pX * N + (act ? n : 0)]; ST.Y = P.par[(size_t)pY * N + (act ? n : 0)];
+    ST.Zpar = wsd[(size_t)WS_ZPAR * N];
+    ST.cosA = wsd[(size_t)WS_COSA * N]; ST.sinA = wsd[(size_t)WS_SINA * N];
+    ST.minpd = wsd[(size_t)WS_MINPD * N]; ST.maxpd = wsd[(size_t)WS_MAXPD * N];
+    SI.zb = wsd[(size_t)WS_ZETA0 * N]; SI.zc = wsd[(size_t)WS_ZETA1 * N]; SI.zf = wsd[(size_t)WS_ZETA2 * N];
+    SI.nd0 = P.UE[eu - 1];
   }
   // ---------------- pass B: what is left of this stage
   run_tasks(ws, (nchk < LT_CHK_CAP) ? nchk : LT_CHK_CAP, nev, lane, 0);
@@ -562,6 +592,20 @@ __global__ __launch_bounds__(256) void k_pre(const StepParams P) {
         wsd[(size_t)WS_PZ1 * N] = Pz[1];
         wsd[(size_t)WS_PZ2 * N] = Pz[2];
         wsd[(size_t)WS_ZPAR * N] = Zpar;  // = par(n,pZ) after :922
+        {  // maxpartdepth / minpartdepth :981-987: the limits of every RK stage depth
+          const double* wtab = P.lev + 3 * LT_LEV_STRIDE;
+          const double hh = -1.0 * P_depth;
+          double mx = level_z(wtab, 1, zeta[0], hh, P.hc, P.Vtransform);
+          double t1 = level_z(wtab, 1, zeta[1], hh, P.hc, P.Vtransform), t2 = level_z(wtab, 1, zeta[2], hh, P.hc, P.Vtransform);
+          if (t1 > mx) mx = t1;
+          if (t2 > mx) mx = t2;
+          double mn = level_z(wtab, P.ws, zeta[0], hh, P.hc, P.Vtransform);
+          t1 = level_z(wtab, P.ws, zeta[1], hh, P.hc, P.Vtransform); t2 = level_z(wtab, P.ws, zeta[2], hh, P.hc, P.Vtransform);
+          if (t1 < mn) mn = t1;
+          if (t2 < mn) mn = t2;
+          wsd[(size_t)WS_MINPD * N] = mn;
+          wsd[(size_t)WS_MAXPD * N] = mx;
+        }
       }
     }
     P.ws_i[n] = flags | (err << FL_ERR_SHIFT);
@@ -749,7 +793,7 @@ __global__ __launch_bounds__(256) void k_beh_pre(const StepParams P) {
 }
 
 #ifndef LT_RK_BLOCK
-#define LT_RK_BLOCK 256
+#define LT_RK_BLOCK 64   // one wave per block: a finished wave frees its slot at once (256-lane blocks: +3 % kernel time)
 #endif
 template <typename SlabT, int VT, int WAVES_PER_SIMD>
 __global__ __launch_bounds__(LT_RK_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES_PER_SIMD, WAVES_PER_SIMD)))
@@ -788,6 +832,12 @@ void k_rk(const StepParams P) {
     slow = true;
     act_fast = false;
   }
+  StageIn SI;
+  StageTail ST;
+  SI.zb = wsd[(size_t)WS_ZETA0 * N]; SI.zc = wsd[(size_t)WS_ZETA1 * N]; SI.zf = wsd[(size_t)WS_ZETA2 * N];
+  SI.nd0 = P.UE[eu - 1];
+  SI.ii = 1; SI.iii = 1;
+  ST.X = ST.Y = ST.Zpar = ST.cosA = ST.sinA = ST.minpd = ST.maxpd = 0.0;
 #pragma unroll 1
   for (int st = 0; st < 4; st++) {
     const int version = (st == 0) ? 1 : (st == 3) ? 3 : 2;
@@ -795,41 +845,26 @@ void k_rk(const StepParams P) {
     // (h made opaque per stage: otherwise every h-dependent level coefficient is hoisted
     // out of the stage loop and held in registers for the whole kernel)
     asm volatile("" : "+v"(h));
-    find_currents<SlabT, VT>(P, lev, ws, act_fast, n, er, eu, ev_, h, dv, Xs, Ys, Zs, version, Uad, Vad, Wad, sigerr_count, slow);
+    find_currents<SlabT, VT>(P, lev, ws, act_fast, n, er, eu, ev_, h, dv, Xs, Ys, Zs, version, Uad, Vad, Wad, sigerr_count, slow,
+                             SI, ST, st == 0, st == 3);
     if (st == 0) { sumU = Uad; sumV = Vad; sumW = Wad; }
     else if (st == 3) { sumU = sumU + Uad; sumV = sumV + Vad; sumW = sumW + Wad; }
     else { sumU = sumU + 2.0 * Uad; sumV = sumV + 2.0 * Vad; sumW = sumW + 2.0 * Wad; }
-    if (st < 3 && act) {
-      // next RK position :999-1035; the per-particle constants come back from
-      // the workspace / par (coalesced) instead of staying in registers
-      const double X = P.par[(size_t)pX * N + n], Y = P.par[(size_t)pY * N + n];
-      const double Zpar = wsd[(size_t)WS_ZPAR * N];
-      const double cosA = wsd[(size_t)WS_COSA * N], sinA = wsd[(size_t)WS_SINA * N];
+    if (st < 3) {
+      // next RK position :999-1035 (the per-particle constants were requested before the last round of
+      // the stage); maxpartdepth / minpartdepth :981-987 come from k_pre
       const double dtf = (double)P.idt;
       if (st < 2) {
-        Xs = X + (Uad * cosA - Vad * sinA) * dtf / 2.0;
-        Ys = Y + (Uad * sinA + Vad * cosA) * dtf / 2.0;
-        Zs = Zpar + Wad * dtf / 2.0;
+        Xs = ST.X + (Uad * ST.cosA - Vad * ST.sinA) * dtf / 2.0;
+        Ys = ST.Y + (Uad * ST.sinA + Vad * ST.cosA) * dtf / 2.0;
+        Zs = ST.Zpar + Wad * dtf / 2.0;
       } else {
-        Xs = X + (Uad * cosA - Vad * sinA) * dtf;
-        Ys = Y + (Uad * sinA + Vad * cosA) * dtf;
-        Zs = Zpar + Wad * dtf;
+        Xs = ST.X + (Uad * ST.cosA - Vad * ST.sinA) * dtf;
+        Ys = ST.Y + (Uad * ST.sinA + Vad * ST.cosA) * dtf;
+        Zs = ST.Zpar + Wad * dtf;
       }
-      // maxpartdepth / minpartdepth :981-987
-      const double* wtab = lev + 3 * LT_LEV_STRIDE;
-      const LevCoef w1 = level_coef_d(wtab, 1, h, P.hc, VT, dv);
-      const LevCoef wN = level_coef_d(wtab, P.ws, h, P.hc, VT, dv);
-      const double zb = wsd[(size_t)WS_ZETA0 * N], zc = wsd[(size_t)WS_ZETA1 * N], zf = wsd[(size_t)WS_ZETA2 * N];
-      double maxpartdepth = level_at(w1, zb, h, VT);
-      double t1 = level_at(w1, zc, h, VT), t2 = level_at(w1, zf, h, VT);
-      if (t1 > maxpartdepth) maxpartdepth = t1;
-      if (t2 > maxpartdepth) maxpartdepth = t2;
-      double minpartdepth = level_at(wN, zb, h, VT);
-      t1 = level_at(wN, zc, h, VT); t2 = level_at(wN, zf, h, VT);
-      if (t1 < minpartdepth) minpartdepth = t1;
-      if (t2 < minpartdepth) minpartdepth = t2;
-      if (Zs > minpartdepth) Zs = minpartdepth - (double)0.000001f;
-      if (Zs < maxpartdepth) Zs = maxpartdepth + (double)0.000001f;
+      if (Zs > ST.minpd) Zs = ST.minpd - (double)0.000001f;
+      if (Zs < ST.maxpd) Zs = ST.maxpd + (double)0.000001f;
     }
   }
 #ifdef LT_RK_TIMING
