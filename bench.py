@@ -4,21 +4,34 @@
     python bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of update_particles() (LTRANS.f90:707) over the shard of
-particles a rank holds: one internal time step of LTRANS.  Workload (N = 1):
-BASELINE.json configs[1] -- 1M particles on a synthetic 512x256x30 ROMS grid,
-RK4 advection only (HTurb / VTurb / behaviour off).  For N > 1 every rank holds
-its own 1M-particle shard of the same grid (fields replicated, weak scaling,
-SURVEY.md section 8e) and the ranks all-gather the new (x,y,z) over RCCL at the
-end of each step.  Inputs are resident in HBM when the timed region starts.
+particles a rank holds: one internal time step of LTRANS.
+
+  N = 1   BASELINE.json configs[1]: 1M particles on a synthetic 512x256x30 ROMS grid, RK4
+          advection only (the configuration the metric is quoted on).  The same line carries,
+          under config.turbulence, configs[2] (the same + HTurb + VTurb with the device
+          MT19937 stream) timed for the same number of steps.
+  N > 1   BASELINE.json configs[3]: 10M particles in total on a 1024x512x50 grid, RK4 + HTurb
+          + VTurb, sharded by contiguous index block over the N ranks (fields replicated,
+          SURVEY.md section 8e): STRONG scaling.  After every step the ranks all-gather the
+          new (x,y,z) over RCCL.  --weak keeps --numpar particles per rank instead;
+          --workload picks any configuration explicitly.
+
+When started without a launcher (`python bench.py --gpus N`, N > 1) this process only starts
+N children (one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), relays rank 0's
+line and exits non-zero if any child fails; it never touches the GPU itself.  Under
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` the ranks exist
+already; a WORLD_SIZE that differs from --gpus is an error.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
   "roofline":     algorithmic bytes / HIP-event kernel time vs the HBM peak
   "cpu_baseline": the CPU oracle (a single-thread C port of the reference path)
-                  timed on a bounded sample of the same workload.
+                  timed on a bounded sample of the same workload (N = 1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,57 +45,147 @@ A_ADV_F32 = 96 + 256 + 48 + 576          # = 976 B
 A_ADV_F64 = 96 + 256 + 96 + 1152         # = 1600 B
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
+WORKLOADS = {
+    # name: (grid, total particles, turbulence, reflect/behaviour-6/settlement)
+    "config2": ("512x256x30", 1_000_000, False, False),
+    "config3": ("512x256x30", 1_000_000, True, False),
+    "config4": ("1024x512x50", 10_000_000, True, False),
+    "config5": ("1024x512x50", 10_000_000, True, True),
+}
 
-def parse():
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--numpar", type=int, default=1_000_000, help="particles per GPU")
-    ap.add_argument("--grid", type=str, default="512x256x30")
+    ap.add_argument("--workload", choices=["auto"] + sorted(WORKLOADS), default="auto",
+                    help="auto = config2 on one GPU, config4 (10M particles in total, strong scaling) on several")
+    ap.add_argument("--weak", action="store_true", help="N > 1: --numpar particles PER RANK on --grid (weak scaling)")
+    ap.add_argument("--numpar", type=int, default=None, help="particles (per GPU with --weak, else in total)")
+    ap.add_argument("--grid", type=str, default=None)
     ap.add_argument("--slab", choices=["f32", "f64"], default="f32")
-    ap.add_argument("--turb", action="store_true",
-                    help="BASELINE configs[2]: RK4 + HTurb + VTurb (MT19937 stream on device)")
-    ap.add_argument("--behavior", type=int, default=0,
+    ap.add_argument("--turb", action="store_true", help="= --workload config3 on one GPU")
+    ap.add_argument("--behavior", type=int, default=None,
                     help="behaviour type 0-7 (BASELINE configs[4] uses 6 = sinking, with --settle)")
     ap.add_argument("--settle", action="store_true", help="settlement on habitat polygons + mortality")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hydro-timing", action="store_true",
-                    help="skip the updateHydro cost measurement (set_slab vs slab pipeline)")
-    ap.add_argument("--cpu-sample", type=int, default=40000,
-                    help="particles of the bounded CPU-baseline sample")
+                    help="skip the updateHydro / print-step / init-geometry cost measurements")
+    ap.add_argument("--no-turbulence-line", action="store_true",
+                    help="N = 1, config2: skip the embedded configs[2] measurement (config.turbulence)")
+    ap.add_argument("--no-single-ref", action="store_true",
+                    help="N > 1, strong scaling: skip rank 0's run of the WHOLE workload on one GPU afterwards")
+    ap.add_argument("--cpu-sample", type=int, default=40000, help="particles of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-steps", type=int, default=30)
-    return ap.parse_args()
+    ap.add_argument("--selftest-launch", choices=["ok", "fail"], default=None,
+                    help="only exercise the launcher: ranks rendezvous over gloo on CPU tensors and print a line")
+    return ap.parse_args(argv)
 
 
-def pmc_traffic(tag, kernels, n, args):
-    """HBM-side bytes per launch of the timed kernel(s) from the committed rocprofv3 PMC
-    summary of THIS command (profiles/<tag>/pmc.json: FETCH_SIZE x 2 on gfx950 +
-    WRITE_SIZE, separate passes, see profiles/tools/).  Counters cannot be collected
-    inside an ordinary run, so the number is the one measured for the default workload;
-    any other workload reports null."""
-    if n != 1_000_000 or args.grid != "512x256x30" or args.slab != "f32":
-        return None, None
+# ----------------------------------------------------------------------------- launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_children(args):
+    """--gpus N without a launcher: start the N ranks.  Nothing here imports torch or touches HIP."""
+    n = args.gpus
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
+    out0 = b""
+    failed = None
+    pending = set(range(n))
+    while pending and failed is None:
+        for r in sorted(pending):
+            p = procs[r]
+            try:
+                if r == 0:
+                    o, _ = p.communicate(timeout=0.2)
+                    out0 += o or b""
+                else:
+                    p.wait(timeout=0.2)
+            except subprocess.TimeoutExpired:
+                continue
+            pending.discard(r)
+            if p.returncode != 0:
+                failed = (r, p.returncode)
+                break
+    if failed is not None:
+        for r in pending:                       # the exact children this process started
+            procs[r].terminate()
+        for r in pending:
+            try:
+                procs[r].wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+        sys.stderr.write("bench.py: rank %d exited with code %d\n" % failed)
+        sys.stdout.write(out0.decode(errors="replace"))
+        return 1
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    return 0
+
+
+def selftest_launch(args, world, rank):
+    """the launcher alone (CPU, gloo): rendezvous, one collective, rank 0's line"""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group(backend="gloo")
+    t = torch.tensor([rank + 1], dtype=torch.int64)
+    dist.all_reduce(t)
+    ok = int(t.item()) == world * (world + 1) // 2 and dist.get_world_size() == world
+    dist.barrier()
+    dist.destroy_process_group()
+    if args.selftest_launch == "fail" and rank == world - 1:
+        return 3
+    if rank == 0:
+        print(json.dumps({"selftest": "launch", "n_gpus": world, "sum_ok": bool(ok)}))
+    return 0 if ok else 4
+
+
+# ----------------------------------------------------------------------------- helpers
+def source_hash_of_profile(tag):
     p = os.path.join(ROOT, "profiles", tag, "pmc.json")
     try:
         d = json.load(open(p))
     except (OSError, ValueError):
         return None, None
+    return d, d.get("_meta", {}).get("source_hash")
+
+
+def pmc_traffic(tag, kernels, lib_hash):
+    """HBM-side bytes per launch of the timed kernel(s) from the committed rocprofv3 PMC summary
+    of THIS command (profiles/<tag>/pmc.json, separate --pmc passes, see profiles/tools/).
+    Counters cannot be collected inside an ordinary run, so the number is the one measured for
+    the default workload -- and only while the library is built from the very kernel sources the
+    profile was taken with (pmc.json records their hash, the library exports its own); otherwise null."""
+    d, prof_hash = source_hash_of_profile(tag)
+    if d is None or prof_hash is None or prof_hash != lib_hash:
+        return None, None, None
     tot = 0.0
     valu = {}
     for kern in kernels:
         hit = [v for k, v in d.items() if ("::" + kern + "(" in k or "::" + kern + "<" in k)]
         if not hit or "fetch_bytes_per_launch" not in hit[0] or "write_bytes_per_launch" not in hit[0]:
-            return None, None
+            return None, None, None
         tot += hit[0]["fetch_bytes_per_launch"] + hit[0]["write_bytes_per_launch"]
         g = lambda c: hit[0].get(c, {}).get("mean_per_launch")  # noqa: E731
         if g("SQ_WAVES") and g("SQ_WAVE_CYCLES"):
-            # what actually bounds these kernels: the fp64 VALU instruction stream
             valu[kern] = {"valu_instr_per_particle_step": g("SQ_INSTS_VALU") / g("SQ_WAVES"),
                           "wave_cycles_valu_active": g("SQ_ACTIVE_INST_VALU") / g("SQ_WAVE_CYCLES"),
                           "wave_cycles_waiting": g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES")}
-    pmc_traffic.valu = valu
-    return tot, "profiles/%s/pmc.json" % tag
+    return tot, "profiles/%s/pmc.json" % tag, valu
 
 
 def valu_issue(valu, kernels, n, k_avg_s):
@@ -98,22 +201,41 @@ def valu_issue(valu, kernels, n, k_avg_s):
             "valu_instr_per_particle_step": per}
 
 
-def build_inputs(vi, uj, us, numpar, seed):
+def algorithmic_bytes(slab, turb, ws):
+    A = A_ADV_F32 if slab == "f32" else A_ADV_F64
+    if turb:
+        # SURVEY.md 8(d): + Kh 4 nodes x ws x 3 slots, + the materialised stream (124 draws
+        # of 4 B written once and read once)
+        A += (48 if slab == "f32" else 96) * ws + 124 * 4 * 2
+    return A
+
+
+ISLANDS_B = [(200, 215, 100, 140), (600, 640, 300, 310), (820, 830, 80, 90), (400, 402, 400, 460)]
+
+
+def build_world(vi, uj, us, reflect):
     from ltrans_amd import roms_synth as rs
-    g = rs.make_grid(vi, uj, us)
+    g = rs.make_grid(vi, uj, us, islands=[(int(a * vi / 1024), int(b * vi / 1024), int(c * uj / 512), int(d * uj / 512))
+                                          for a, b, c, d in ISLANDS_B] if reflect else ())
     geo = rs.build_geometry(g)
     bounds = rs.create_bounds(g)
-    parts = rs.make_particles(g, geo, bounds, numpar, seed=seed)
-    return g, geo, bounds, parts
+    return g, geo, bounds
 
 
-def behaviour_cfg(args):
+def make_parts(g, geo, bounds, numpar, seed, reflect):
+    from ltrans_amd import roms_synth as rs
+    if reflect:   # configs[4]: a fifth of the particles within 120 m of the west / south coast
+        return rs.make_particles(g, geo, bounds, numpar, seed=seed, near_land=0.2, coast_band=(5.0, 120.0))
+    return rs.make_particles(g, geo, bounds, numpar, seed=seed)
+
+
+def behaviour_cfg(behavior, settle):
     """extra lt_config fields of the optional behaviour / settlement workload"""
-    kw = dict(Behavior=args.behavior)
-    if args.behavior:
-        kw.update(swimstart=0.0, swimslow=0.002, swimfast=0.004, sink=-0.002, pediage=7200.0, deadage=90000.0,
-                  Sgradient=0.3, Hswimspeed=0.3)
-    if args.settle:
+    kw = dict(Behavior=behavior)
+    if behavior:
+        kw.update(swimstart=0.0, swimslow=0.002, swimfast=0.004, sink=-0.0003 if behavior == 6 else -0.002,
+                  pediage=7200.0, deadage=90000.0, Sgradient=0.3, Hswimspeed=0.3)
+    if settle:
         kw.update(settlementon=1, holesExist=1, mortality=1, pediage=3600.0, deadage=36000.0)
     return kw
 
@@ -134,7 +256,52 @@ def make_engine(ltrans_amd, cfg, g, geo, bounds, parts, records, **kw):
     return e, run
 
 
-def hydro_update_costs(e, run, rs, g, geo, args, state, one_step, fence):
+class Stepper:
+    """the internal-step loop of one engine: rotation outside the timed region"""
+
+    def __init__(self, e, run, cfg):
+        self.e, self.run, self.cfg = e, run, cfg
+        self.p = 2                      # second external step: plain (b,c,f) time interpolation
+        self.ex = run.external_times(self.p)
+        self.stepIT = cfg.dt // cfg.idt
+        self.it = 0
+
+    def needs_rotation(self):
+        return self.it + 1 > self.stepIT
+
+    def rotate(self):
+        """next external step: updateHydro = rotate slots + upload ONE record.  Kept
+        outside the timed region (SURVEY.md 8d: slab upload is reported separately)."""
+        self.p += 1
+        self.it = 0
+        self.run.p = self.p
+        self.run.update_hydro()
+        self.ex = self.run.external_times(self.p)
+
+    def next_times(self):
+        self.it += 1
+        return self.run.internal_times(self.ex, self.it)
+
+
+def timed_steps(st, nsteps, one_step, fence):
+    wall = upload = 0.0
+    t0 = time.perf_counter()
+    for _ in range(nsteps):
+        if st.needs_rotation():
+            fence()
+            wall += time.perf_counter() - t0
+            tu = time.perf_counter()
+            st.rotate()
+            fence()
+            upload += time.perf_counter() - tu
+            t0 = time.perf_counter()
+        one_step()
+    fence()
+    wall += time.perf_counter() - t0
+    return wall, upload
+
+
+def hydro_update_costs(e, run, rs, g, geo, turb, st, one_step, fence):
     """What one updateHydro costs on this box, outside the throughput measurement
     (SURVEY.md 8f row 1): the synchronous lt_set_slab path (host waits, GPU idle) against
     the slab pipeline (lt_slab_prefetch beside the steps, lt_slab_commit at the rotation).
@@ -142,15 +309,15 @@ def hydro_update_costs(e, run, rs, g, geo, args, state, one_step, fence):
     import numpy as np
     stepIT = run.dt // run.idt
     r0 = run.stepf
-    masked = rs.make_record(g, geo, r0, with_kh=bool(args.turb))
-    rom32 = rs.make_record(g, geo, r0 + 1, with_kh=bool(args.turb), raw=np.float32)
-    rom64 = rs.make_record(g, geo, r0 + 2, with_kh=bool(args.turb), raw=np.float64)
+    masked = rs.make_record(g, geo, r0, with_kh=bool(turb))
+    rom32 = rs.make_record(g, geo, r0 + 1, with_kh=bool(turb), raw=np.float32)
+    rom64 = rs.make_record(g, geo, r0 + 2, with_kh=bool(turb), raw=np.float64)
     dims = (g["vi"], g["uj"], g["ui"], g["vj"])
     mb = lambda d: sum(v.nbytes for v in d.values() if v is not None) / 1e6  # noqa: E731
 
     def steps():
         for _ in range(stepIT):
-            state["it"] = state["it"] % stepIT
+            st.it = st.it % stepIT
             one_step()
 
     def rotated():
@@ -189,17 +356,16 @@ def hydro_update_costs(e, run, rs, g, geo, args, state, one_step, fence):
     return out
 
 
-def cpu_baseline(ltrans_amd, args, vi, uj, us, g, geo, bounds, records):
+def cpu_baseline(ltrans_amd, args, spec, g, geo, bounds, records):
     """Time the CPU oracle (kind "port": single-thread C restatement of the
     reference path, oracle/ltrans_oracle.c) on a bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
-    from ltrans_amd import roms_synth as rs
     n = args.cpu_sample
-    parts = rs.make_particles(g, geo, bounds, n, seed=777)
-    turb = 1 if args.turb else 0
-    cfg = ltrans_amd.LtConfig(numpar=n, us=us, ws=us + 1, dt=3600, idt=120,
-                              ErrorFlag=1, HTurbOn=turb, VTurbOn=turb, **behaviour_cfg(args))
+    parts = make_parts(g, geo, bounds, n, 777, spec["reflect"])
+    turb = 1 if spec["turb"] else 0
+    cfg = ltrans_amd.LtConfig(numpar=n, us=spec["us"], ws=spec["us"] + 1, dt=3600, idt=120,
+                              ErrorFlag=1, HTurbOn=turb, VTurbOn=turb, **behaviour_cfg(spec["behavior"], spec["settle"]))
     e, run = make_engine(ltrans_amd, cfg, g, geo, bounds, parts, records,
                          lib=oracle_lib.load_oracle(), prefix="lto_")
     ex = run.external_times(2)
@@ -211,19 +377,64 @@ def cpu_baseline(ltrans_amd, args, vi, uj, us, g, geo, bounds, records):
     return {"value": n * args.cpu_steps / dt, "unit": "particle-steps/s", "cores": 1,
             "kind": "port",
             "sample": f"{n} particles x {args.cpu_steps} internal steps on the same "
-                      f"{vi}x{uj}x{us} grid, {dt:.1f} s wall, {os.cpu_count()} host cores present"}
+                      f"{spec['grid']} grid, {dt:.1f} s wall, {os.cpu_count()} host cores present"}
 
 
+def resolve_workload(args, world):
+    name = args.workload
+    if name == "auto":
+        name = "config3" if (args.turb and world == 1) else ("config2" if world == 1 else "config4")
+    grid, total, turb, reflect = WORKLOADS[name]
+    if args.turb:
+        turb = True
+    grid = args.grid or grid
+    vi, uj, us = (int(v) for v in grid.split("x"))
+    behavior = args.behavior if args.behavior is not None else (6 if reflect else 0)
+    settle = bool(args.settle or reflect)
+    weak = bool(args.weak and world > 1)
+    if weak:
+        per_rank = args.numpar or 1_000_000
+        total = per_rank * world
+    else:
+        total = args.numpar or total
+    return dict(name=name, grid=grid, vi=vi, uj=uj, us=us, turb=turb, reflect=reflect, behavior=behavior,
+                settle=settle, total=total, weak=weak)
+
+
+def workload_text(spec, world, n_local):
+    s = (f"{spec['total']} particles in total" if not spec["weak"] else f"{n_local} particles per GPU")
+    s += f", synthetic {spec['grid']} ROMS grid, "
+    s += ("RK4 + HTurb + VTurb (MT19937 stream on device), idt=120 s" if spec["turb"]
+          else "RK4 advection only (HTurb/VTurb off), idt=120 s")
+    s += (f", behaviour {spec['behavior']}" if spec["behavior"] else ", behavior off")
+    s += (", islands + drift into the coast (reflection), settlement + mortality" if spec["reflect"]
+          else (", settlement + mortality" if spec["settle"] else ""))
+    if world > 1:
+        s += f", sharded over {world} GPUs by contiguous index block, RCCL all-gather of (x,y,z) per step"
+    return s
+
+
+# ----------------------------------------------------------------------------- main
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        return launch_children(args)                     # before anything touches torch.cuda / HIP
+    world = int(env_world or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with matching values\n")
+        return 2
+    if args.selftest_launch:
+        return selftest_launch(args, world, rank)
+
     import numpy as np
     import torch
     import ltrans_amd
     from ltrans_amd import roms_synth as rs
+    from ltrans_amd import sharding
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     # LT_BENCH_BACKEND=gloo (rehearsal on a box with fewer GPUs than ranks: ranks share the
     # cards, the all-gather goes through host memory) -- the driver's runs use RCCL
@@ -237,85 +448,95 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend=backend)
+        assert dist.get_world_size() == args.gpus
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", dev_index)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
-    vi, uj, us = (int(v) for v in args.grid.split("x"))
-    n = args.numpar
-    g, geo, bounds, parts = build_inputs(vi, uj, us, n, seed=12345 + rank)
+    spec = resolve_workload(args, world)
+    vi, uj, us = spec["vi"], spec["uj"], spec["us"]
+    lo, hi = sharding.shard_range(spec["total"], world, rank)
+    n = hi - lo
+    g, geo, bounds = build_world(vi, uj, us, spec["reflect"])
+    drift = (-0.2, -0.15) if spec["reflect"] else (0.0, 0.0)
+    # every rank's shard is its own draw (seed + rank): the shards of a strong-scaling run are the
+    # blocks of the global particle list that rank 0 re-assembles for the single-GPU reference
+    parts = make_parts(g, geo, bounds, n, 12345 + rank, spec["reflect"])
     rec_cache = {}
 
-    def records(r):
-        if r not in rec_cache:
-            rec_cache[r] = rs.make_record(g, geo, r, with_kh=bool(args.turb))
-        return rec_cache[r]
+    def records(r, with_kh=None):
+        k = (r, bool(spec["turb"] if with_kh is None else with_kh))
+        if k not in rec_cache:
+            rec_cache[k] = rs.make_record(g, geo, r, with_kh=k[1], drift=drift)
+        return rec_cache[k]
 
-    turb = 1 if args.turb else 0
-    cfg = ltrans_amd.LtConfig(numpar=n, us=us, ws=us + 1, dt=3600, idt=120,
-                              ErrorFlag=1, device=dev.index, HTurbOn=turb, VTurbOn=turb, **behaviour_cfg(args),
-                              slab_storage=(ltrans_amd.abi.LT_SLAB_F32 if args.slab == "f32"
-                                            else ltrans_amd.abi.LT_SLAB_F64))
+    def config_for(numpar, turb):
+        t = 1 if turb else 0
+        return ltrans_amd.LtConfig(numpar=numpar, us=us, ws=us + 1, dt=3600, idt=120, ErrorFlag=1, device=dev.index,
+                                   HTurbOn=t, VTurbOn=t, ConstantHTurb=1.0, **behaviour_cfg(spec["behavior"], spec["settle"]),
+                                   slab_storage=(ltrans_amd.abi.LT_SLAB_F32 if args.slab == "f32"
+                                                 else ltrans_amd.abi.LT_SLAB_F64))
+
+    cfg = config_for(n, spec["turb"])
     e, run = make_engine(ltrans_amd, cfg, g, geo, bounds, parts, records)
+    st = Stepper(e, run, cfg)
+    lib_hash = e.source_hash()
 
-    # N > 1: the end-of-step all-gather of (x,y,z) runs on its own stream and overlaps the
-    # next step's kernels; the packed positions are double-buffered so a step never
-    # overwrites a buffer RCCL may still be reading.
-    send = recv = gather_stream = None
+    # N > 1: the end-of-step all-gather of (x,y,z) runs on its own stream and overlaps the next
+    # step's kernels.  It is ordered behind the step on the DEVICE (an event on the engine's stream;
+    # no host synchronisation per step); the packed positions are double-buffered and the engine's
+    # stream waits for the all-gather that last read a buffer before packing into it again.
+    nmax = max(sharding.shard_sizes(spec["total"], world)) if world > 1 else n
+    send = recv = gather_stream = eng_stream = None
     send_done = [None, None]
+    nstep = [0]
     if world > 1:
-        send = [torch.empty(3 * n, dtype=torch.float64, device=dev) for _ in range(2)]
-        recv = torch.empty(3 * n * world, dtype=torch.float64, device=dev)
+        send = [torch.zeros(3 * nmax, dtype=torch.float64, device=dev) for _ in range(2)]
+        recv = torch.empty(3 * nmax * world, dtype=torch.float64, device=dev)
         gather_stream = torch.cuda.Stream(device=dev)
+        eng_stream = torch.cuda.ExternalStream(e.stream(), device=dev)
 
-    p = 2                      # second external step: plain (b,c,f) time interpolation
-    ex = run.external_times(p)
-    stepIT = cfg.dt // cfg.idt
-    state = {"it": 0, "p": p, "ex": ex, "nstep": 0}
-
-    def needs_rotation():
-        return state["it"] + 1 > stepIT
-
-    def rotate():
-        """next external step: updateHydro = rotate slots + upload ONE record.  Kept
-        outside the timed region (SURVEY.md 8d: slab upload is reported separately)."""
-        state["p"] += 1
-        state["it"] = 0
-        run.p = state["p"]
-        run.update_hydro()
-        state["ex"] = run.external_times(state["p"])
+    draws = spec["turb"] or 1 <= spec["behavior"] <= 5
+    # A shard's window of the single serial random stream is static while no particle can stop drawing:
+    # nothing is unreleased (DOB <= 0), settles, dies or leaves through an open boundary.  Otherwise the
+    # ranks exchange their counts before every step (one all-gather of one int64 each, one host read).
+    static_window = (draws and not (1 <= spec["behavior"] <= 5) and not spec["settle"]
+                     and float(parts["par"][:, 10].max()) <= 0.0)
+    if world > 1 and static_window:
+        sizes = sharding.shard_sizes(spec["total"], world)
+        e.set_rng_window(int(sum(sizes[:rank])), int(sum(sizes)), persistent=True)
 
     def one_step():
-        state["it"] += 1
-        ix = run.internal_times(state["ex"], state["it"])
-        if world > 1 and (args.turb or 1 <= args.behavior <= 5):
-            # every rank's place in the single serial random stream of this step
-            from ltrans_amd import sharding
-            if 1 <= args.behavior <= 5:   # data-dependent number of deviates: count draws
-                mine = e.count_draws(state["ex"], ix, state["p"], state["it"])
+        ix = st.next_times()
+        if world > 1 and draws and not static_window:
+            if 1 <= spec["behavior"] <= 5:   # data-dependent number of deviates: count draws
+                mine = e.count_draws(st.ex, ix, st.p, st.it)
                 before, total = sharding.rng_window(dist, torch, mine, world, rank, device=coll_dev)
                 e.set_rng_window_draws(before, total)
             else:
                 before, total = sharding.rng_window(dist, torch, e.count_active(ix), world, rank, device=coll_dev)
                 e.set_rng_window(before, total)
-        e.update_particles(state["ex"], ix, state["p"], state["it"])
+        e.update_particles(st.ex, ix, st.p, st.it)
         if world > 1:
-            b = state["nstep"] & 1
-            state["nstep"] += 1
+            b = nstep[0] & 1
+            nstep[0] += 1
             if send_done[b] is not None:
-                send_done[b].synchronize()      # the all-gather that last read this buffer
+                eng_stream.wait_event(send_done[b])   # the all-gather that last read this buffer
             e.pack_positions(send[b].data_ptr())
-            e.sync()                            # engine stream: step + pack complete
-            with torch.cuda.stream(gather_stream):
-                if backend == "nccl":
+            if backend == "nccl":
+                packed = torch.cuda.Event()
+                packed.record(eng_stream)
+                gather_stream.wait_event(packed)
+                with torch.cuda.stream(gather_stream):
                     dist.all_gather_into_tensor(recv, send[b])
-                else:
-                    parts_ = [torch.empty(3 * n, dtype=torch.float64) for _ in range(world)]
-                    dist.all_gather(parts_, send[b].cpu())
-                    recv.copy_(torch.cat(parts_))
-                send_done[b] = torch.cuda.Event()
-                send_done[b].record(gather_stream)
+                    send_done[b] = torch.cuda.Event()
+                    send_done[b].record(gather_stream)
+            else:                                       # rehearsal: through host memory
+                e.sync()
+                parts_ = [torch.empty(3 * nmax, dtype=torch.float64) for _ in range(world)]
+                dist.all_gather(parts_, send[b].cpu())
+                recv.copy_(torch.cat(parts_))
 
     def fence():
         e.sync()
@@ -325,26 +546,12 @@ def main():
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        if needs_rotation():
-            rotate()
+        if st.needs_rotation():
+            st.rotate()
         one_step()
     fence()
     e.profile_begin(args.steps)
-    wall = 0.0
-    upload_s = 0.0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        if needs_rotation():
-            fence()
-            wall += time.perf_counter() - t0
-            tu = time.perf_counter()
-            rotate()
-            fence()
-            upload_s += time.perf_counter() - tu
-            t0 = time.perf_counter()
-        one_step()
-    fence()
-    wall += time.perf_counter() - t0
+    wall, upload_s = timed_steps(st, args.steps, one_step, fence)
     k_ms, k_n = e.profile_end()
     stats = e.counters()
 
@@ -353,46 +560,75 @@ def main():
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
     wall = float(wall_t.item())
 
-    active = stats["active"]
-    total_particle_steps = float(n) * world * args.steps
+    total_particle_steps = float(spec["total"]) * args.steps
     value = total_particle_steps / wall
-    A = A_ADV_F32 if args.slab == "f32" else A_ADV_F64
-    if args.turb:
-        # SURVEY.md 8(d): + Kh 4 nodes x ws x 3 slots, + the materialised stream (124 draws
-        # of 4 B written once and read once)
-        ws_ = us + 1
-        A += (48 if args.slab == "f32" else 96) * ws_ + 124 * 4 * 2
+    A = algorithmic_bytes(args.slab, spec["turb"], us + 1)
     k_avg_s = (k_ms / max(k_n, 1)) * 1e-3
     achieved = (A * n / k_avg_s) / 1e9 if k_avg_s > 0 else 0.0
-    kernels = ["k_vt_table", "k_vt_sigs", "k_vt_walk"] if args.turb else ["k_rk"]
-    traffic, traffic_src = pmc_traffic("r01_turb" if args.turb else "r01_adv", kernels, n, args)
+    kernels = ["k_vt_table", "k_vt_sigs", "k_vt_walk"] if spec["turb"] else ["k_rk"]
+    default_shape = (n == 1_000_000 and spec["grid"] == "512x256x30" and args.slab == "f32" and not spec["reflect"])
+    traffic = traffic_src = valu = None
+    if default_shape:
+        traffic, traffic_src, valu = pmc_traffic("r02_turb" if spec["turb"] else "r02_adv", kernels, lib_hash)
 
     out = {
         "metric": "particle-steps/s", "value": value, "unit": "particle-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak" if (spec["weak"] or world == 1) else "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{n} particles per GPU, synthetic {vi}x{uj}x{us} ROMS grid, "
-                               + ("RK4 + HTurb + VTurb (MT19937 stream on device), idt=120 s" if args.turb
-                                  else "RK4 advection only (HTurb/VTurb off), idt=120 s")
-                               + (f", behaviour {args.behavior}" if args.behavior else ", behavior off")
-                               + (", settlement + mortality" if args.settle else "")
-                               + (", RCCL all-gather of (x,y,z) per step" if world > 1 else ""),
-                   "particles_per_gpu": n, "grid": args.grid, "slab_storage": args.slab,
-                   "active_last_step": active, "errors_last_step": stats["errors"],
-                   "sigerr_last_step": stats["sigerr"],
-                   "slab_rotation_s_excluded": upload_s},
+        "config": {"workload": workload_text(spec, world, n), "baseline_config": spec["name"],
+                   "particles_total": spec["total"], "particles_this_rank": n, "grid": spec["grid"],
+                   "slab_storage": args.slab, "kernel_source_hash": lib_hash,
+                   "active_last_step": stats["active"], "errors_last_step": stats["errors"],
+                   "sigerr_last_step": stats["sigerr"], "slab_rotation_s_excluded": upload_s,
+                   "rng_window": ("static" if static_window else "exchanged per step") if (world > 1 and draws) else None},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": traffic_src,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "+".join(kernels), "kernel_ms_avg": k_avg_s * 1e3,
-                     "valu_pmc": getattr(pmc_traffic, "valu", None),
-                     "valu_issue": valu_issue(getattr(pmc_traffic, "valu", None), kernels, n, k_avg_s),
-                     "algorithmic_bytes_per_launch": A * n,
-                     "algorithmic_bytes_per_particle_step": A},
+                     "valu_pmc": valu, "valu_issue": valu_issue(valu, kernels, n, k_avg_s),
+                     "algorithmic_bytes_per_launch": A * n, "algorithmic_bytes_per_particle_step": A},
     }
+
+    if world == 1 and spec["name"] == "config2" and not args.no_turbulence_line:
+        # BASELINE configs[2] in the same line: the same particles with HTurb + VTurb, same number of steps
+        cfg_t = config_for(n, True)
+        e_t, run_t = make_engine(ltrans_amd, cfg_t, g, geo, bounds, parts, lambda r: records(r, True))
+        st_t = Stepper(e_t, run_t, cfg_t)
+
+        def step_t():
+            e_t.update_particles(st_t.ex, st_t.next_times(), st_t.p, st_t.it)
+
+        def fence_t():
+            e_t.sync()
+            torch.cuda.synchronize()
+
+        for _ in range(args.warmup):
+            if st_t.needs_rotation():
+                st_t.rotate()
+            step_t()
+        fence_t()
+        e_t.profile_begin(args.steps)
+        wall_tb, _ = timed_steps(st_t, args.steps, step_t, fence_t)
+        kt_ms, kt_n = e_t.profile_end()
+        A_t = algorithmic_bytes(args.slab, True, us + 1)
+        kt_avg = (kt_ms / max(kt_n, 1)) * 1e-3
+        kern_t = ["k_vt_table", "k_vt_sigs", "k_vt_walk"]
+        tr_t, src_t, valu_t = pmc_traffic("r02_turb", kern_t, lib_hash) if default_shape else (None, None, None)
+        out["config"]["turbulence"] = {
+            "workload": "BASELINE configs[2]: the same + HTurb + VTurb (MT19937 stream on device)",
+            "value": n * args.steps / wall_tb, "unit": "particle-steps/s", "ms_per_step": wall_tb / args.steps * 1e3,
+            "steps": args.steps, "sigerr_last_step": e_t.counters()["sigerr"],
+            "roofline": {"bound": "hbm", "achieved": (A_t * n / kt_avg) / 1e9 if kt_avg > 0 else 0.0,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ((A_t * n / kt_avg) / 1e9 / HBM_PEAK_GBS) if kt_avg > 0 else 0.0,
+                         "traffic": tr_t, "traffic_source": src_t, "kernel": "+".join(kern_t),
+                         "kernel_ms_avg": kt_avg * 1e3, "valu_issue": valu_issue(valu_t, kern_t, n, kt_avg),
+                         "algorithmic_bytes_per_particle_step": A_t}}
+        e_t.close()
+
     if world == 1 and not args.no_hydro_timing:
-        out["config"]["hydro_update"] = hydro_update_costs(e, run, rs, g, geo, args, state, one_step, fence)
+        out["config"]["hydro_update"] = hydro_update_costs(e, run, rs, g, geo, spec["turb"], st, one_step, fence)
         # the print step: lon/lat/status on the device + download of the
         # writers' columns, against downloading the whole particle state
         fence()
@@ -413,17 +649,49 @@ def main():
                 and np.array_equal(adj[1], geo["u_Adjacent"]) and np.array_equal(adj[2], geo["v_Adjacent"]))
         out["config"]["init_geometry"] = {"lt_locate_particles_ms": t_loc * 1e3, "lt_build_adjacency_ms": t_adj * 1e3,
                                           "matches_host_construction": bool(same)}
+    e.close()
+
+    if world > 1 and not spec["weak"] and not args.no_single_ref:
+        # strong scaling needs its one-GPU point on the SAME workload: rank 0 alone runs all the
+        # particles (the concatenation of the ranks' shards) for a few steps; reported raw, beside `value`
+        torch.cuda.synchronize()
+        dist.barrier()
+        if rank == 0:
+            sizes = sharding.shard_sizes(spec["total"], world)
+            shards = [parts] + [make_parts(g, geo, bounds, sizes[r], 12345 + r, spec["reflect"]) for r in range(1, world)]
+            allp = {k: np.concatenate([s[k] for s in shards]) if shards[0][k].ndim == 1
+                    else np.asfortranarray(np.vstack([s[k] for s in shards])) for k in parts}
+            del shards
+            cfg1 = config_for(spec["total"], spec["turb"])
+            e1, run1 = make_engine(ltrans_amd, cfg1, g, geo, bounds, allp, records)
+            st1 = Stepper(e1, run1, cfg1)
+            k1 = max(2, min(args.steps, 5))
+
+            def step1():
+                e1.update_particles(st1.ex, st1.next_times(), st1.p, st1.it)
+
+            def fence1():
+                e1.sync()
+
+            step1(); step1(); fence1()
+            w1, _ = timed_steps(st1, k1, step1, fence1)
+            out["config"]["single_gpu_same_workload"] = {
+                "value": spec["total"] * k1 / w1, "unit": "particle-steps/s", "ms_per_step": w1 / k1 * 1e3, "steps": k1,
+                "note": "all the particles on rank 0's GPU alone, no all-gather"}
+            e1.close()
+        dist.barrier()
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(ltrans_amd, args, vi, uj, us, g, geo, bounds, records)
+        out["cpu_baseline"] = cpu_baseline(ltrans_amd, args, spec, g, geo, bounds, records)
     elif rank == 0:
         out["cpu_baseline"] = None
-    e.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -275,6 +275,9 @@ int lt_create(const lt_config *cfg, lt_engine **out);
 int lt_destroy(lt_engine *e);
 const char *lt_last_error(const lt_engine *e);     /* NUL-terminated, engine-owned */
 int lt_abi_version(void);
+/* hash of the kernel sources the library was built from (profiles/<tag>/pmc.json records the one
+ * its counters were collected with; "unknown" for a build outside __graft_entry__.build()) */
+const char *lt_source_hash(void);
 
 /* uploads: replace the module state the path reads ----------------------- */
 int lt_set_grid(lt_engine *e, const lt_grid *g);            /* after initGrid      */
@@ -311,6 +314,10 @@ int lt_get_rng(lt_engine *e, int32_t *mt624, int32_t *mti);
  * and the total over all shards.  Defaults: 0 and the shard's own count. */
 int lt_count_active(lt_engine *e, const double *ix3, int64_t *n_active);
 int lt_set_rng_window(lt_engine *e, int64_t active_before, int64_t active_total);
+/* The same window for every following step, until a window is set again: for runs in which no
+ * particle can stop drawing (nothing unreleased, no settlement, mortality or open boundary), where
+ * the shards' counts never change and need not be exchanged before each step. */
+int lt_set_rng_window_static(lt_engine *e, int64_t active_before, int64_t active_total);
 /* Behaviours 1-5 draw a data-dependent number of deviates per particle
  * (genrand_real1, behavior_module.f90:256-452), so a shard's place in the stream is a
  * number of DRAWS: lt_count_draws runs the first part of the step (the gates, the element

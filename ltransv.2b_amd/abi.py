@@ -180,5 +180,5 @@ ENTRY_POINTS = [
     "step", "sync", "get_stats", "get_particles", "get_output",
     "build_adjacency", "locate_particles", "create_polyspecs", "get_polyspecs",
 ]
-HIP_ONLY_ENTRY_POINTS = ["last_error", "abi_version", "pack_positions", "stream",
+HIP_ONLY_ENTRY_POINTS = ["last_error", "abi_version", "source_hash", "set_rng_window_static", "pack_positions", "stream",
                          "profile_begin", "profile_end", "get_counters"]

@@ -85,6 +85,8 @@ struct lt_engine {
   uint32_t mt[624];
   int32_t mti = 624;
   int64_t rng_before = 0, rng_total = -1;
+  bool rng_static = false;  // lt_set_rng_window_static: the window holds until it is set again
+  int64_t rng_static_before = 0, rng_static_total = -1;
   bool rng_ready = false;
   uint64_t rng_cur = 624;          // next stream word to be consumed
   long long rng_next_block = 0;    // next block to generate
@@ -659,6 +661,11 @@ extern "C" {
 int lt_abi_version(void) { return LT_ABI_VERSION; }
 
 const char* lt_last_error(const lt_engine* e) { return e ? e->err : "null engine"; }
+
+#ifndef LT_SOURCE_HASH
+#define LT_SOURCE_HASH "unknown"
+#endif
+const char* lt_source_hash(void) { return LT_SOURCE_HASH; }
 
 int lt_create(const lt_config* cfg, lt_engine** out) {
   if (!cfg || !out) return LT_ERR_ARG;
@@ -1776,6 +1783,16 @@ int lt_set_rng_window(lt_engine* e, int64_t active_before, int64_t active_total)
   const int64_t D = (e->cfg.HTurbOn ? 4 : 0) + (e->cfg.VTurbOn ? 2 * (e->cfg.idt / 2) : 0);
   e->rng_before = active_before * D;
   e->rng_total = active_total * D;
+  e->rng_static = false;
+  return LT_OK;
+}
+
+int lt_set_rng_window_static(lt_engine* e, int64_t active_before, int64_t active_total) {
+  const int rc = lt_set_rng_window(e, active_before, active_total);
+  if (rc != LT_OK) return rc;
+  e->rng_static = active_total > 0;
+  e->rng_static_before = e->rng_before;
+  e->rng_static_total = e->rng_total;
   return LT_OK;
 }
 
@@ -1919,8 +1936,8 @@ int lt_step(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32
       P.rng_mask = (unsigned long long)e->rng_R * RNG_S - 1ull;
       P.rng_base = base;
       e->rng_cur += (uint64_t)total;
-      e->rng_total = -1;
-      e->rng_before = 0;
+      e->rng_total = e->rng_static ? e->rng_static_total : -1;
+      e->rng_before = e->rng_static ? e->rng_static_before : 0;
       e->stats.rng_draws = own;
     }
     // lt_profile_* times the dominant kernel(s) of the configuration: the three VTurb kernels when

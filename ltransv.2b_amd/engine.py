@@ -362,7 +362,20 @@ class Engine:
         self._check(self._fn["set_rng_window_draws"](self._h, C.c_int64(int(draws_before)),
                                                      C.c_int64(int(draws_total))), "set_rng_window_draws")
 
-    def set_rng_window(self, active_before, active_total):
+    def source_hash(self):
+        f = self.lib.lt_source_hash
+        f.restype = C.c_char_p
+        return f().decode()
+
+    def set_rng_window(self, active_before, active_total, persistent=False):
+        if persistent:
+            f = self.lib.lt_set_rng_window_static
+            f.restype = C.c_int
+            self._check(f(self._h, C.c_int64(int(active_before)), C.c_int64(int(active_total))), "set_rng_window_static")
+            return
+        return self._set_rng_window(active_before, active_total)
+
+    def _set_rng_window(self, active_before, active_total):
         self._check(self._fn["set_rng_window"](self._h, C.c_int64(int(active_before)),
                                                C.c_int64(int(active_total))), "set_rng_window")
 

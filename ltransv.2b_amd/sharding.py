@@ -55,7 +55,7 @@ def rng_window(dist, torch, n_active_local, world, rank, device="cpu"):
     if world > 1:
         allc = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allc, mine)
-        counts = [int(c.item()) for c in allc]
+        counts = torch.cat(allc).tolist()          # one device-to-host read for all ranks
     else:
         counts = [int(n_active_local)]
     return int(np.sum(counts[:rank])), int(np.sum(counts))

@@ -1,0 +1,72 @@
+"""bench.py's own multi-rank launch: `python bench.py --gpus N` with no launcher around it must start
+N ranks itself (before anything touches the GPU), relay rank 0's line and fail when a rank fails; a
+WORLD_SIZE that disagrees with --gpus is an error.  CPU part: the launcher alone (gloo rendezvous of the
+children).  GPU part: the 2-rank rehearsal of the benchmark itself on one card (LT_BENCH_BACKEND=gloo:
+the ranks share the GPU, the all-gather goes through host memory), on a small grid with the structure
+of BASELINE configs[3] (turbulence, strong scaling, the shards' windows of the serial random stream)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env_extra=None, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, BENCH] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def _json_line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_launcher_starts_n_ranks_and_relays_rank0():
+    r = _run(["--gpus", "2", "--selftest-launch", "ok"])
+    assert r.returncode == 0, r.stderr
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["sum_ok"] is True
+
+
+def test_launcher_fails_when_a_rank_fails():
+    r = _run(["--gpus", "2", "--selftest-launch", "fail"])
+    assert r.returncode != 0
+    assert "rank 1 exited with code 3" in r.stderr
+
+
+def test_world_size_must_match_gpus():
+    r = _run(["--gpus", "2", "--selftest-launch", "ok"], {"WORLD_SIZE": "3", "RANK": "0"})
+    assert r.returncode == 2 and "WORLD_SIZE=3" in r.stderr
+
+
+@pytest.mark.gpu
+def test_two_rank_rehearsal_of_the_benchmark():
+    r = _run(["--gpus", "2", "--workload", "config4", "--grid", "128x64x20", "--numpar", "40000", "--steps", "3",
+              "--warmup", "1"], {"LT_BENCH_BACKEND": "gloo"}, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 3
+    assert d["config"]["particles_total"] == 40000 and d["config"]["particles_this_rank"] == 20000
+    assert d["config"]["baseline_config"] == "config4" and d["config"]["rng_window"] == "static"
+    assert d["config"]["errors_last_step"] == 0 and d["value"] > 0
+    assert d["config"]["single_gpu_same_workload"]["value"] > 0
+    assert d["cpu_baseline"] is None
+
+
+@pytest.mark.gpu
+def test_single_gpu_line_carries_config3_and_hash():
+    r = _run(["--steps", "3", "--warmup", "1", "--numpar", "20000", "--grid", "128x64x20", "--no-cpu-baseline",
+              "--no-hydro-timing"], timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 1 and d["config"]["baseline_config"] == "config2"
+    t = d["config"]["turbulence"]
+    assert t["value"] > 0 and t["roofline"]["kernel"] == "k_vt_table+k_vt_sigs+k_vt_walk"
+    assert len(d["config"]["kernel_source_hash"]) == 16
+    assert d["roofline"]["traffic"] is None          # not the profiled shape
