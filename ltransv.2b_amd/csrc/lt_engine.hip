@@ -85,6 +85,7 @@ struct lt_engine {
   uint32_t mt[624];
   int32_t mti = 624;
   int64_t rng_before = 0, rng_total = -1;
+  bool rng_kernels_configured = false;
   bool rng_static = false;  // lt_set_rng_window_static: the window holds until it is set again
   int64_t rng_static_before = 0, rng_static_total = -1;
   bool rng_ready = false;
@@ -494,12 +495,13 @@ const ltmt::Poly& mt_phi() {
   return phi;
 }
 
+// (the attribute is per device: every engine sets it on its own device, after hipSetDevice)
 int rng_configure_kernels(lt_engine* e) {
-  static bool done = false;
-  if (!done) {
+  if (!e->rng_kernels_configured) {
+    HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipFuncSetAttribute((const void*)ltmt::k_mt_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ltmt::LDS_BYTES));
     HIPCHK(e, hipFuncSetAttribute((const void*)ltmt::k_mt_jump, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ltmt::LDS_BYTES));
-    done = true;
+    e->rng_kernels_configured = true;
   }
   return LT_OK;
 }
@@ -677,6 +679,13 @@ int lt_create(const lt_config* cfg, lt_engine** out) {
     return LT_ERR_ARG;
   if (cfg->Behavior < 0 || cfg->Behavior > 7) return LT_ERR_UNSUPPORTED;
   if (cfg->slab_storage != LT_SLAB_F32 && cfg->slab_storage != LT_SLAB_F64) return LT_ERR_ARG;
+  {
+    // the draw offsets of a shard (prefix sum over its particles) are 32-bit: a shard may hold at most
+    // (2^31 - 1) / (4 + 2 (idt/2) + 3) particles when it draws -- 16.9M at idt = 120 (a larger run shards)
+    const int64_t per = (cfg->HTurbOn ? 4 : 0) + (cfg->VTurbOn ? 2 * (int64_t)(cfg->idt / 2) : 0) +
+                        ((cfg->Behavior >= 1 && cfg->Behavior <= 5) ? 3 : 0);
+    if (per > 0 && (int64_t)cfg->numpar * per > (int64_t)INT32_MAX) return LT_ERR_ARG;
+  }
   lt_engine* e = new (std::nothrow) lt_engine();
   if (!e) return LT_ERR_NOMEM;
   e->cfg = *cfg;
@@ -1312,7 +1321,9 @@ int lt_set_particles(lt_engine* e, const lt_particles* p) {
     TRY(put_field<int32_t>(e, e->bottom, p->bottom, 1));
     if (fresh && !p->bottom && e->cfg.Behavior == 7) {  // bottom = .TRUE., behavior_module.f90:113
       std::vector<int32_t> ones((size_t)n, 1);
-      HIPCHK(e, hipMemcpy(e->bottom.p, ones.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+      // (on the engine's stream, behind put_field's memset: a null-stream copy is not ordered against it)
+      HIPCHK(e, hipMemcpyAsync(e->bottom.p, ones.data(), (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
+      HIPCHK(e, hipStreamSynchronize(e->stream));
     }
   }
   TRY(put_field<double>(e, e->P_Salt, p->P_Salt, 1));

@@ -230,8 +230,12 @@ __global__ __launch_bounds__(256) void k_post(const StepParams P) {
     // particle is returned to its previous location as under ErrorFlag 1)
     if (err != 0) {
       c_err = 1;
-      if (P.ErrorFlag == 2) { P.dead[n] = 1; keep_pn = true; }
-      else if (P.ErrorFlag == 3) { P.oob[n] = 1; keep_pn = true; }
+      // An error of the closing setEle (27-29) is raised AFTER par(n,pnX..pnZ) took the new position
+      // (:1312-1317): die() / setOut() leave it there and the commit loop moves the particle to it.  The
+      // earlier errors (4-6, 24-26) `cycle` before that assignment: pn keeps what the last step left.
+      const bool pn_assigned = (err >= 27);
+      if (P.ErrorFlag == 2) { P.dead[n] = 1; keep_pn = !pn_assigned; }
+      else if (P.ErrorFlag == 3) { P.oob[n] = 1; keep_pn = !pn_assigned; }
       else { nX = X; nY = Y; nZ = Z; keep_pn = false; }
     }
     P.err_code[n] = err;

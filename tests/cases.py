@@ -70,6 +70,10 @@ CASES = {
     "tiny_fs_salt": dict(grid=(24, 16, 8), islands=[(10, 12, 6, 8)], numpar=512, near_land=0.6,
                          cfg=dict(Behavior=5, FreeSlip=1, SaltTempOn=1, swimstart=0.0, swimslow=0.002, swimfast=0.004,
                                   Sgradient=0.3)),
+    # horizontal random walk with steps of more than a cell: particles jump over elements (errors 27-29 of
+    # the closing setEle, LTRANS.f90:1317-1364), leave the domain (25), land on the island (26)
+    "tiny_jump": dict(grid=(24, 16, 8), islands=[(10, 12, 6, 8)], numpar=768, near_land=0.2,
+                      cfg=dict(Behavior=0, HTurbOn=1, VTurbOn=0, ConstantHTurb=6000.0)),
     # open eastern boundary, drift towards it: particles leave through open ocean
     "tiny_open": dict(grid=(24, 16, 8), islands=[], numpar=512, near_land=0.0, open_east=True,
                       drift=(0.45, 0.05), cfg=dict(Behavior=0, OpenOceanBoundary=1)),

@@ -81,6 +81,9 @@ def test_create_rejects_bad_abi_and_unsupported_options():
         assert lib.lt_create(C.byref(cfg), C.byref(h)) == -4      # LT_ERR_UNSUPPORTED
     cfg = ltrans_amd.LtConfig(numpar=4, us=8, ws=10)
     assert lib.lt_create(C.byref(cfg), C.byref(h)) == -1          # ws must be us+1
+    # a shard's draw offsets are 32-bit: 17.4M particles x 124 draws would wrap
+    cfg = ltrans_amd.LtConfig(numpar=17_400_000, us=8, ws=9, idt=120, HTurbOn=1, VTurbOn=1)
+    assert lib.lt_create(C.byref(cfg), C.byref(h)) == -1
 
 
 def test_no_cpu_fallback_without_gpu():

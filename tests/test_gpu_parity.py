@@ -51,6 +51,20 @@ def test_parity_reflection(errflag):
     assert int(ora["hitLand"].sum()) > 50, "case must exercise reflections"
 
 
+@pytest.mark.parametrize("errflag", [1, 2, 3])
+def test_parity_jumped_over_an_element(errflag):
+    """steps longer than a cell: the closing setEle fails (27-29) AFTER par(n,pn*) took the new position
+    (LTRANS.f90:1312-1317), so under ErrorFlag 2 / 3 the dead / out-of-bounds particle is moved there."""
+    case = cases.build_case("tiny_jump", ErrorFlag=errflag, mortality=1 if errflag == 2 else 0, deadage=1e9,
+                            OpenOceanBoundary=1 if errflag == 3 else 0)
+    hip, ora = _both(case, n_external=1, max_internal=6)
+    _check(hip, ora)
+    if errflag == 2:
+        assert int(ora["dead"].sum()) > 100
+    if errflag == 3:
+        assert int(ora["oob"].sum()) > 100
+
+
 def test_parity_open_ocean_boundary():
     case = cases.build_case("tiny_open")
     hip, ora = _both(case, n_external=3)
