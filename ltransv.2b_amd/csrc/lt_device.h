@@ -26,6 +26,8 @@ enum Counter : int {
   CNT_SIGERR = 2,     // spline fits that fell back to linint (SigErr /= 0)
   CNT_BRUTE = 3,      // boundary queries that used the full segment scan
   CNT_PIP_SLOW = 4,   // point-in-polygon queries that used the full algorithm
+  CNT_VT_QUEUED = 5,  // VTurb spline intervals whose tension factor needed the batched SIGS iteration
+  CNT_VT_ROUNDS = 6,  // rounds (of up to 64 intervals) of that iteration, summed over the waves
   CNT_COUNT = 8
 };
 
@@ -60,6 +62,14 @@ struct PipIndex {
 // the L1 can take per cycle, not by bytes.
 #define LT_LAYOUT_SLOTFAST 0
 #define LT_LAYOUT_LEVFAST 1
+
+// per-wave task lists of VTurb's SIGS iterations (lt_vturb.h)
+struct VtQueue {
+  double *S, *S1, *S2;      // [wave][cap]
+  unsigned short* wl;       // knot << 6 | lane
+  int* count;               // [wave]
+  int cap;
+};
 
 struct StepParams {
   // ---- particle state (device copies of the reference's arrays)
@@ -134,7 +144,8 @@ struct StepParams {
   const int* rank;                // [numpar] offset of the particle's first draw behind rng_base: exclusive
                                   // sum, in reference order, of the draws of the tracked particles
   const int* orig;                // [numpar] reference index of internal slot i
-  double* vt_x; double* vt_y; double* vt_yp; double* vt_sig;  // VTurb spline tables [4*ws][numpar]
+  double4* vt_tab;  // VTurb spline table [wave][4*ws][lane] of {x, y, yp, sigma}
+  VtQueue vt_q;     // per-wave task lists of the SIGS iterations (lt_vturb.h)
   // ---- per-step workspace exchanged between k_pre / k_rk / k_post
   unsigned char* ele_ok;  // [numpar] 1: the stored elements were found for the CURRENT position
                           //     by the setEle at the end of the previous step (LTRANS.f90:1317)

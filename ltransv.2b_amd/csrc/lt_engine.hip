@@ -94,7 +94,8 @@ struct lt_engine {
   int rng_P = 128;                 // generator states
   int rng_R = 0;                   // ring capacity in blocks (power of two)
   DevBuf rng_states, rng_ring, rng_gJ;
-  DevBuf flag, rank, scan_tmp, vt_x, vt_y, vt_yp, vt_sig;
+  DevBuf flag, rank, scan_tmp, vt_tab, vt_qS, vt_qS1, vt_qS2, vt_qwl, vt_qcount;
+  int vt_qcap = 0;
   size_t scan_tmp_bytes = 0;
   // counters
   DevBuf counters;
@@ -269,7 +270,9 @@ void fill_params(lt_engine* e, StepParams& P) {
   P.rng_mask = e->rng_R ? ((unsigned long long)e->rng_R * RNG_S - 1ull) : 0ull;
   P.rng_draws = (c.HTurbOn ? 4 : 0) + (c.VTurbOn ? 2 * (c.idt / 2) : 0);
   P.rank = (const int*)e->rank.p; P.orig = (const int*)e->orig.p;
-  P.vt_x = (double*)e->vt_x.p; P.vt_y = (double*)e->vt_y.p; P.vt_yp = (double*)e->vt_yp.p; P.vt_sig = (double*)e->vt_sig.p;
+  P.vt_tab = (double4*)e->vt_tab.p;
+  P.vt_q.S = (double*)e->vt_qS.p; P.vt_q.S1 = (double*)e->vt_qS1.p; P.vt_q.S2 = (double*)e->vt_qS2.p;
+  P.vt_q.wl = (unsigned short*)e->vt_qwl.p; P.vt_q.count = (int*)e->vt_qcount.p; P.vt_q.cap = e->vt_qcap;
   P.ele_ok = (unsigned char*)e->ele_ok.p;
   P.FreeSlip = c.FreeSlip ? 1 : 0;
   P.fsR = (const unsigned char*)e->fsR.p; P.fsU = (const unsigned char*)e->fsU.p;
@@ -748,7 +751,7 @@ int lt_destroy(lt_engine* e) {
                     &e->pv, &e->P_behave, &e->dead, &e->oob, &e->settle, &e->endpoly,
                     &e->hitBottom, &e->hitLand, &e->err_code, &e->P_swim, &e->P_pediage,
                     &e->P_deadage, &e->settletime, &e->timer, &e->P_Sprev, &e->P_zprev, &e->bottom, &e->P_Salt, &e->P_Temp, &e->S, &e->T, &e->counters, &e->ws_d, &e->ws_i, &e->orig, &e->ele_ok, &e->block_active, &e->count_slots, &e->out_cols, &e->out_hits, &e->rng_states, &e->rng_ring, &e->rng_gJ, &e->flag, &e->rank, &e->scan_tmp,
-                    &e->vt_x, &e->vt_y, &e->vt_yp, &e->vt_sig, &e->sort_keys, &e->sort_idx_in, &e->sort_idx_out,
+                    &e->vt_tab, &e->vt_qS, &e->vt_qS1, &e->vt_qS2, &e->vt_qwl, &e->vt_qcount, &e->sort_keys, &e->sort_idx_in, &e->sort_idx_out,
                     &e->sort_tmp, &e->permute_tmp};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
@@ -1287,9 +1290,14 @@ int lt_set_particles(lt_engine* e, const lt_particles* p) {
       TRY(dev_alloc(e, e->rank, (n + 1) * 4));
     }
     if (e->cfg.VTurbOn) {
-      const size_t tb = (size_t)4 * e->cfg.ws * ((n + 63) / 64 * 64) * 8;  // p2 = 4*ws knots per particle, [wave][k][lane]
-      TRY(dev_alloc(e, e->vt_x, tb)); TRY(dev_alloc(e, e->vt_y, tb));
-      TRY(dev_alloc(e, e->vt_yp, tb)); TRY(dev_alloc(e, e->vt_sig, tb));
+      // p2 = 4*ws knots per particle, [wave][knot][lane] records {x, y, yp, sigma}
+      TRY(dev_alloc(e, e->vt_tab, (size_t)4 * e->cfg.ws * ((n + 63) / 64 * 64) * 32));
+      // task lists of the SIGS iterations: room for a quarter of a wave's intervals (~9 % need one)
+      const size_t waves = (n + 63) / 64;
+      e->vt_qcap = 64 * e->cfg.ws;
+      TRY(dev_alloc(e, e->vt_qS, waves * e->vt_qcap * 8)); TRY(dev_alloc(e, e->vt_qS1, waves * e->vt_qcap * 8));
+      TRY(dev_alloc(e, e->vt_qS2, waves * e->vt_qcap * 8)); TRY(dev_alloc(e, e->vt_qwl, waves * e->vt_qcap * 2));
+      TRY(dev_alloc(e, e->vt_qcount, waves * 4 + 4));
     }
   }
   TRY(sync_perm(e));

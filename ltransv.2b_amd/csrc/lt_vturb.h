@@ -22,28 +22,30 @@ LT_DEV double draw_norm(const StepParams& P, unsigned long long idx) {
 
 // HVAL / HPVAL on a spline table in memory (element k of array a at a[k*stride]),
 // tension_module.f90:980-1253.  `il` caches the last interval like INTRVL's SAVE IL.
+// (tab: the records {x, y, yp, sigma} of one particle, knot k at tab[k * VT_TS]; zero_sig: TSPSI failed
+// before SIGS ran)
+#define VT_TS 64  // table layout [wave][knot][lane]: a wave's records of one knot are 2 KB contiguous
 template <bool DERIV>
-LT_DEV double hval_table(double T, int n, const double* x, const double* y, const double* yp,
-                         const double* sig, size_t stride, int& il) {
+LT_DEV double hval_table(double T, int n, const double4* tab, bool zero_sig, int& il) {
   int I;
-  if (T < x[0]) I = 1;
-  else if (T > x[(size_t)(n - 1) * stride]) I = n - 1;
+  if (T < tab[0].x) I = 1;
+  else if (T > tab[(size_t)(n - 1) * VT_TS].x) I = n - 1;
   else {
     // INTRVL :1287-1354: try the previous interval, else bisection
     bool hit = false;
-    if (il >= 1 && il < n) hit = (x[(size_t)(il - 1) * stride] <= T) && (T < x[(size_t)il * stride]);
+    if (il >= 1 && il < n) hit = (tab[(size_t)(il - 1) * VT_TS].x <= T) && (T < tab[(size_t)il * VT_TS].x);
     if (!hit) {
       int lo = 1, hi = n;
       while (hi > lo + 1) {
         int kk = (lo + hi) >> 1;
-        if (T < x[(size_t)(kk - 1) * stride]) hi = kk; else lo = kk;
+        if (T < tab[(size_t)(kk - 1) * VT_TS].x) hi = kk; else lo = kk;
       }
       il = lo;
     }
     I = il;
   }
-  const size_t a = (size_t)(I - 1) * stride, b = (size_t)I * stride;
-  const double X1 = x[a], X2 = x[b], Y1 = y[a], Y2 = y[b], P1 = yp[a], P2 = yp[b], SG = sig[a];
+  const double4 ra = tab[(size_t)(I - 1) * VT_TS], rb = tab[(size_t)I * VT_TS];
+  const double X1 = ra.x, X2 = rb.x, Y1 = ra.y, Y2 = rb.y, P1 = ra.z, P2 = rb.z, SG = zero_sig ? 0.0 : ra.w;
   if (X2 - X1 <= 0.0) return 0.0;  // IER = -2
   if (DERIV) return hpval_interval(T, X1, X2, Y1, Y2, P1, P2, SG);
   return hval_interval(T, X1, X2, Y1, Y2, P1, P2, SG);
@@ -90,6 +92,7 @@ LT_DEV void polintd3x3(const StepParams& P, double ya1, double ya2, double ya3,
 struct VtInterval {
   int I;
   double X1, X2, Y1, Y2, P1, P2, SG;
+  double SGhi;  // tension factor of the interval above (stored with the upper knot)
   double S, D1, D2, SM, CM, CMM;
   Divisor dx;
 };
@@ -151,70 +154,73 @@ LT_DEV double hpval_prepared(double T, const VtInterval& c) {
                 SIG * ((E1 * EMS - E2) * D1 + (E1 - E2 * EMS) * D2)) / E;
   }
 }
-LT_DEV void vt_seek(VtInterval& c, double T, int n, const double* x, const double* y,
-                    const double* yp, const double* sig, size_t stride) {
+// (a move to the neighbouring interval loads ONE 32-byte record -- the new knot; the knot shared with
+// the old interval is kept)
+LT_DEV void vt_seek(VtInterval& c, double T, int n, const double4* tab) {
   bool moved = false;
   if (c.I == 0) {  // first use: bisection
     int lo = 1, hi = n;
     while (hi > lo + 1) {
       const int kk = (lo + hi) >> 1;
-      if (T < x[(size_t)(kk - 1) * stride]) hi = kk; else lo = kk;
+      if (T < tab[(size_t)(kk - 1) * VT_TS].x) hi = kk; else lo = kk;
     }
     c.I = lo;
-    c.X1 = x[(size_t)(lo - 1) * stride];
-    c.X2 = x[(size_t)lo * stride];
+    const double4 ra = tab[(size_t)(lo - 1) * VT_TS], rb = tab[(size_t)lo * VT_TS];
+    c.X1 = ra.x; c.Y1 = ra.y; c.P1 = ra.z; c.SG = ra.w;
+    c.X2 = rb.x; c.Y2 = rb.y; c.P2 = rb.z; c.SGhi = rb.w;
     moved = true;
   }
-  while (T < c.X1 && c.I > 1) { c.I -= 1; c.X2 = c.X1; c.X1 = x[(size_t)(c.I - 1) * stride]; moved = true; }
-  while (T >= c.X2 && c.I < n - 1) { c.I += 1; c.X1 = c.X2; c.X2 = x[(size_t)c.I * stride]; moved = true; }
-  if (moved) {
-    const size_t a = (size_t)(c.I - 1) * stride, b = (size_t)c.I * stride;
-    c.Y1 = y[a]; c.Y2 = y[b]; c.P1 = yp[a]; c.P2 = yp[b]; c.SG = sig[a];
-    vt_prepare(c);
+  while (T < c.X1 && c.I > 1) {
+    c.I -= 1;
+    const double4 r = tab[(size_t)(c.I - 1) * VT_TS];
+    c.X2 = c.X1; c.Y2 = c.Y1; c.P2 = c.P1; c.SGhi = c.SG;
+    c.X1 = r.x; c.Y1 = r.y; c.P1 = r.z; c.SG = r.w;
+    moved = true;
   }
+  while (T >= c.X2 && c.I < n - 1) {
+    c.I += 1;
+    const double4 r = tab[(size_t)c.I * VT_TS];
+    c.X1 = c.X2; c.Y1 = c.Y2; c.P1 = c.P2; c.SG = c.SGhi;
+    c.X2 = r.x; c.Y2 = r.y; c.P2 = r.z; c.SGhi = r.w;
+    moved = true;
+  }
+  if (moved) vt_prepare(c);
 }
 
-// per-wave LDS queue of the spline intervals of the VTurb table whose tension
-// factor needs an iteration (SIGS, tension_module.f90:531-760)
-#define LT_VT_CAP 256
-struct VtScratch {
-  double S[LT_VT_CAP], S1[LT_VT_CAP], S2[LT_VT_CAP];
-  unsigned short where[LT_VT_CAP];  // interval index k (0-based)
-  unsigned char lane[LT_VT_CAP];
-  unsigned int failed[64];
-};
+// The spline intervals of the VTurb table whose tension factor needs an iteration (SIGS,
+// tension_module.f90:531-760; ~9 % of them) are written by the table kernel to a task list per
+// wave in HBM (S, S1, S2, knot, lane: 26 bytes) and iterated by k_vt_sigs, 64 at a time, at the
+// occupancy that kernel's few registers allow.  (Iterating them inside the table kernel -- 255
+// VGPRs, two waves per SIMD -- cost 1.2 ms per step; a kernel that re-read the whole table to
+// find them 0.95 ms.)  A wave whose list is full iterates the interval in its own lane.
 
-LT_DEV void vt_run_tasks(VtScratch& q, int ntask, int lane, int wave_first, double* vt_sig,
-                         int p2) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll 1
-  for (int t = lane; t < ntask; t += 64) {
-    double sg, T;
-    bool failed = false;
-    const int kind = sigs_classify(q.S[t], q.S1[t], q.S2[t], sg, T);
-    if (kind == SIGK_NEWTON) sg = sigs_newton(T, failed);
-    else if (kind == SIGK_SECANT) sg = sigs_secant(q.S[t], q.S1[t], q.S2[t]);
-    vt_sig[((size_t)(wave_first >> 6) * (size_t)p2 + q.where[t]) * 64 + q.lane[t]] = sg;
-    if (failed) atomicOr(&q.failed[q.lane[t]], 1u);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+// (the table kernel's overflow path: out of line, so that its registers are not the stream's)
+__device__ __noinline__ double sigs_in_lane(double S, double S1, double S2, int* failed) {
+  double sg = 0.0, T = 0.0;
+  bool f = false;
+  const int kind = sigs_classify(S, S1, S2, sg, T);
+  if (kind == SIGK_NEWTON) sg = sigs_newton(T, f);
+  else if (kind == SIGK_SECANT) sg = sigs_secant(S, S1, S2);
+  *failed = f ? 1 : 0;
+  return sg;
 }
 
-// VTurb, ver_turb_module.f90:30-380, as three kernels, one lane per particle:
-//   k_vt_table  builds the spline table of the time-interpolated, smoothed Kh profile
-//               (the register-heavy, arithmetic part);
-//   k_vt_sigs   chooses the tension factors (SIGS), iterating only the intervals that
-//               need it, 64 at a time per wave;
-//   k_vt_walk   runs the idt/2 random-walk sub-steps on the table.
+// VTurb, ver_turb_module.f90:30-380, as three kernels:
+//   k_vt_table  one lane per particle: builds the spline table of the time-interpolated, smoothed Kh
+//               profile (TSPSI's YPC1) and settles every tension factor that needs no iteration in the
+//               same stream over the knots;
+//   k_vt_sigs   one wave per task list: the SIGS iterations of the intervals that need one;
+//   k_vt_walk   one lane per particle: the idt/2 random-walk sub-steps on the table.
 // The ~30 work arrays of the reference are never materialised: the proliferated /
-// smoothed profile is produced as a stream over k (8-point window in registers),
-// the YPC1 derivative of point k-1 is formed as soon as point k exists, and only the
-// final spline table (x, y, yp, sigma)(k) goes to HBM, [wave][k][lane], so every table
-// access of the build phases is coalesced and a wave streams one contiguous block.
+// smoothed profile is produced as a stream over k (8-point window in an LDS ring),
+// the YPC1 derivative of knot k-1 is formed as soon as knot k exists, the interval (k-2, k-1)
+// is classified as soon as both its end derivatives exist -- its tension factor is zero (the
+// usual case), or it goes to the wave's task list -- and knot k-2 goes to
+// HBM as ONE 32-byte record {x, y, yp, sigma}, [wave][knot][lane]: the table is written once, in
+// 2 KB rows per wave and knot (per-lane runs of 32-byte records, [particle][knot], cost 3.6x their
+// size in HBM writes: profiles/r02_calib), and never read back by the build; the walk loads one
+// record per move to a neighbouring interval.  (Four separate arrays, re-read by a SIGS kernel and
+// gathered 8 bytes at a time by the walk, moved 14.9 GB per step for 3.5 GB of algorithmic traffic.)
 // SIGS' "RETURN at the first SigErr" leaves later tensions at 0 in the reference;
 // since SigErr switches every later evaluation to linint, which ignores the
 // tensions, computing all of them here changes nothing.
@@ -227,8 +233,11 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
   for (int i = threadIdx.x; i < 6 * LT_LEV_STRIDE; i += blockDim.x) lev[i] = P.lev[i];
   exp_table_load();
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= P.numpar || !(P.ws_i[n] & FL_ACT)) return;
-  const bool act = true;
+  const int lane = threadIdx.x & 63;
+  const int wave = n >> 6;
+  // (every lane of the wave stays to the end: the task list is filled with wave-wide ballots)
+  const int fl = (n < P.numpar) ? P.ws_i[n] : 0;
+  const bool act = (fl & FL_ACT) != 0;
   const size_t N = (size_t)P.numpar;
   const int na = act ? n : 0;
   double* wsd = P.ws_d + na;
@@ -250,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
   }
   const SlabT* K = (const SlabT*)P.Kh;
   const int pslot[3] = {P.tb, P.tc, P.tf};
-  const unsigned fsm = (P.FreeSlip && act) ? P.fsR[P.P_r_element[n] - 1] : 15u;  // free slip, :1934-1994
+  const unsigned fsm = (P.FreeSlip && act) ? P.fsR[P.P_r_element[na] - 1] : 15u;  // free slip, :1934-1994
   auto KH = [&](int s, int i) -> double {  // Pwc_KH{b,c,f}(i) :102-108
     double f1 = fld(K, rn.x, ws, i, pslot[s]), f2 = fld(K, rn.y, ws, i, pslot[s]);
     double f3 = fld(K, rn.z, ws, i, pslot[s]), f4 = fld(K, rn.w, ws, i, pslot[s]);
@@ -314,14 +323,38 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
 #pragma unroll
     for (int j = 5; j <= 8; j++) wring[s][j & 7][threadIdx.x] = NEWY(s, j);
   }
-  // table layout: [wave][k][lane], a wave streams one contiguous 4*ws*512 B block per array
-  const size_t TS = 64, toff = (size_t)(na >> 6) * (size_t)p2 * 64 + (size_t)(na & 63);
-  double* tx = P.vt_x + toff; double* ty = P.vt_y + toff; double* typ = P.vt_yp + toff;
-  // streaming YPC1 / SIGS state: previous point, previous interval, YP(k-2)
-  double xm1 = 0.0, ym1 = 0.0, Sp = 0.0, DXp = 0.0, YPp = 0.0;
+  // table layout: [wave][knot][lane] records {x, y, yp, sigma}; knot k-2 is written at iteration k
+  double4* tab = P.vt_tab + (size_t)(na >> 6) * (size_t)p2 * VT_TS + (size_t)(na & 63);
+  // streaming YPC1 / SIGS state: the two previous knots, the two previous chord slopes, YP(k-2)
+  double xm1 = 0.0, ym1 = 0.0, xm2 = 0.0, ym2 = 0.0, Sp = 0.0, DXp = 0.0, YPp = 0.0;
   bool ypc_fail = false;
+  int ntask = 0;  // wave-uniform: intervals on this wave's task list
+  const VtQueue Q = P.vt_q;
+  const size_t qb = (size_t)wave * (size_t)Q.cap;
+  bool lane_failed = false;
+  // one interval of SIGS (tension_module.f90:448-776) as soon as its end derivatives exist: tension
+  // zero, or onto the task list (the known-SBIG case goes through the list too: rare)
+  auto SIGMA = [&](bool on, double S, double S1, double S2, int where) -> double {
+    double sg_here = 0.0;  // what the owner stores with the knot (the list's results are written later)
+    const bool need = on && !sigs_eval_zero(S, S1, S2);
+    const unsigned long long m = __ballot(need);
+    if (need) {
+      const int idx = ntask + __popcll(m & ((1ull << lane) - 1ull));
+      if (idx < Q.cap) {
+        Q.S[qb + idx] = S; Q.S1[qb + idx] = S1; Q.S2[qb + idx] = S2;
+        Q.wl[qb + idx] = (unsigned short)((where << 6) | lane);
+      } else {  // list full (a profile that queues > 25 % of its intervals): iterate here, in this lane
+        int failed = 0;
+        sg_here = sigs_in_lane(S, S1, S2, &failed);
+        lane_failed = lane_failed || (failed != 0);
+      }
+    }
+    ntask += __popcll(m);
+    return sg_here;
+  };
 #pragma unroll 1
   for (int k = 1; k <= p2; k++) {
+    double xk = 0.0, yk = 0.0;
     if (act) {
       double mx[3], my[3];
 #pragma unroll
@@ -347,38 +380,52 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
       if (fyb < 0.0) fyb = 0.0;
       if (fyc < 0.0) fyc = 0.0;
       if (fyf < 0.0) fyf = 0.0;
-      const double yk = div_by(fyb + 4.0 * fyc + fyf, 6.0, P.r_6, FD);
-      const double xk = div_by(fxb + 4.0 * fxc + fxf, 6.0, P.r_6, FD);
-      tx[(size_t)(k - 1) * TS] = xk;
-      ty[(size_t)(k - 1) * TS] = yk;
-      // TSPSI(p2) as a stream: YPC1 (tension_module.f90:852-977), SIGS (:314-781)
-      if (k >= 2 && !ypc_fail) {
-        const double DX = xk - xm1;  // DX_{k-1}
-        if (DX <= 0.0) {
-          ypc_fail = true;  // YPC1 fails -> TSPSI returns IER = -4 and SIGS never runs
-          typ[(size_t)(k - 2) * TS] = 0.0;  // derivatives not reached stay 0
-        } else {
-          const double S = (yk - ym1) / DX;  // S_{k-1}
-          if (k == 3) {
-            YPp = ypc1_end(Sp, Sp + DXp * (Sp - S) / (DXp + DX));  // YP(1)
-            typ[0] = YPp;
-          }
-          if (k >= 3) {
-            const double YPc = ypc1_mid(DXp, DX, Sp, S);  // YP(k-1)
-            typ[(size_t)(k - 2) * TS] = YPc;
-            YPp = YPc;
-          }
-          if (k == p2) {
-            const double YPn = ypc1_end(S, S + DX * (S - Sp) / (DXp + DX));  // YP(N)
-            typ[(size_t)(k - 1) * TS] = YPn;
-          }
-          Sp = S;
-          DXp = DX;
-        }
+      yk = div_by(fyb + 4.0 * fyc + fyf, 6.0, P.r_6, FD);
+      xk = div_by(fxb + 4.0 * fxc + fxf, 6.0, P.r_6, FD);
+    }
+    // TSPSI(p2) as a stream: YPC1 (tension_module.f90:852-977), SIGS (:314-781).  YPC1 stops at the
+    // first non-increasing abscissa (IER = -4 of TSPSI, SIGS never runs): the derivatives found so
+    // far stay, the others and every tension factor are 0 (the walk ignores the stored tensions then).
+    bool fail_now = false;
+    double S = 0.0, DX = 0.0, YPc = 0.0, YPn = 0.0;
+    const bool live = act && !ypc_fail;
+    if (live && k >= 2) {
+      DX = xk - xm1;  // DX_{k-1}
+      if (DX <= 0.0) {
+        fail_now = true;
+      } else {
+        S = (yk - ym1) / DX;  // S_{k-1}
+        if (k == 3) YPp = ypc1_end(Sp, Sp + DXp * (Sp - S) / (DXp + DX));  // YP(1)
+        if (k >= 3) YPc = ypc1_mid(DXp, DX, Sp, S);                         // YP(k-1)
+        if (k == p2) YPn = ypc1_end(S, S + DX * (S - Sp) / (DXp + DX));     // YP(N)
       }
-      if (ypc_fail) typ[(size_t)(k - 1) * TS] = 0.0;
-      xm1 = xk;
-      ym1 = yk;
+    }
+    const bool ok = live && !fail_now;
+    // interval (k-2, k-1): chord slope S_{k-2} (still in Sp), derivatives YP(k-2), YP(k-1)
+    const double sgA = SIGMA(ok && k >= 3, Sp, YPp, YPc, k - 3);
+    // (the last interval (N-1, N) with YP(N-1), YP(N))
+    const double sgB = SIGMA(ok && k == p2, S, YPc, YPn, p2 - 2);
+    if (act) {
+      if (ok) {
+        if (k >= 3) tab[(size_t)(k - 3) * VT_TS] = make_double4(xm2, ym2, YPp, sgA);           // knot k-2, interval (k-2, k-1)
+        if (k == p2) {
+          tab[(size_t)(p2 - 2) * VT_TS] = make_double4(xm1, ym1, YPc, sgB);
+          tab[(size_t)(p2 - 1) * VT_TS] = make_double4(xk, yk, YPn, 0.0);
+        }
+      } else if (fail_now) {
+        if (k >= 3) tab[(size_t)(k - 3) * VT_TS] = make_double4(xm2, ym2, (k >= 4) ? YPp : 0.0, 0.0);
+        if (k >= 2) tab[(size_t)(k - 2) * VT_TS] = make_double4(xm1, ym1, 0.0, 0.0);
+        tab[(size_t)(k - 1) * VT_TS] = make_double4(xk, yk, 0.0, 0.0);
+        ypc_fail = true;
+      } else {  // after a failure: abscissa and ordinate only
+        tab[(size_t)(k - 1) * VT_TS] = make_double4(xk, yk, 0.0, 0.0);
+      }
+      if (ok && k >= 2) {
+        if (k >= 3) YPp = YPc;
+        Sp = S; DXp = DX;
+      }
+      xm2 = xm1; ym2 = ym1;
+      xm1 = xk; ym1 = yk;
       // slide the 8-point window: drop newy(k), append newy(k+8)
       if (k + 8 <= p2 + 7) {
 #pragma unroll
@@ -388,75 +435,46 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
       }
     }
   }
-  if (ypc_fail) P.ws_i[n] |= FL_VT_YPCFAIL;
+  if (lane == 0) {
+    Q.count[wave] = (ntask < Q.cap) ? ntask : Q.cap;
+    if (ntask) atomicAdd(&P.counters[CNT_VT_QUEUED], (unsigned long long)ntask);
+  }
+  if (act) {
+    int f2 = fl & ~(FL_VT_YPCFAIL | FL_VT_SIGERR);
+    if (ypc_fail) f2 |= FL_VT_YPCFAIL;
+    else if (lane_failed) f2 |= FL_VT_SIGERR;
+    if (f2 != fl) P.ws_i[n] = f2;
+  }
 }
 
-// SIGS over the finished tables (tension_module.f90:314-781): intervals whose tension
-// is known without iterating are stored at once, the others are queued for the wave.
-// Whole waves stay converged (ballots); a particle whose YPC1 failed is skipped: TSPSI
-// returned IER = -4 before SIGS, so its tensions stay 0 and SigErr = 0.
+// The SIGS iterations (tension_module.f90:531-760) of the listed intervals, one wave per list, 64 at a
+// time; the tension factor goes into the knot's record, a failed convexity iteration (SigErr) into the
+// particle's flag word.
 __global__ __launch_bounds__(256) void k_vt_sigs(const StepParams P) {
-  __shared__ VtScratch vsc[4];
   exp_table_load();
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  const int wave_first = n - lane;
-  VtScratch& q = vsc[threadIdx.x >> 6];
-  q.failed[lane] = 0;
-  const int fl = (n < P.numpar) ? P.ws_i[n] : 0;
-  const bool act = (fl & FL_ACT) != 0;
-  const bool ypc_fail = (fl & FL_VT_YPCFAIL) != 0;
-  const int na = act ? n : 0;
-  const int p2 = 4 * P.ws;
-  const size_t TS = 64, toff = (size_t)(na >> 6) * (size_t)p2 * 64 + (size_t)(na & 63);
-  const double* tx = P.vt_x + toff; const double* ty = P.vt_y + toff; const double* typ = P.vt_yp + toff;
-  double* tsg = P.vt_sig + toff;
-  int ntask = 0;  // wave-uniform
-  {
-    double x0 = 0.0, y0 = 0.0, p0 = 0.0;
-    const bool run = act && !ypc_fail;
-    if (act && ypc_fail)
-      for (int k = 0; k < p2 - 1; k++) tsg[(size_t)k * TS] = 0.0;
-    if (run) { x0 = tx[0]; y0 = ty[0]; p0 = typ[0]; }
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = gid >> 6;
+  if ((size_t)wave * 64 >= (size_t)P.numpar) return;
+  const VtQueue Q = P.vt_q;
+  const int count = Q.count[wave], p2 = 4 * P.ws;
+  const size_t qb = (size_t)wave * (size_t)Q.cap;
+  unsigned rounds = 0;
 #pragma unroll 1
-    for (int k0 = 0; k0 < p2 - 1; k0 += 4) {
-      // the table comes back from HBM: 12 loads in flight per lane, then the arithmetic
-      double xs[4], ys[4], ps[4];
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int kk = (k0 + j + 1 < p2) ? (k0 + j + 1) : (p2 - 1);
-        xs[j] = ys[j] = ps[j] = 0.0;
-        if (run) { xs[j] = tx[(size_t)kk * TS]; ys[j] = ty[(size_t)kk * TS]; ps[j] = typ[(size_t)kk * TS]; }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        if (k0 + j < p2 - 1) {
-          if (ntask > LT_VT_CAP - 64) {
-            vt_run_tasks(q, ntask, lane, wave_first, P.vt_sig, p2);
-            ntask = 0;
-          }
-          double S = 0.0, sg = 0.0;
-          bool need = false;
-          if (run) {
-            S = (ys[j] - y0) / (xs[j] - x0);
-            need = !sigs_eval_known(S, p0, ps[j], sg);
-            if (!need) tsg[(size_t)(k0 + j) * TS] = sg;
-          }
-          const unsigned long long m = __ballot(need);
-          if (need) {
-            const int idx = ntask + __popcll(m & ((1ull << lane) - 1ull));
-            q.S[idx] = S; q.S1[idx] = p0; q.S2[idx] = ps[j];
-            q.where[idx] = (unsigned short)(k0 + j);
-            q.lane[idx] = (unsigned char)lane;
-          }
-          ntask += __popcll(m);
-          x0 = xs[j]; y0 = ys[j]; p0 = ps[j];
-        }
-      }
+  for (int t = lane; t - lane < count; t += 64) {
+    rounds += 1;
+    if (t < count) {
+      const double S = Q.S[qb + t], S1 = Q.S1[qb + t], S2 = Q.S2[qb + t];
+      const unsigned wl = Q.wl[qb + t];
+      double sg = 0.0, T = 0.0;
+      bool failed = false;
+      const int kind = sigs_classify(S, S1, S2, sg, T);
+      if (kind == SIGK_NEWTON) sg = sigs_newton(T, failed);
+      else if (kind == SIGK_SECANT) sg = sigs_secant(S, S1, S2);
+      P.vt_tab[((size_t)wave * (size_t)p2 + (wl >> 6)) * VT_TS + (wl & 63u)].w = sg;
+      if (failed) atomicOr(&P.ws_i[(size_t)wave * 64 + (wl & 63u)], (int)FL_VT_SIGERR);
     }
   }
-  vt_run_tasks(q, ntask, lane, wave_first, P.vt_sig, p2);
-  if (act && q.failed[lane]) P.ws_i[n] = fl | FL_VT_SIGERR;
+  if (lane == 0 && rounds) atomicAdd(&P.counters[CNT_VT_ROUNDS], (unsigned long long)rounds);
 }
 
 // :282-335 random displacement model, idt/2 sub-steps of 2 s
@@ -473,9 +491,7 @@ __global__ __launch_bounds__(256) void k_vt_walk(const StepParams P) {
   const size_t N = (size_t)P.numpar;
   double* wsd = P.ws_d + n;
   const int p2 = 4 * P.ws;
-  const size_t TS = 64, toff = (size_t)(n >> 6) * (size_t)p2 * 64 + (size_t)(n & 63);
-  const double* tx = P.vt_x + toff; const double* ty = P.vt_y + toff; const double* typ = P.vt_yp + toff;
-  const double* tsg = P.vt_sig + toff;
+  const double4* tab = P.vt_tab + (size_t)(n >> 6) * (size_t)p2 * VT_TS + (size_t)(n & 63);
   const double P_depth = wsd[(size_t)WS_PDEPTH * N], P_zc = wsd[(size_t)WS_PZ1 * N];
   const double P_zetac = wsd[(size_t)WS_ZETA1 * N];
   // :282-335 random displacement model, idt/2 sub-steps of 2 s
@@ -487,7 +503,7 @@ __global__ __launch_bounds__(256) void k_vt_walk(const StepParams P) {
   double ParZc = P_zc;
   int il = 1;
   VtInterval ci;
-  ci.I = 0; ci.X1 = ci.X2 = ci.Y1 = ci.Y2 = ci.P1 = ci.P2 = ci.SG = 0.0;
+  ci.I = 0; ci.X1 = ci.X2 = ci.Y1 = ci.Y2 = ci.P1 = ci.P2 = ci.SG = ci.SGhi = 0.0;
   ci.S = ci.D1 = ci.D2 = ci.SM = ci.CM = ci.CMM = 0.0; ci.dx.b = 1.0; ci.dx.y = 1.0;
   const bool cached = (sigerr == 0) && !ypc_fail;
 #pragma unroll 1
@@ -519,11 +535,11 @@ __global__ __launch_bounds__(256) void k_vt_walk(const StepParams P) {
     double Kprimec = 0.0;
     if (!(ParZc < P_depth || ParZc > P_zetac)) {
       if (cached) {
-        vt_seek(ci, ParZc, p2, tx, ty, typ, tsg, TS);
+        vt_seek(ci, ParZc, p2, tab);
         Kprimec = hpval_prepared(ParZc, ci);
       } else if (sigerr == 0) {
-        Kprimec = hval_table<true>(ParZc, p2, tx, ty, typ, tsg, TS, il);
-      } else { double yy; linint_n(tx, ty, p2, (int)TS, ParZc, yy, Kprimec); }
+        Kprimec = hval_table<true>(ParZc, p2, tab, ypc_fail, il);
+      } else { double yy; linint_n(&tab[0].x, &tab[0].y, p2, 4 * VT_TS, ParZc, yy, Kprimec); }
     }
     const double KprimeZc = -1.0 * Kprimec * deltat;
     const double Z3rdc = ParZc + 0.5 * KprimeZc;
@@ -532,11 +548,11 @@ __global__ __launch_bounds__(256) void k_vt_walk(const StepParams P) {
       KH3rdc = background;
     } else {
       if (cached) {
-        vt_seek(ci, Z3rdc, p2, tx, ty, typ, tsg, TS);
+        vt_seek(ci, Z3rdc, p2, tab);
         KH3rdc = hval_prepared(Z3rdc, ci);
       } else if (sigerr == 0) {
-        KH3rdc = hval_table<false>(Z3rdc, p2, tx, ty, typ, tsg, TS, il);
-      } else { double mm; linint_n(tx, ty, p2, (int)TS, Z3rdc, KH3rdc, mm); }
+        KH3rdc = hval_table<false>(Z3rdc, p2, tab, ypc_fail, il);
+      } else { double mm; linint_n(&tab[0].x, &tab[0].y, p2, 4 * VT_TS, Z3rdc, KH3rdc, mm); }
       if (KH3rdc < background) KH3rdc = background;
     }
     // norm(), norm_module.f90:25-39

@@ -436,7 +436,7 @@ class Engine:
         a = np.zeros(8, dtype=np.uint64)
         self._check(f(self._h, a.ctypes.data_as(C.c_void_p)), "get_counters")
         return {"active": int(a[0]), "errors": int(a[1]), "sigerr": int(a[2]),
-                "brute_bounds": int(a[3]), "pip_full": int(a[4])}
+                "brute_bounds": int(a[3]), "pip_full": int(a[4]), "vt_queued": int(a[5]), "vt_rounds": int(a[6])}
 
     def stream(self):
         f = self.lib.lt_stream
