@@ -240,10 +240,10 @@ def behaviour_cfg(behavior, settle):
     return kw
 
 
-def make_engine(ltrans_amd, cfg, g, geo, bounds, parts, records, **kw):
+def make_engine(ltrans_amd, cfg, g, geo, bounds, parts, records, engine_cls=None):
     from ltrans_amd import roms_synth as rs
     from ltrans_amd.driver import LtransRun
-    e = ltrans_amd.Engine(cfg, **kw)
+    e = (engine_cls or ltrans_amd.Engine)(cfg)
     e.set_grid(geo)
     e.set_bounds(bounds)
     if cfg.settlementon:
@@ -366,8 +366,7 @@ def cpu_baseline(ltrans_amd, args, spec, g, geo, bounds, records):
     turb = 1 if spec["turb"] else 0
     cfg = ltrans_amd.LtConfig(numpar=n, us=spec["us"], ws=spec["us"] + 1, dt=3600, idt=120,
                               ErrorFlag=1, HTurbOn=turb, VTurbOn=turb, **behaviour_cfg(spec["behavior"], spec["settle"]))
-    e, run = make_engine(ltrans_amd, cfg, g, geo, bounds, parts, records,
-                         lib=oracle_lib.load_oracle(), prefix="lto_")
+    e, run = make_engine(ltrans_amd, cfg, g, geo, bounds, parts, records, engine_cls=oracle_lib.OracleEngine)
     ex = run.external_times(2)
     t0 = time.perf_counter()
     for it in range(1, args.cpu_steps + 1):

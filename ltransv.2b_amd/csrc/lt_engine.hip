@@ -1581,6 +1581,9 @@ int lt_get_rng(lt_engine* e, int32_t* mt624, int32_t* mti) {
   return LT_OK;
 }
 
+/* ---- test aids: only in the test build (-DLT_TEST_HOOKS -> libltrans_hip_test.so, tests/hip_test_lib.py); the
+ * product library exports none of them ---- */
+#ifdef LT_TEST_HOOKS
 /* test aid (host only, no device): n tempered words of the stream that starts at
  * the given (mt, mti) state, beginning `offset` words after the next draw, computed
  * with the polynomial jump-ahead that positions the device generators. */
@@ -1638,7 +1641,9 @@ int lt_test_div(const double* a, const double* b, double* q_fast, double* q_ref,
  * sigs_newton / sigs_secant (3), SigErr flag, HVAL at the 8 points through hval_cubic_d (zero tension) or hval_interval_s (8;
  * the last 5 unused).  kind 5: x -> exp_core(x), lt_exp(x) (the host-libm-exact exp).  kind 6: x -> lt_log, lt_log10,
  * lt_pow_half, lt_cos, lt_sin, lt_sincos (sin, cos), lt_atan of lt_libm.h.  kind 7: the free-slip
- * substitution, rows (kind, water mask m, v-grid diagonal mask d, v1..v4) -> v1..v4. */
+ * substitution, rows (kind, water mask m, v-grid diagonal mask d, v1..v4) -> v1..v4.
+ * kind 9: linint over n <= 124 points in the strided form of VTurb's SigErr fallback (linint_n) and, for
+ * n = 4, the register form of k_rk_slow (linint4): rows (n, t, x[124], y[124]) -> value, slope, value4. */
 __global__ void k_test_leaf(int kind, const double* in, double* out, int n) {
   using namespace ltd;
   libm_tables_load<LM_EXP | LM_LOG | LM_POW | LM_SINCOS>();
@@ -1718,6 +1723,17 @@ __global__ void k_test_leaf(int kind, const double* in, double* out, int n) {
     o[3] = lt_cos(x); o[4] = lt_sin(x);
     lt_sincos(x, &o[5], &o[6]);
     o[7] = lt_atan_g(x);
+  } else if (kind == 9) {
+    const double* r = in + (size_t)i * 250;
+    const int nn = (int)r[0];
+    double y = 0.0, m = 0.0;
+    linint_n(r + 2, r + 126, nn, 1, r[1], y, m);
+    double* o = out + 3 * (size_t)i;
+    o[0] = y; o[1] = m; o[2] = 0.0;
+    if (nn == 4) {
+      const double xa[4] = {r[2], r[3], r[4], r[5]}, ya[4] = {r[126], r[127], r[128], r[129]};
+      o[2] = linint4(xa, ya, r[1]);
+    }
   } else if (kind == 7) {  // free-slip substitution: rows (kind, m, d, v1..v4) -> v1..v4
     const double* r = in + (size_t)i * 7;
     double v1 = r[3], v2 = r[4], v3 = r[5], v4 = r[6];
@@ -1727,8 +1743,8 @@ __global__ void k_test_leaf(int kind, const double* in, double* out, int n) {
   }
 }
 int lt_test_leaf(int32_t kind, const double* in, int32_t n, int32_t in_per_item, double* out, int32_t out_per_item) {
-  if (!in || !out || n < 0 || kind < 1 || kind > 7) return LT_ERR_ARG;
-  const int expect_in[8] = {0, 7, 10, 1, 16, 1, 1, 7}, expect_out[8] = {0, 1, 1, 3, 37, 2, 8, 4};
+  if (!in || !out || n < 0 || kind < 1 || kind > 9 || kind == 8) return LT_ERR_ARG;
+  const int expect_in[10] = {0, 7, 10, 1, 16, 1, 1, 7, 0, 250}, expect_out[10] = {0, 1, 1, 3, 37, 2, 8, 4, 0, 3};
   if (in_per_item != expect_in[kind] || out_per_item != expect_out[kind]) return LT_ERR_ARG;
   double *di = nullptr, *dout = nullptr;
   const size_t bi = (size_t)n * in_per_item * 8, bo = (size_t)n * out_per_item * 8;
@@ -1762,6 +1778,130 @@ int lt_test_mt_ring(lt_engine* e, uint64_t offset, int32_t n, uint32_t* out) {
   for (int i = 0; i < n; i++) out[i] = ltmt::temper(tmp[i]);
   return LT_OK;
 }
+
+
+/* test aid (device): inpoly (point_in_polygon_module.f90:25-167) for nq points against ONE closed polygon,
+ * through the two forms the engine uses: the reference-shaped inpoly_full (onin = -1 absent / 1: on the
+ * boundary counts as inside; 0: as outside) and the y-slab edge index of mbounds (lt_set_bounds builds it
+ * with the same build_pip_index), which hands a point whose ray passes through a vertex to the full form.
+ * out_full[q], out_index[q] (0/1; -1 where the indexed form does not apply: onin = 0), out_slow[q]. */
+__global__ void k_test_inpoly(const StepParams P, const double* qx, const double* qy, const int* onin, int nq,
+                              int* out_full, int* out_index, int* out_slow) {
+  using namespace ltd;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  out_full[i] = inpoly_full(qx[i], qy[i], P.maxbound, P.bx, P.by, onin[i] == 0) ? 1 : 0;
+  out_index[i] = -1; out_slow[i] = 0;
+  if (onin[i] != 0) {
+    bool slow = false;
+    bool in = mbounds_indexed(P, qx[i], qy[i], slow);
+    if (slow) in = inpoly_full(qx[i], qy[i], P.maxbound, P.bx, P.by, false);
+    out_index[i] = in ? 1 : 0;
+    out_slow[i] = slow ? 1 : 0;
+  }
+}
+int lt_test_inpoly(const double* px, const double* py, int32_t npts, const double* qx, const double* qy,
+                   const int32_t* onin, int32_t nq, int32_t* out_full, int32_t* out_index, int32_t* out_slow) {
+  if (!px || !py || npts < 3 || !qx || !qy || !onin || nq < 0) return LT_ERR_ARG;
+  PipIndex I; HostIndex H;
+  build_pip_index(py, npts, [](int) { return true; }, I, H);
+  double *dpx, *dpy, *dqx, *dqy; int *dptr, *dids, *donin, *o1, *o2, *o3;
+  const size_t nb = (size_t)npts * 8, qb = (size_t)nq * 8 + 8, ib = (size_t)nq * 4 + 4;
+  if (hipMalloc(&dpx, nb) != hipSuccess || hipMalloc(&dpy, nb) != hipSuccess || hipMalloc(&dqx, qb) != hipSuccess ||
+      hipMalloc(&dqy, qb) != hipSuccess || hipMalloc(&dptr, H.ptr.size() * 4 + 4) != hipSuccess ||
+      hipMalloc(&dids, H.ids.size() * 4 + 4) != hipSuccess || hipMalloc(&donin, ib) != hipSuccess ||
+      hipMalloc(&o1, ib) != hipSuccess || hipMalloc(&o2, ib) != hipSuccess || hipMalloc(&o3, ib) != hipSuccess)
+    return LT_ERR_NOMEM;
+  (void)hipMemcpy(dpx, px, nb, hipMemcpyHostToDevice); (void)hipMemcpy(dpy, py, nb, hipMemcpyHostToDevice);
+  (void)hipMemcpy(dqx, qx, (size_t)nq * 8, hipMemcpyHostToDevice); (void)hipMemcpy(dqy, qy, (size_t)nq * 8, hipMemcpyHostToDevice);
+  (void)hipMemcpy(donin, onin, (size_t)nq * 4, hipMemcpyHostToDevice);
+  (void)hipMemcpy(dptr, H.ptr.data(), H.ptr.size() * 4, hipMemcpyHostToDevice);
+  (void)hipMemcpy(dids, H.ids.data(), H.ids.size() * 4, hipMemcpyHostToDevice);
+  StepParams P;
+  memset(&P, 0, sizeof(P));
+  P.bx = dpx; P.by = dpy; P.maxbound = npts;
+  P.pip_main = I; P.pip_main.ptr = dptr; P.pip_main.ids = dids;
+  if (nq) hipLaunchKernelGGL(k_test_inpoly, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, 0, P, dqx, dqy, donin, (int)nq, o1, o2, o3);
+  const hipError_t rc = hipDeviceSynchronize();
+  (void)hipMemcpy(out_full, o1, (size_t)nq * 4, hipMemcpyDeviceToHost);
+  (void)hipMemcpy(out_index, o2, (size_t)nq * 4, hipMemcpyDeviceToHost);
+  (void)hipMemcpy(out_slow, o3, (size_t)nq * 4, hipMemcpyDeviceToHost);
+  for (void* q : {(void*)dpx, (void*)dpy, (void*)dqx, (void*)dqy, (void*)dptr, (void*)dids, (void*)donin, (void*)o1, (void*)o2, (void*)o3}) (void)hipFree(q);
+  return rc == hipSuccess ? LT_OK : LT_ERR_DEVICE;
+}
+
+/* test aid (device): N-knot tension splines (N = 4*ws in VTurb) through the forms the VTurb kernels use: the
+ * streaming YPC1 of k_vt_table (ypc1_end / ypc1_mid in knot order), its screening of every interval
+ * (sigs_eval_zero) with the task-list iteration of k_vt_sigs (sigs_classify + sigs_newton / sigs_secant), the
+ * table layout [wave][knot][lane], and the walk's cached-interval evaluation (vt_seek + hval_prepared /
+ * hpval_prepared) at 8 points per profile.  in: per profile (n, x[124], y[124], t[8]) = 257 doubles; out: per
+ * profile yp[124], sigma[124], SigErr, hval[8], hpval[8] = 265 doubles. */
+__global__ void k_test_spline_n(const double* in, double* out, double4* tab, int nprof, int maxn) {
+  using namespace ltd;
+  libm_tables_load<LM_EXP>();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nprof) return;
+  const double* r = in + (size_t)i * 257;
+  double* o = out + (size_t)i * 265;
+  const int n = (int)r[0];
+  const double *X = r + 1, *Y = r + 125, *T = r + 249;
+  double4* t = tab + (size_t)(i >> 6) * (size_t)maxn * VT_TS + (size_t)(i & 63);
+  // YPC1 in the stream's order
+  double Sp = 0.0, DXp = 0.0, YPp = 0.0;
+  bool fail = false;
+  for (int k = 1; k <= n; k++) t[(size_t)(k - 1) * VT_TS] = make_double4(X[k - 1], Y[k - 1], 0.0, 0.0);
+  for (int k = 2; k <= n && !fail; k++) {
+    const double DX = X[k - 1] - X[k - 2];
+    if (DX <= 0.0) { fail = true; break; }
+    const double S = (Y[k - 1] - Y[k - 2]) / DX;
+    if (k == 3) { YPp = ypc1_end(Sp, Sp + DXp * (Sp - S) / (DXp + DX)); t[0].z = YPp; }
+    if (k >= 3) { const double YPc = ypc1_mid(DXp, DX, Sp, S); t[(size_t)(k - 2) * VT_TS].z = YPc; YPp = YPc; }
+    if (k == n) t[(size_t)(k - 1) * VT_TS].z = ypc1_end(S, S + DX * (S - Sp) / (DXp + DX));
+    Sp = S; DXp = DX;
+  }
+  int sigerr = 0;
+  if (!fail) {
+    for (int k = 0; k < n - 1 && !sigerr; k++) {   // SIGS returns at the first failure: later tensions stay 0
+      const double4 a = t[(size_t)k * VT_TS], b = t[(size_t)(k + 1) * VT_TS];
+      const double S = (b.y - a.y) / (b.x - a.x);
+      double sg = 0.0;
+      if (!sigs_eval_zero(S, a.z, b.z)) {
+        double TT = 0.0;
+        bool failed = false;
+        const int kind = sigs_classify(S, a.z, b.z, sg, TT);
+        if (kind == SIGK_NEWTON) sg = sigs_newton(TT, failed);
+        else if (kind == SIGK_SECANT) sg = sigs_secant(S, a.z, b.z);
+        if (failed) { sigerr = 1; sg = 0.0; }
+      }
+      t[(size_t)k * VT_TS].w = sg;
+    }
+  }
+  for (int k = 0; k < n; k++) { o[k] = t[(size_t)k * VT_TS].z; o[124 + k] = t[(size_t)k * VT_TS].w; }
+  o[248] = (double)sigerr;
+  VtInterval ci;
+  ci.I = 0; ci.X1 = ci.X2 = ci.Y1 = ci.Y2 = ci.P1 = ci.P2 = ci.SG = ci.SGhi = 0.0;
+  ci.S = ci.D1 = ci.D2 = ci.SM = ci.CM = ci.CMM = 0.0; ci.dx.b = 1.0; ci.dx.y = 1.0;
+  for (int j = 0; j < 8; j++) {
+    vt_seek(ci, T[j], n, t);
+    o[249 + j] = hval_prepared(T[j], ci);
+    o[257 + j] = hpval_prepared(T[j], ci);
+  }
+}
+int lt_test_spline_n(const double* in, int32_t nprof, double* out) {
+  if (!in || !out || nprof < 0) return LT_ERR_ARG;
+  double *di, *dout; double4* tab;
+  const size_t bi = (size_t)nprof * 257 * 8 + 8, bo = (size_t)nprof * 265 * 8 + 8;
+  const size_t tb = (size_t)((nprof + 63) / 64) * 124 * 64 * 32 + 32;
+  if (hipMalloc(&di, bi) != hipSuccess || hipMalloc(&dout, bo) != hipSuccess || hipMalloc(&tab, tb) != hipSuccess) return LT_ERR_NOMEM;
+  (void)hipMemcpy(di, in, (size_t)nprof * 257 * 8, hipMemcpyHostToDevice);
+  (void)hipMemset(dout, 0, bo);
+  if (nprof) hipLaunchKernelGGL(k_test_spline_n, dim3((unsigned)((nprof + 63) / 64)), dim3(64), 0, 0, di, dout, tab, (int)nprof, 124);
+  const hipError_t rc = hipDeviceSynchronize();
+  (void)hipMemcpy(out, dout, (size_t)nprof * 265 * 8, hipMemcpyDeviceToHost);
+  (void)hipFree(di); (void)hipFree(dout); (void)hipFree(tab);
+  return rc == hipSuccess ? LT_OK : LT_ERR_DEVICE;
+}
+#endif  /* LT_TEST_HOOKS */
 
 static int ready_to_step(lt_engine* e) {
   if (!e->have_grid || !e->have_particles) return fail(e, LT_ERR_STATE, "grid / particles missing");

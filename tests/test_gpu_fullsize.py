@@ -44,7 +44,7 @@ def world():
 def _engine(world, lo, hi, kw=None, **cfgkw):
     n = hi - lo
     cfg = ltrans_amd.LtConfig(numpar=n, us=world["us"], ws=world["us"] + 1, dt=3600, idt=120, ErrorFlag=1, **cfgkw)
-    e = ltrans_amd.Engine(cfg, **(kw or {}))
+    e = oracle_lib.engine(cfg, **(kw or {}))
     e.set_grid(world["geo"])
     e.set_bounds(world["bounds"])
     parts = {k: (v[lo:hi] if v.ndim == 1 else np.asfortranarray(v[lo:hi])) for k, v in world["parts"].items()}

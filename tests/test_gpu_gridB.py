@@ -59,7 +59,7 @@ def world():
 def _engine(world, idx, cfgkw, kw=None):
     n = idx.size
     cfg = ltrans_amd.LtConfig(numpar=n, us=world["us"], ws=world["us"] + 1, dt=3600, idt=120, ErrorFlag=1, **cfgkw)
-    e = ltrans_amd.Engine(cfg, **(kw or {}))
+    e = oracle_lib.engine(cfg, **(kw or {}))
     e.set_grid(world["geo"])
     e.set_bounds(world["bounds"])
     if cfg.settlementon:

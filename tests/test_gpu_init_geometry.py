@@ -25,7 +25,7 @@ def _engines(okw, vi, uj, islands, curvilinear=0.08, settle=False, polygons=(), 
     geo = rs.build_geometry(g)
     cfg = ltrans_amd.LtConfig(numpar=64, us=8, ws=9, dt=3600, idt=120, settlementon=1 if settle else 0,
                               holesExist=1 if holes else 0)
-    hip, ora = ltrans_amd.Engine(cfg), ltrans_amd.Engine(cfg, **okw)
+    hip, ora = ltrans_amd.Engine(cfg), oracle_lib.engine(cfg, **okw)
     hip.set_grid(geo)
     ora.set_grid(geo)
     hab = rs.make_habitat(g, geo, list(polygons), list(holes)) if polygons else None

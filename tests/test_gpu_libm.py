@@ -9,6 +9,7 @@ import math
 import numpy as np
 import pytest
 
+import hip_test_lib
 import ltrans_amd
 
 pytestmark = pytest.mark.gpu
@@ -16,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def hip_lib():
-    lib = ltrans_amd.load_hip_library()
+    lib = hip_test_lib.load()
     lib.lt_test_leaf.restype = C.c_int
     return lib
 

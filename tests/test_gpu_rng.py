@@ -7,6 +7,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
+import hip_test_lib
 import ltrans_amd
 import oracle_lib
 
@@ -27,7 +28,7 @@ def _oracle_stream(oracle, seed, skip, n):
 @pytest.mark.parametrize("seed", [9, 5489])
 def test_ring_matches_sequential_stream(oracle, seed):
     cfg = ltrans_amd.LtConfig(numpar=4, us=8, ws=9, seed=seed)
-    e = ltrans_amd.Engine(cfg)
+    e = hip_test_lib.HipTestEngine(cfg)
     f = e.lib.lt_test_mt_ring
     f.restype = C.c_int
     # offsets relative to the cursor (= first draw after init_genrand)
@@ -50,7 +51,7 @@ def test_set_rng_mid_batch(oracle):
     oracle.lto_genrand_fill(C.byref(st), C.c_uint64(0), C.c_int(1000), burn.ctypes.data_as(C.c_void_p))
     assert 0 < st.mti < 624
     cfg = ltrans_amd.LtConfig(numpar=4, us=8, ws=9)
-    e = ltrans_amd.Engine(cfg)
+    e = hip_test_lib.HipTestEngine(cfg)
     e.set_rng(np.array(st.mt, dtype=np.uint32), st.mti)
     f = e.lib.lt_test_mt_ring
     f.restype = C.c_int
@@ -67,7 +68,7 @@ def test_ring_far_into_the_stream(oracle):
     state jumped ~22 times), as a long turbulence run gets after a few dozen steps"""
     seed = 9
     cfg = ltrans_amd.LtConfig(numpar=4, us=8, ws=9, seed=seed)
-    e = ltrans_amd.Engine(cfg)
+    e = hip_test_lib.HipTestEngine(cfg)
     f = e.lib.lt_test_mt_ring
     f.restype = C.c_int
     off = 3_000_000_123

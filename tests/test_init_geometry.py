@@ -24,7 +24,7 @@ def _grid_engine(okw, name="tiny_settle", **grid_kw):
         vi, uj, us = spec["grid"]
         g = rs.make_grid(vi, uj, us, islands=spec["islands"], **grid_kw)
         case["g"], case["geo"] = g, rs.build_geometry(g)
-    e = ltrans_amd.Engine(case["cfg"], **okw)
+    e = oracle_lib.engine(case["cfg"], **okw)
     e.set_grid(case["geo"])
     return case, e
 

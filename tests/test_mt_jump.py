@@ -6,6 +6,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
+import hip_test_lib
 import ltrans_amd
 import oracle_lib
 
@@ -29,7 +30,7 @@ def _oracle_words(oracle, st, skip, n):
 @pytest.mark.parametrize("seed,burn,offset", [(9, 0, 0), (9, 0, 5000), (5489, 100, 123457),
                                                (4357, 700, 1 << 20), (9, 3, 624)])
 def test_host_jump_matches_sequential(oracle, seed, burn, offset):
-    lib = ltrans_amd.load_hip_library()
+    lib = hip_test_lib.load()
     st = _seed_state(oracle, seed, burn)
     mt = np.array(st.mt, dtype=np.uint32).view(np.int32)
     out = np.zeros(700, dtype=np.uint32)
