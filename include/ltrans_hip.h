@@ -349,6 +349,24 @@ int lt_pack_positions(lt_engine *e, void *dst_device);
 /* the engine's HIP stream (hipStream_t) for ordering external work */
 void *lt_stream(lt_engine *e);
 
+/* Multi-GPU: one process (one engine) per GPU, particles sharded by contiguous index block,
+ * fields replicated.  The one collective of the path -- the all-gather of the shards' new (x,y,z), which
+ * the reference needs as one array at print steps (LTRANS.f90:604-612) -- is done here with RCCL over xGMI,
+ * so that a Fortran host needs no other library.  The RCCL library is opened at lt_comm_init.
+ *   lt_comm_unique_id   (rank 0) 128 opaque bytes that every rank must pass to lt_comm_init; how they
+ *                       travel is the host's business (a file, MPI_Bcast, ...)
+ *   lt_comm_init_file   the same through a file: rank 0 creates `path` (atomically), the others wait
+ *                       for it up to timeout_s seconds
+ *   lt_allgather_positions  counts(nranks) = numpar of every rank; result xyz(sum(counts),3), column-major,
+ *                       shards in rank order, each in the reference's particle order, into host memory
+ *                       (xyz_host, synchronous) and / or device memory (xyz_device, asynchronous on the
+ *                       engine's stream); either may be NULL. */
+int lt_comm_unique_id(void *id128);
+int lt_comm_init(lt_engine *e, const void *id128, int32_t nranks, int32_t rank);
+int lt_comm_init_file(lt_engine *e, const char *path, int32_t nranks, int32_t rank, int32_t timeout_s);
+int lt_allgather_positions(lt_engine *e, const int32_t *counts, double *xyz_host, void *xyz_device);
+int lt_comm_destroy(lt_engine *e);
+
 /* init-time geometry on the device ------------------------ */
 /* The adjacency lists of initGrid (hydrodynamic_module.f90:588-645): for element i the
  * elements j of [i-(row+2), i+row+2] that share a node with it, ascending, after i itself;
@@ -381,6 +399,15 @@ int lt_create_polyspecs(lt_engine *e, const lt_habitat *h);
 int lt_get_polyspecs(lt_engine *e, int32_t *polyspecs, int32_t *holespecs,
                      int32_t *elepolys_ptr, int32_t *elepolys_ids, int32_t elepolys_cap,
                      int32_t *polyholes_ptr, int32_t *polyholes_ids, int32_t polyholes_cap);
+
+/* Per-phase GPU time of the steps: the counterpart of WriteModelTiming (LTRANS.h:261; CPU_TIME stamps at
+ * LTRANS.f90:780,979,1085,1096,1108,1121,1390 accumulated into timeCounts, written to Timing.csv at :1669-1689).
+ * lt_phase_timing(e, 1) arms it; lt_get_phase_times returns (and with reset /= 0 clears) the accumulated
+ * milliseconds of ms4 = { set-up, advection, vertical turbulence, update } -- the reference's "Set Up",
+ * "Advection", "VTurb" and "Update" columns; its "HTurb" and "Behavior" work is inside the update kernel,
+ * its "Hydro" column is the host's own time around lt_set_slab / lt_slab_commit. */
+int lt_phase_timing(lt_engine *e, int32_t on);
+int lt_get_phase_times(lt_engine *e, double *ms4, int32_t reset);
 
 /* measurement aids (not part of the reference interface) ------------------- */
 /* HIP-event timing of the step kernel on the engine's stream: arm up to

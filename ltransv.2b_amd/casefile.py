@@ -69,7 +69,7 @@ def _l(v):
     return ".TRUE." if v else ".FALSE."
 
 
-def write_ltrans_data(path, cfg, days=1.0, tdim=8):
+def write_ltrans_data(path, cfg, days=1.0, tdim=8, iprint=None, model_timing=False):
     """A run file in the LTRANS.data syntax with the groups the path reads."""
     txt = f"""! written by ltrans_amd.casefile.write_ltrans_data (LTRANS.data syntax)
 $numparticles
@@ -77,7 +77,7 @@ $numparticles
 $end
 $timeparam
   days   = {days}
-  iprint = {cfg.dt}
+  iprint = {iprint or cfg.dt}
   dt     = {cfg.dt}
   idt    = {cfg.idt}
 $end
@@ -156,7 +156,7 @@ $other
   SaltTempOn   = {_l(cfg.SaltTempOn)}
   TrackCollisions  = {_l(cfg.TrackCollisions)}
   WriteHeaders     = .FALSE.
-  WriteModelTiming = .FALSE.
+  WriteModelTiming = {_l(model_timing)}
   ijbuff = 4
   FreeSlip = {_l(cfg.FreeSlip)}
 $end

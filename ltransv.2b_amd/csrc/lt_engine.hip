@@ -5,6 +5,9 @@
 // and launches the step kernel of lt_kernels.h.  There is NO CPU fallback: every
 // entry point that computes runs on the HIP device or fails with LT_ERR_DEVICE.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: the library is opened at lt_comm_init (no link-time dependency)
+#include <unistd.h>
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -86,6 +89,15 @@ struct lt_engine {
   int32_t mti = 624;
   int64_t rng_before = 0, rng_total = -1;
   bool rng_kernels_configured = false;
+  // per-phase GPU time (the counterpart of WriteModelTiming's CPU_TIME stamps, LTRANS.f90:780-1397)
+  bool phase_on = false;
+  std::vector<hipEvent_t> phase_ev;   // 5 events per recorded step: before k_pre | after set-up | after RK4 | after VTurb | after k_post
+  size_t phase_used = 0;
+  double phase_ms[4] = {0.0, 0.0, 0.0, 0.0};   // set-up, advection, vertical turbulence, update
+  // multi-GPU: RCCL communicator of lt_comm_init (nullptr = none)
+  ncclComm_t comm = nullptr;
+  int comm_nranks = 0, comm_rank = 0;
+  DevBuf comm_send, comm_recv, comm_out, comm_counts;
   bool rng_static = false;  // lt_set_rng_window_static: the window holds until it is set again
   int64_t rng_static_before = 0, rng_static_total = -1;
   bool rng_ready = false;
@@ -756,12 +768,16 @@ int lt_destroy(lt_engine* e) {
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : e->phase_ev) (void)hipEventDestroy(ev);
   if (e->h_counters) (void)hipHostFree(e->h_counters);
   if (e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);
   for (int i = 0; i < 2; i++) {
     if (e->pin[i]) (void)hipHostFree(e->pin[i]);
     if (e->pin_free[i]) (void)hipEventDestroy(e->pin_free[i]);
   }
+  if (e->comm) (void)lt_comm_destroy(e);
+  for (DevBuf* b : {&e->comm_send, &e->comm_recv, &e->comm_out, &e->comm_counts})
+    if (b->p) (void)hipFree(b->p);
   if (e->prefetch_done) (void)hipEventDestroy(e->prefetch_done);
   if (e->compute_mark) (void)hipEventDestroy(e->compute_mark);
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
@@ -1962,6 +1978,25 @@ int lt_set_rng_window_draws(lt_engine* e, int64_t draws_before, int64_t draws_to
   return LT_OK;
 }
 
+static int phase_flush(lt_engine* e) {
+  if (!e->phase_used) return LT_OK;
+  HIPCHK(e, hipEventSynchronize(e->phase_ev[e->phase_used - 1]));
+  for (size_t s0 = 0; s0 + 5 <= e->phase_used; s0 += 5)
+    for (int k = 0; k < 4; k++) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, e->phase_ev[s0 + k], e->phase_ev[s0 + k + 1]) == hipSuccess) e->phase_ms[k] += ms;
+    }
+  e->phase_used = 0;
+  return LT_OK;
+}
+static int phase_mark(lt_engine* e, int k) {  // k = 0..4 within the current step
+  if (!e->phase_on) return LT_OK;
+  if (k == 0 && e->phase_used + 5 > e->phase_ev.size()) TRY(phase_flush(e));
+  HIPCHK(e, hipEventRecord(e->phase_ev[e->phase_used + k], e->stream));
+  if (k == 4) e->phase_used += 5;
+  return LT_OK;
+}
+
 // The first part of a step: parameters, k_pre, the behaviour pre-pass and -- when anything
 // draws -- the prefix sum that places every tracked particle in the serial random stream.
 // Returns with e->stream idle and the shard's number of draws known.
@@ -2008,6 +2043,7 @@ static int step_prepare(lt_engine* e, const double* ex3, const double* ix3, int3
   const bool beh_pre = beh_draws || e->cfg.Behavior == 7 || e->cfg.SaltTempOn;
   const bool draws = e->cfg.HTurbOn || e->cfg.VTurbOn || beh_draws;
   e->pre_own = 0;
+  TRY(phase_mark(e, 0));
   if (blocks) {
     const bool f32 = e->cfg.slab_storage == LT_SLAB_F32;
     if (f32) hipLaunchKernelGGL((k_pre<float>), dim3(blocks), dim3(256), 0, e->stream, P);
@@ -2038,6 +2074,7 @@ static int step_prepare(lt_engine* e, const double* ex3, const double* ix3, int3
     }
   }
   HIPCHK(e, hipGetLastError());
+  TRY(phase_mark(e, 1));
   e->pre_valid = true;
   e->pre_sig[0] = ex3[0]; e->pre_sig[1] = ex3[1]; e->pre_sig[2] = ex3[2];
   e->pre_sig[3] = ix3[0]; e->pre_sig[4] = ix3[1]; e->pre_sig[5] = ix3[2];
@@ -2110,15 +2147,20 @@ int lt_step(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32
     }
     if (f32) hipLaunchKernelGGL((k_rk_slow<float>), dim3(blocks), dim3(256), 0, e->stream, P);
     else hipLaunchKernelGGL((k_rk_slow<double>), dim3(blocks), dim3(256), 0, e->stream, P);
+    TRY(phase_mark(e, 2));
     if (prof_vt) HIPCHK(e, hipEventRecord(e->prof_ev[e->prof_used], e->stream));
     if (e->cfg.VTurbOn) launch_vturb(e, P, blocks);
     if (prof_vt) {
       HIPCHK(e, hipEventRecord(e->prof_ev[e->prof_used + 1], e->stream));
       e->prof_used += 2;
     }
+    TRY(phase_mark(e, 3));
     wait_rng(e);
     hipLaunchKernelGGL(k_post, dim3(blocks), dim3(256), 0, e->stream, P);
     HIPCHK(e, hipGetLastError());
+    TRY(phase_mark(e, 4));
+  } else if (e->phase_on) {
+    for (int k = 2; k <= 4; k++) TRY(phase_mark(e, k));
   }
   e->stats_valid = false;  // the step's counters stay on the device until somebody asks (fetch_counters)
   e->counters_fetched = false;
@@ -2173,6 +2215,30 @@ int lt_get_counters(lt_engine* e, uint64_t* out8) {
   return LT_OK;
 }
 
+/* Per-phase GPU time of the steps (the counterpart of WriteModelTiming, LTRANS.f90:1389-1398, 1669-1689):
+ * lt_phase_timing(e, 1) arms it (a few HIP events per step), lt_get_phase_times(e, ms4, reset) synchronises
+ * and returns the accumulated milliseconds of: set-up (gates, setEle, setInterp, s-levels, draw offsets),
+ * advection (RK4), vertical turbulence, update (HTurb, behaviour, reflection, boundaries, setEle, settlement,
+ * commit). */
+int lt_phase_timing(lt_engine* e, int32_t on) {
+  if (!e) return LT_ERR_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  if (on && e->phase_ev.empty()) {
+    e->phase_ev.resize(5 * 64);
+    for (auto& ev : e->phase_ev) HIPCHK(e, hipEventCreate(&ev));
+  }
+  if (!on) TRY(phase_flush(e));
+  e->phase_on = on != 0;
+  return LT_OK;
+}
+int lt_get_phase_times(lt_engine* e, double* ms4, int32_t reset) {
+  if (!e || !ms4) return LT_ERR_ARG;
+  TRY(phase_flush(e));
+  for (int k = 0; k < 4; k++) ms4[k] = e->phase_ms[k];
+  if (reset) for (int k = 0; k < 4; k++) e->phase_ms[k] = 0.0;
+  return LT_OK;
+}
+
 /* HIP-event timing of the step kernel on the engine's stream.
  * lt_profile_begin(e, max_steps) arms up to max_steps (start, stop) event pairs;
  * lt_profile_end(e, &total_ms, &launches) synchronises and sums them. */
@@ -2203,6 +2269,167 @@ int lt_profile_end(lt_engine* e, double* total_ms, int32_t* launches) {
   *launches = (int32_t)(e->prof_used / 2);
   e->prof_on = false;
   e->prof_used = 0;
+  return LT_OK;
+}
+
+
+/* ---- multi-GPU: the end-of-step all-gather of the shards' (x,y,z), RCCL over xGMI, behind the ABI ---- */
+namespace {
+struct RcclApi {
+  void* h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi* rccl() {
+  static RcclApi api;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      api.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (api.h) break;
+    }
+    if (api.h) {
+      api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.h, "ncclGetUniqueId");
+      api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.h, "ncclCommInitRank");
+      api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.h, "ncclCommDestroy");
+      api.AllGather = (decltype(api.AllGather))dlsym(api.h, "ncclAllGather");
+      api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.h, "ncclGetErrorString");
+      if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather) api.h = nullptr;
+    }
+  }
+  return api.h ? &api : nullptr;
+}
+// xyz_global(numpar_global,3) column-major <- the ranks' padded blocks [rank][3][nmax]
+__global__ void k_unpad_positions(const double* __restrict__ recv, const long long* __restrict__ offs, int nranks,
+                                  long long nmax, long long total, double* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int r = 0;
+  while (r + 1 < nranks && offs[r + 1] <= i) r++;
+  const long long j = i - offs[r];
+  const double* b = recv + (size_t)r * 3 * (size_t)nmax;
+  out[i] = b[j];
+  out[(size_t)total + i] = b[(size_t)nmax + j];
+  out[2 * (size_t)total + i] = b[2 * (size_t)nmax + j];
+}
+}  // namespace
+
+int lt_comm_unique_id(void* id128) {
+  if (!id128) return LT_ERR_ARG;
+  RcclApi* R = rccl();
+  if (!R) return LT_ERR_UNSUPPORTED;
+  ncclUniqueId id;
+  if (R->GetUniqueId(&id) != ncclSuccess) return LT_ERR_DEVICE;
+  static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+  memcpy(id128, &id, 128);
+  return LT_OK;
+}
+
+int lt_comm_init(lt_engine* e, const void* id128, int32_t nranks, int32_t rank) {
+  if (!e || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return LT_ERR_ARG;
+  if (e->comm) return fail(e, LT_ERR_STATE, "lt_comm_init: a communicator exists (lt_comm_destroy first)");
+  RcclApi* R = rccl();
+  if (!R) return fail(e, LT_ERR_UNSUPPORTED, "librccl.so could not be opened");
+  HIPCHK(e, hipSetDevice(e->device));
+  ncclUniqueId id;
+  memcpy(&id, id128, 128);
+  const ncclResult_t rc = R->CommInitRank(&e->comm, nranks, id, rank);
+  if (rc != ncclSuccess) {
+    e->comm = nullptr;
+    return fail(e, LT_ERR_DEVICE, "ncclCommInitRank: %s", R->GetErrorString ? R->GetErrorString(rc) : "error");
+  }
+  e->comm_nranks = nranks;
+  e->comm_rank = rank;
+  return LT_OK;
+}
+
+int lt_comm_init_file(lt_engine* e, const char* path, int32_t nranks, int32_t rank, int32_t timeout_s) {
+  if (!e || !path || nranks < 1 || rank < 0 || rank >= nranks) return LT_ERR_ARG;
+  unsigned char id[128];
+  if (rank == 0) {
+    TRY(lt_comm_unique_id(id));
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f || fwrite(id, 1, 128, f) != 128) { if (f) fclose(f); return fail(e, LT_ERR_ARG, "lt_comm_init_file: cannot write %s", tmp.c_str()); }
+    fclose(f);
+    if (rename(tmp.c_str(), path) != 0) return fail(e, LT_ERR_ARG, "lt_comm_init_file: cannot rename to %s", path);
+  } else {
+    bool ok = false;
+    for (int waited_ms = 0; waited_ms <= timeout_s * 1000 && !ok; waited_ms += 50) {
+      FILE* f = fopen(path, "rb");
+      if (f) { ok = fread(id, 1, 128, f) == 128; fclose(f); }
+      if (!ok) usleep(50 * 1000);
+    }
+    if (!ok) return fail(e, LT_ERR_STATE, "lt_comm_init_file: %s did not appear within %d s", path, (int)timeout_s);
+  }
+  return lt_comm_init(e, id, nranks, rank);
+}
+
+int lt_comm_destroy(lt_engine* e) {
+  if (!e) return LT_ERR_ARG;
+  if (e->comm) {
+    RcclApi* R = rccl();
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (R) (void)R->CommDestroy(e->comm);
+    e->comm = nullptr;
+  }
+  return LT_OK;
+}
+
+int lt_allgather_positions(lt_engine* e, const int32_t* counts, double* xyz_host, void* xyz_device) {
+  if (!e || !counts || (!xyz_host && !xyz_device)) return LT_ERR_ARG;
+  if (!e->comm) return fail(e, LT_ERR_STATE, "lt_allgather_positions before lt_comm_init");
+  if (!e->have_particles) return fail(e, LT_ERR_STATE, "no particles uploaded");
+  RcclApi* R = rccl();
+  if (!R) return LT_ERR_UNSUPPORTED;
+  HIPCHK(e, hipSetDevice(e->device));
+  const int G = e->comm_nranks;
+  if (counts[e->comm_rank] != e->cfg.numpar) return fail(e, LT_ERR_ARG, "lt_allgather_positions: counts(rank+1) /= numpar of this engine");
+  long long nmax = 0, total = 0;
+  std::vector<long long> offs(G + 1, 0);
+  for (int r = 0; r < G; r++) {
+    if (counts[r] < 0) return LT_ERR_ARG;
+    nmax = std::max<long long>(nmax, counts[r]);
+    offs[r + 1] = offs[r] + counts[r];
+  }
+  total = offs[G];
+  if (total == 0) return LT_OK;
+  const size_t blk = (size_t)3 * (size_t)nmax * 8;
+  if (e->comm_send.bytes < blk) TRY(dev_alloc(e, e->comm_send, blk));
+  if (e->comm_recv.bytes < blk * G) TRY(dev_alloc(e, e->comm_recv, blk * G));
+  if (e->comm_counts.bytes < (size_t)(G + 1) * 8) TRY(dev_alloc(e, e->comm_counts, (size_t)(G + 1) * 8));
+  double* out = (double*)xyz_device;
+  if (!out) {
+    if (e->comm_out.bytes < (size_t)3 * total * 8) TRY(dev_alloc(e, e->comm_out, (size_t)3 * total * 8));
+    out = (double*)e->comm_out.p;
+  }
+  HIPCHK(e, hipMemcpyAsync(e->comm_counts.p, offs.data(), (size_t)(G + 1) * 8, hipMemcpyHostToDevice, e->stream));
+  // pack this shard as [3][nmax] (column-major xyz(numpar,3) with the columns nmax apart)
+  const int n = e->cfg.numpar;
+  if (n) {
+    unsigned blocks = (unsigned)(((size_t)n + 255) / 256);
+    // k_pack_positions writes dst[o], dst[N + o], dst[2N + o] with N = numpar: pack densely, then spread the columns
+    double* dense = (double*)e->comm_recv.p;  // scratch: the receive buffer is free until the collective
+    hipLaunchKernelGGL(k_pack_positions, dim3(blocks), dim3(256), 0, e->stream, (const double*)e->par.p,
+                       (const int*)e->orig.p, dense, n);
+    for (int c = 0; c < 3; c++)
+      HIPCHK(e, hipMemcpyAsync((double*)e->comm_send.p + (size_t)c * nmax, dense + (size_t)c * n, (size_t)n * 8,
+                               hipMemcpyDeviceToDevice, e->stream));
+  }
+  const ncclResult_t rc = R->AllGather(e->comm_send.p, e->comm_recv.p, (size_t)3 * (size_t)nmax, ncclDouble, e->comm, e->stream);
+  if (rc != ncclSuccess) return fail(e, LT_ERR_DEVICE, "ncclAllGather: %s", R->GetErrorString ? R->GetErrorString(rc) : "error");
+  hipLaunchKernelGGL(k_unpad_positions, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream,
+                     (const double*)e->comm_recv.p, (const long long*)e->comm_counts.p, G, nmax, total, out);
+  HIPCHK(e, hipGetLastError());
+  if (xyz_host) {
+    HIPCHK(e, hipMemcpyAsync(xyz_host, out, (size_t)3 * total * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+  }
   return LT_OK;
 }
 

@@ -421,6 +421,26 @@ class Engine:
         f.restype = C.c_int
         self._check(f(self._h, C.c_void_p(int(dst_device_ptr))), "pack_positions")
 
+    # -- multi-GPU: the RCCL all-gather behind the ABI ---------------------------
+    def comm_init_file(self, path, nranks, rank, timeout_s=60):
+        f = self.lib.lt_comm_init_file
+        f.restype = C.c_int
+        self._check(f(self._h, str(path).encode(), int(nranks), int(rank), int(timeout_s)), "comm_init_file")
+
+    def allgather_positions(self, counts):
+        """-> xyz(sum(counts), 3) of all shards in rank order (host array)"""
+        counts = _i4(counts)
+        out = np.zeros((int(counts.sum()), 3), order="F")
+        f = self.lib.lt_allgather_positions
+        f.restype = C.c_int
+        self._check(f(self._h, _ip(counts), _dp(out), None), "allgather_positions")
+        return out
+
+    def comm_destroy(self):
+        f = self.lib.lt_comm_destroy
+        f.restype = C.c_int
+        self._check(f(self._h), "comm_destroy")
+
     def profile_begin(self, max_steps):
         f = self.lib.lt_profile_begin
         f.restype = C.c_int

@@ -14,6 +14,9 @@
 !
 ! usage: ltrans_hip_driver <LTRANS.data> <case.bin> <out.bin> [n_external] [max_internal] [pipeline]
 !   pipeline = 1: updateHydro through lt_slab_prefetch / lt_slab_commit instead of lt_set_slab
+! Like the reference it appends every particle error to ErrorLog.txt (LTRANS.f90:858-877 etc., formats
+! :761-775) and, with WriteModelTiming = .TRUE., writes Timing.csv (:471-476, :1669-1689) -- both in the
+! current directory.
 program ltrans_hip_driver
   use iso_c_binding
   use ltrans_hip
@@ -86,6 +89,11 @@ program ltrans_hip_driver
   real(c_double), allocatable, target :: o_lon(:), o_lat(:), o_z(:), o_age(:), o_status(:)
   integer(c_int64_t) :: total_errors
   character(len=512) :: nmlfile, casefile, outfile, arg
+  type(lt_particles) :: perr
+  real(c_double) :: ms4(4)
+  double precision :: t_hydro, t_elapsed, tc(7)
+  integer(8) :: clk0, clk1, clk_rate, clk_print
+  integer :: printdt
 
   nargs = command_argument_count()
   if (nargs < 3) then
@@ -244,6 +252,29 @@ program ltrans_hip_driver
   t_b = 1; t_c = 2; t_f = 3; stepf = 3
   call lt_check(lt_set_time_slots(eng, t_b, t_c, t_f), eng, 'lt_set_time_slots')
 
+  ! ErrorLog.txt is opened fresh by ini_LTRANS (LTRANS.f90:337-354); only err_code comes back for it
+  open(210, file='ErrorLog.txt', status='replace'); close(210)
+  perr%par = c_null_ptr
+  perr%P_r_element = c_null_ptr; perr%P_u_element = c_null_ptr; perr%P_v_element = c_null_ptr
+  perr%P_behave = c_null_ptr; perr%dead = c_null_ptr; perr%oob = c_null_ptr
+  perr%P_swim = c_null_ptr; perr%P_pediage = c_null_ptr; perr%P_deadage = c_null_ptr
+  perr%settle = c_null_ptr; perr%settletime = c_null_ptr
+  perr%endpoly = c_null_ptr; perr%hitBottom = c_null_ptr; perr%hitLand = c_null_ptr
+  perr%timer = c_null_ptr; perr%P_Sprev = c_null_ptr; perr%P_zprev = c_null_ptr; perr%bottom = c_null_ptr
+  perr%P_Salt = c_null_ptr; perr%P_Temp = c_null_ptr
+  perr%err_code = c_loc(err_code)
+  if (WriteModelTiming) then        ! LTRANS.f90:471-476
+    open(300, file='Timing.csv', status='replace')
+    write(300,'(A)') 'Daytime,Elapsed,Hydro,Hydro %,Set Up,Set Up %,'// &
+                     'Advection,Advection %,HTurb,HTurb %,VTurb,VTurb %,Behavior,'// &
+                     'Behavior %,Update,Update %'
+    close(300)
+    call lt_check(lt_phase_timing(eng, 1_c_int32_t), eng, 'lt_phase_timing')
+  endif
+  call system_clock(clk_print, clk_rate)
+  t_hydro = 0.0d0
+  printdt = 0
+
   ! ---- run_LTRANS (LTRANS.f90:141-161)
   stepT = int(days*86400.0)/dt
   if (n_external > 0) stepT = min(stepT, n_external)
@@ -260,6 +291,7 @@ program ltrans_hip_driver
       stepf = stepf + 1
       if (stepf > nrec) stop 'case file holds too few history records'
       read(2) zeta, Uvel, Vvel, Wvel, Kh
+      call system_clock(clk0)
       if (pipeline == 0) then
         call lt_check(lt_set_slab(eng, t_f, slab), eng, 'lt_set_slab')
         call lt_check(lt_set_time_slots(eng, t_b, t_c, t_f), eng, 'lt_set_time_slots')
@@ -274,6 +306,8 @@ program ltrans_hip_driver
         call lt_check(lt_slab_prefetch(eng, rec), eng, 'lt_slab_prefetch')
         call lt_check(lt_slab_commit(eng, t_b, t_c, t_f), eng, 'lt_slab_commit')
       endif
+      call system_clock(clk1)
+      t_hydro = t_hydro + dble(clk1 - clk0) / dble(clk_rate)
     endif
     ex = 0.0
     ex(1) = (p-2)*dt
@@ -287,10 +321,51 @@ program ltrans_hip_driver
       call lt_check(lt_step(eng, ex, ix, p, it), eng, 'lt_step')   ! = call update_particles()
       call lt_check(lt_get_stats(eng, st), eng, 'lt_get_stats')
       total_errors = total_errors + st%errors
+      if (st%errors > 0) then
+        ! the reference appends one line per event to ErrorLog.txt as it happens; here the step's
+        ! per-particle codes come back once and are written in particle order (formats LTRANS.f90:761-775)
+        call lt_check(lt_get_particles(eng, perr), eng, 'lt_get_particles(err_code)')
+        open(210, file='ErrorLog.txt', position='append')
+        do n = 1, numpar
+          select case (err_code(n))
+            case (4);  write(210,21) n, int(ix(3))
+            case (5);  write(210,22) n, int(ix(3))
+            case (6);  write(210,23) n, int(ix(3))
+            case (24); write(210,24) n, int(ix(3))
+            case (25); write(210,25) n, int(ix(3))
+            case (26); write(210,26) n, int(ix(3))
+            case (27); write(210,27) n, int(ix(3))
+            case (28); write(210,28) n, int(ix(3))
+            case (29); write(210,29) n, int(ix(3))
+          end select
+        enddo
+        close(210)
+      endif
       if (st%errors > 0 .and. (ErrorFlag < 1 .or. ErrorFlag > 3)) then
         write(*,*) st%errors, ' particle error(s) at model time ', ix(3)
         write(*,*) 'The Program Cannot Continue and Will Terminate'
         stop 1
+      endif
+      ! printOutput's timing line (LTRANS.f90:1669-1689) every iprint seconds of model time
+      printdt = printdt + idt
+      if (printdt >= iprint) then
+        printdt = 0
+        if (WriteModelTiming) then
+          call lt_check(lt_get_phase_times(eng, ms4, 1_c_int32_t), eng, 'lt_get_phase_times')
+          call system_clock(clk1)
+          t_elapsed = dble(clk1 - clk_print) / dble(clk_rate)
+          clk_print = clk1
+          tc = 0.0d0
+          tc(1) = t_hydro; tc(2) = ms4(1) * 1.0d-3; tc(3) = ms4(2) * 1.0d-3
+          tc(5) = ms4(3) * 1.0d-3; tc(7) = ms4(4) * 1.0d-3      ! HTurb, Behavior: inside the update kernel
+          t_hydro = 0.0d0
+          open(300, file='Timing.csv', position='append')
+          write(300,"(15(F14.4,','),F14.4)") ix(3)/86400.0d0, t_elapsed, &
+            tc(1), tc(1)/t_elapsed*100.0d0, tc(2), tc(2)/t_elapsed*100.0d0, tc(3), tc(3)/t_elapsed*100.0d0, &
+            tc(4), tc(4)/t_elapsed*100.0d0, tc(5), tc(5)/t_elapsed*100.0d0, tc(6), tc(6)/t_elapsed*100.0d0, &
+            tc(7), tc(7)/t_elapsed*100.0d0
+          close(300)
+        endif
       endif
     enddo
   enddo
@@ -312,4 +387,13 @@ program ltrans_hip_driver
   write(*,'(A,I0,A,I0,A,I0)') 'ltrans_hip_driver: ', numpar, ' particles, ', stepT*stepIT, &
         ' internal steps, particle errors: ', total_errors
   call lt_check(lt_destroy(eng), c_null_ptr, 'lt_destroy')
+    21 FORMAT ('Particle ',I10,' not in rho element after ',I10,' seconds')
+    22 FORMAT ('Particle ',I10,' not in u element after '  ,I10,' seconds')
+    23 FORMAT ('Particle ',I10,' not in v element after '  ,I10,' seconds')
+    24 FORMAT ('Particle ',I10,' out after 3rd reflection after ',I10,' seconds')
+    25 FORMAT ('Particle ',I10,' outside main bounds after intersect_reflect after ',I10,' seconds')
+    26 FORMAT ('Particle ',I10,' inside island bounds after intersect_reflect after ',I10,' seconds')
+    27 FORMAT ('Particle ',I10,' jumped over rho element after ',I10,' seconds')
+    28 FORMAT ('Particle ',I10,' jumped over u element after ',I10,' seconds')
+    29 FORMAT ('Particle ',I10,' jumped over v element after ',I10,' seconds')
 end program ltrans_hip_driver

@@ -223,6 +223,48 @@ module ltrans_hip
       integer(c_int) :: rc
     end function
     ! = update_particles() with main's ex, ix, p, it (LTRANS.f90:568-571,588-590)
+    function lt_set_rng_window_static(engine, active_before, active_total) &
+        bind(C, name="lt_set_rng_window_static") result(rc)
+      import :: c_ptr, c_int, c_int64_t
+      type(c_ptr), value :: engine
+      integer(c_int64_t), value :: active_before, active_total
+      integer(c_int) :: rc
+    end function
+    ! per-phase GPU time (WriteModelTiming): ms4 = set-up, advection, vertical turbulence, update
+    function lt_phase_timing(engine, on) bind(C, name="lt_phase_timing") result(rc)
+      import :: c_ptr, c_int, c_int32_t
+      type(c_ptr), value :: engine
+      integer(c_int32_t), value :: on
+      integer(c_int) :: rc
+    end function
+    function lt_get_phase_times(engine, ms4, reset) bind(C, name="lt_get_phase_times") result(rc)
+      import :: c_ptr, c_int, c_int32_t, c_double
+      type(c_ptr), value :: engine
+      real(c_double), intent(out) :: ms4(4)
+      integer(c_int32_t), value :: reset
+      integer(c_int) :: rc
+    end function
+    ! multi-GPU: the RCCL all-gather of the shards' (x,y,z) behind the ABI (one process per GPU)
+    function lt_comm_init_file(engine, path, nranks, rank, timeout_s) bind(C, name="lt_comm_init_file") result(rc)
+      import :: c_ptr, c_int, c_int32_t, c_char
+      type(c_ptr), value :: engine
+      character(kind=c_char), intent(in) :: path(*)
+      integer(c_int32_t), value :: nranks, rank, timeout_s
+      integer(c_int) :: rc
+    end function
+    function lt_allgather_positions(engine, counts, xyz_host, xyz_device) bind(C, name="lt_allgather_positions") result(rc)
+      import :: c_ptr, c_int, c_int32_t, c_double
+      type(c_ptr), value :: engine
+      integer(c_int32_t), intent(in) :: counts(*)
+      real(c_double), intent(out) :: xyz_host(*)
+      type(c_ptr), value :: xyz_device
+      integer(c_int) :: rc
+    end function
+    function lt_comm_destroy(engine) bind(C, name="lt_comm_destroy") result(rc)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: engine
+      integer(c_int) :: rc
+    end function
     function lt_step(engine, ex, ix, p, it) bind(C, name="lt_step") result(rc)
       import :: c_int, c_int32_t, c_double, c_ptr
       type(c_ptr), value :: engine

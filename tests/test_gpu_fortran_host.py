@@ -26,7 +26,8 @@ def test_fortran_driver_matches_python_driver(tmp_path, name, pipeline):
     casefile.write_case(tmp_path / "case.bin", case["g"], case["geo"], case["bounds"], case["parts"],
                         [case["record"](r) for r in range(n_ext + 1)], case["cfg"].numpar)
     r = subprocess.run([DRIVER, str(tmp_path / "LTRANS.data"), str(tmp_path / "case.bin"),
-                        str(tmp_path / "out.bin"), str(n_ext), str(n_int), str(pipeline)], capture_output=True, text=True)
+                        str(tmp_path / "out.bin"), str(n_ext), str(n_int), str(pipeline)], capture_output=True, text=True,
+                       cwd=tmp_path)
     assert r.returncode == 0, r.stdout + r.stderr
     f = casefile.read_result(tmp_path / "out.bin")
     assert "setEle_all on the device: 0 particles located differently" in r.stdout
@@ -42,3 +43,36 @@ def test_fortran_driver_matches_python_driver(tmp_path, name, pipeline):
     e.close()
     for k in ("lon", "lat", "z", "age", "status"):
         assert np.array_equal(f[k], o[k]), k
+
+
+def test_fortran_driver_writes_errorlog_and_timing(tmp_path):
+    """the harness's ErrorLog.txt (one line per particle error in the reference's formats, LTRANS.f90:761-775,
+    858-877) and, with WriteModelTiming, Timing.csv (header :471-476, one row per print interval :1669-1689)."""
+    if not os.path.exists(DRIVER):
+        pytest.skip("Fortran harness not built (flang absent at build time)")
+    case = cases.build_case("tiny_jump", ErrorFlag=1)
+    n_ext, n_int = 1, 6
+    casefile.write_ltrans_data(tmp_path / "LTRANS.data", case["cfg"], days=1.0, iprint=2 * case["cfg"].idt, model_timing=True)
+    casefile.write_case(tmp_path / "case.bin", case["g"], case["geo"], case["bounds"], case["parts"],
+                        [case["record"](r) for r in range(n_ext + 2)], case["cfg"].numpar)
+    r = subprocess.run([DRIVER, str(tmp_path / "LTRANS.data"), str(tmp_path / "case.bin"), str(tmp_path / "out.bin"),
+                        str(n_ext), str(n_int), "0"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    total = int(r.stdout.strip().splitlines()[-1].rsplit(":", 1)[1])
+    trace = []
+    cases.run_case(case, ltrans_amd.Engine, {}, n_external=n_ext, max_internal=n_int, trace=trace)
+    codes = np.concatenate([t["err_code"] for t in trace])
+    assert total == int((codes != 0).sum()) and total > 100
+    lines = (tmp_path / "ErrorLog.txt").read_text().splitlines()
+    assert len(lines) == total
+    want = {28: "jumped over u element", 29: "jumped over v element", 27: "jumped over rho element",
+            25: "outside main bounds after intersect_reflect", 26: "inside island bounds after intersect_reflect",
+            24: "out after 3rd reflection"}
+    for code, text in want.items():
+        assert sum(text in ln for ln in lines) == int((codes == code).sum()), code
+    first = np.flatnonzero(trace[0]["err_code"])[0]
+    assert lines[0].startswith("Particle %10d" % (first + 1)) and lines[0].endswith("%10d seconds" % 120)
+    rows = (tmp_path / "Timing.csv").read_text().splitlines()
+    assert rows[0].strip().startswith("Daytime,Elapsed,Hydro,Hydro %,Set Up") and len(rows) == 1 + n_int // 2
+    vals = [float(v) for v in rows[1].split(",")]
+    assert len(vals) == 16 and vals[1] > 0 and vals[6] > 0 and vals[14] > 0      # elapsed, advection, update

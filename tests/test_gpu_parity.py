@@ -107,3 +107,19 @@ def test_index_equals_brute_force(monkeypatch):
     b = cases.run_case(case, ltrans_amd.Engine, {}, n_external=2)
     assert np.array_equal(a["par"], b["par"])
     assert np.array_equal(a["hitLand"], b["hitLand"])
+
+
+def test_abi_allgather_single_rank(tmp_path):
+    """the RCCL all-gather behind the ABI (lt_comm_init_file / lt_allgather_positions), one rank: the gathered
+    xyz is the shard's own (x,y,z) in the reference's particle order (the N-rank form needs N GPUs)."""
+    case = cases.build_case("tiny_adv")
+    e = cases.make_engine(case, ltrans_amd.Engine, {})
+    from ltrans_amd.driver import LtransRun
+    run = LtransRun(e, case["cfg"].dt, case["cfg"].idt, case["record"])
+    run.init_hydro()
+    run.run(1, max_internal=3)
+    e.comm_init_file(tmp_path / "lt_comm_id", 1, 0)
+    xyz = e.allgather_positions([case["cfg"].numpar])
+    assert np.array_equal(xyz, e.get_particles(fields=("par",))["par"][:, :3])
+    e.comm_destroy()
+    e.close()
