@@ -1,5 +1,13 @@
 // lt_libm_impl.h -- the function bodies of lt_libm.h.  Included by lt_libm.h once per table
 // placement with LT_LM_NAME(f) and the LT_*_TAB macros set (no include guard on purpose).
+//
+// Provenance and licences.  These are restatements, operation for operation (the reference's results branch
+// on the last bit of what libm returns), of the double-precision algorithms the GNU C
+// Library 2.28+ executes on an FMA-capable x86-64: exp / log / pow from the Arm Optimized Routines (MIT licence;
+// in glibc under the LGPL 2.1+), sin / cos / sincos / atan from the IBM Accurate Mathematical Library (LGPL 2.1+
+// in glibc), log10 in fdlibm's form (Sun Microsystems: "permission to use, copy, modify, and distribute this
+// software is freely granted, provided that this notice is preserved").  No glibc source text is included;
+// the polynomial coefficients and tables (lt_libm_tables.h) are the algorithms' published constants.
 // ------------------------------------------------------------------------------------ exp
 // exp(x) = scale * (1 + tmp): the polynomial part and the bits of the scale 2^(k/128); xtail is
 // added to the reduced argument (pow's low part; 0 for exp)

@@ -6,12 +6,22 @@
 //   GRIDCELL_MOD::gridcell             gridcell_module.f90:26-257
 //   HYDRO_MOD interpolation weights    hydrodynamic_module.f90:1680-1740,2527-2563
 // The arithmetic order of every formula follows the Fortran so that results
-// agree with the CPU oracle to rounding of the transcendental functions only
-// (this file is compiled with -ffp-contract=off).  What is different from the
+// agree with the CPU oracle bit for bit (this file is compiled with -ffp-contract=off and the
+// transcendental functions are the host-libm-exact ones of lt_libm.h).  What is different from the
 // reference is the shape: fixed N=4 splines live in registers and are fitted
 // one interval at a time by a single loop body (keeps the instruction
 // footprint of the 36 fits per particle-step small), the interval search is a
 // comparison chain, and nothing is allocated.
+//
+// Provenance and licences.  The TENSION_MOD section restates the ALGORITHM of TSPACK (R. J. Renka, ACM TOMS
+// Algorithm 716: YPC1, SIGS, SNHCSH, HVAL, HPVAL, INTRVL) as the reference's tension_module.f90 carries it --
+// operation by operation, because the reference's results branch on the last bit of these formulas, which is
+// also why the identifiers of the published algorithm (SBIG, RTOL, D1D2, TP1, EMS, SSM, COSHMM, FMAX, ...) are
+// kept.  TSPACK is copyrighted by the ACM and distributed under the ACM Software Copyright and License
+// Agreement (royalty-free for academic, research and other noncommercial use; commercial use needs a licence
+// from ACM, permissions@acm.org) -- see the reference's README.md ("TSPACK: tension spline curve-fitting
+// package"); that agreement, not this repository's licence, governs this section.  MT19937 (lt_mt.h) is the
+// Matsumoto-Nishimura generator (3-clause BSD).  lt_libm_impl.h / lt_libm_tables.h: see their headers.
 #pragma once
 #include <hip/hip_runtime.h>
 

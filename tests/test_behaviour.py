@@ -3,8 +3,9 @@ LTRANS.f90:1062-1076).
 
 CPU part: properties of the oracle's restatement (draw accounting, lto_count_draws leaves
 the state alone, sharded windows in draws).  GPU part: the HIP path against the oracle --
-same positions (1e-9; the deviates and the salinity cue are identical, only libm's last
-bits differ), identical integer state and identical numbers of deviates drawn."""
+same positions (the deviates, the salinity cue and, since the kernels evaluate libm's functions
+exactly as the host does, every bit of them), identical integer state and identical numbers of
+deviates drawn."""
 import numpy as np
 import pytest
 
