@@ -595,7 +595,8 @@ int rng_ensure(lt_engine* e, uint64_t first, uint64_t last, hipStream_t gen_stre
 // then straight-line code in the hot loop)
 template <typename SlabT>
 void launch_rk_t(lt_engine* e, const StepParams& P, unsigned blocks) {
-  const unsigned rkblocks = (unsigned)(((size_t)blocks * 256 + LT_RK_BLOCK - 1) / LT_RK_BLOCK);
+  // (a multiple of 8 workgroups: k_rk maps them to particle chunks per XCD)
+  const unsigned rkblocks = ((unsigned)(((size_t)blocks * 256 + LT_RK_BLOCK - 1) / LT_RK_BLOCK) + 7u) & ~7u;
   static const unsigned dynlds = getenv("LT_RK_DYNLDS") ? (unsigned)atoi(getenv("LT_RK_DYNLDS")) : 0u;  // occupancy experiments
   switch (e->cfg.Vtransform) {
     case 1: hipLaunchKernelGGL((k_rk<SlabT, 1, LT_RK_WAVES>), dim3(rkblocks), dim3(LT_RK_BLOCK), dynlds, e->stream, P); break;

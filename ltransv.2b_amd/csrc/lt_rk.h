@@ -802,7 +802,16 @@ void k_rk(const StepParams P) {
   __shared__ WaveScratch wsc[LT_RK_BLOCK / 64];
   for (int i = threadIdx.x; i < 6 * LT_LEV_STRIDE; i += blockDim.x) lev[i] = P.lev[i];
   exp_table_load();
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  // XCD-aware order: workgroups go round-robin to the 8 XCDs (each with its own L2), so workgroup b takes
+  // the chunk  (b mod 8) * (grid / 8) + b / 8  of the particles: every XCD works through ONE contiguous
+  // eighth of the (element-sorted) particles, and the waves in flight on it share the node columns of
+  // a few neighbouring rows of elements in its L2.  (The grid is a multiple of 8 workgroups.)
+#ifndef LT_RK_NO_XCD_MAP
+  const unsigned vb = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+#else
+  const unsigned vb = blockIdx.x;
+#endif
+  const int n = (int)(vb * blockDim.x + threadIdx.x);
   const size_t N = (size_t)P.numpar;
   const bool act = (n < P.numpar) && ((P.ws_i[n] & FL_ACT) != 0);
   const double* wsd = P.ws_d + (act ? n : 0);

@@ -4,9 +4,15 @@
 kernel_stats.csv : the --stats table of the timed run (unchanged)
 pmc.json         : per kernel, mean counter value per launch for every counter
                    collected, plus HBM-side bytes per launch:
-                   fetch_bytes = FETCH_SIZE [KiB -> B] x 2 (gfx950: wide coalesced
-                   reads are tallied at half their size, MI355X_MICROARCH.md "HBM"),
-                   write_bytes = WRITE_SIZE [KiB -> B]
+                   fetch_bytes = FETCH_SIZE [KiB -> B] x 2, write_bytes = WRITE_SIZE [KiB -> B].
+                   The factors are measured, not assumed: profiles/r02_calib/calib.txt (kernels of
+                   known traffic, profiles/tools/calibrate.sh) shows FETCH_SIZE x 1024 = exactly half
+                   the bytes of the 128-byte lines touched for EVERY read shape the engine uses (wide
+                   16 B/lane, coalesced 8 B, 4 / 8 / 16 / 32-byte gathers), and WRITE_SIZE x 1024 = the
+                   bytes written for coalesced stores (3.6x the payload for per-lane runs of 32-byte
+                   records, which is why no kernel writes that way).
+                   "_meta": the hash of the kernel sources the library was built from (bench.py only
+                   quotes these numbers for a library with the same hash).
 summary.txt      : the same, readable
 """
 import csv, glob, json, os, sys, collections
@@ -45,7 +51,17 @@ def main(out):
         if "WRITE_SIZE" in e:
             e["write_bytes_per_launch"] = e["WRITE_SIZE"]["mean_per_launch"] * 1024.0
         res[k] = e
+    meta = {}
+    for name in ("stats", "pmc_sq", "pmc_fetch", "pmc_write"):
+        p = os.path.join(out, name + ".bench.json")
+        try:
+            meta["source_hash"] = json.loads(open(p).read().strip().splitlines()[-1])["config"]["kernel_source_hash"]
+            break
+        except Exception:
+            pass
+    res["_meta"] = meta
     json.dump(res, open(os.path.join(sm, "pmc.json"), "w"), indent=1, sort_keys=True)
+    res.pop("_meta")
     lines.append("")
     lines.append("counters, mean per launch")
     for k in sorted(res, key=lambda k: -res[k].get("SQ_BUSY_CYCLES", {"mean_per_launch": 0})["mean_per_launch"]):
