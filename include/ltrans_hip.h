@@ -395,6 +395,17 @@ int lt_locate_particles(lt_engine *e, int32_t n, const double *Xpar, const doubl
  * lt_get_polyspecs copies the lists out (any pointer may be NULL; *_cap = capacity of the
  * id arrays, LT_ERR_ARG if too small -- the ptr arrays, which are always filled first,
  * then tell the size needed). */
+/* createBounds (boundary_module.f90:82-1215): from mask_rho(vi,uj) and the coordinates of the u points
+ * x_u,y_u(ui,uj) and v points x_v,y_v(vi,vj), the boundary arrays of lt_bounds in the order the reference's
+ * clockwise walk produces them: bx,by(maxbound) closed main polygon; hx,hy,hid(maxisland) closed island
+ * polygons, ids from 1001; bnd_x,bnd_y(2,nbounds) the segments; land(nbounds) = 0 on open ocean.  A serial walk
+ * on the host, no engine and no device needed.  cap = capacity in points of every output array (2 x cap values
+ * for bnd_x / bnd_y); vi*uj is always enough.  LT_ERR_ARG for a mask the reference cannot handle (no water,
+ * more than one body of water). */
+int lt_create_bounds(int32_t vi, int32_t uj, const int32_t *mask_rho, const double *x_u, const double *y_u,
+                     const double *x_v, const double *y_v, int32_t cap, int32_t *nbounds, int32_t *maxbound,
+                     int32_t *maxisland, int32_t *numislands, double *bx, double *by, double *hx, double *hy,
+                     int32_t *hid, double *bnd_x, double *bnd_y, int32_t *land);
 int lt_create_polyspecs(lt_engine *e, const lt_habitat *h);
 int lt_get_polyspecs(lt_engine *e, int32_t *polyspecs, int32_t *holespecs,
                      int32_t *elepolys_ptr, int32_t *elepolys_ids, int32_t elepolys_cap,

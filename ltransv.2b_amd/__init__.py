@@ -18,5 +18,5 @@ Only what the hot path needs lives here:
 """
 from . import abi  # noqa: F401
 from .abi import LtConfig, LtError  # noqa: F401
-from .engine import Engine, load_hip_library  # noqa: F401
+from .engine import Engine, create_bounds, load_hip_library  # noqa: F401
 from .namelist import read_namelists, config_from_namelists  # noqa: F401

@@ -181,5 +181,5 @@ ENTRY_POINTS = [
     "build_adjacency", "locate_particles", "create_polyspecs", "get_polyspecs",
 ]
 HIP_ONLY_ENTRY_POINTS = ["last_error", "abi_version", "source_hash", "set_rng_window_static", "pack_positions", "stream",
-                         "phase_timing", "get_phase_times", "comm_unique_id", "comm_init", "comm_init_file", "allgather_positions", "comm_destroy",
+                         "phase_timing", "get_phase_times", "create_bounds", "comm_unique_id", "comm_init", "comm_init_file", "allgather_positions", "comm_destroy",
                          "profile_begin", "profile_end", "get_counters"]

@@ -25,6 +25,7 @@
 #define LT_RK_WAVES 2  // k_rk is held to 256 VGPRs (2 waves per SIMD); the few spills sit outside the slot loop
 #endif
 #include "lt_kernels.h"
+#include "lt_bounds_host.h"
 #include "lt_mt.h"
 
 using namespace ltd;
@@ -2432,6 +2433,64 @@ int lt_allgather_positions(lt_engine* e, const int32_t* counts, double* xyz_host
     HIPCHK(e, hipStreamSynchronize(e->stream));
   }
   return LT_OK;
+}
+
+
+/* createBounds (boundary_module.f90:82-1215) on the host side of the library: lt_bounds_host.h does the walk,
+ * this is the re-formatting of :1030-1204 into the arrays lt_set_bounds takes.  No device is touched. */
+int lt_create_bounds(int32_t vi, int32_t uj, const int32_t* mask_rho, const double* x_u, const double* y_u,
+                     const double* x_v, const double* y_v, int32_t cap, int32_t* nbounds_o, int32_t* maxbound_o,
+                     int32_t* maxisland_o, int32_t* numislands_o, double* bx, double* by, double* hx, double* hy,
+                     int32_t* hid, double* bnd_x, double* bnd_y, int32_t* land) {
+  if (vi < 5 || uj < 5 || !mask_rho || !x_u || !y_u || !x_v || !y_v || !nbounds_o || !maxbound_o || !maxisland_o ||
+      !numislands_o || !bx || !by || !hx || !hy || !hid || !bnd_x || !bnd_y || !land)
+    return LT_ERR_ARG;
+  ltb::Bounds B(vi, uj, mask_rho);
+  if (B.build() != 0) return LT_ERR_ARG;
+  const std::vector<ltb::Point>& P = B.points();
+  const int ui = vi - 1, numpoly = P.back().poly, numislands = numpoly - 1;
+  std::vector<int> size(numpoly + 1, 0), first(numpoly + 2, 0);
+  for (const ltb::Point& p : P) size[p.poly]++;
+  for (int m = 1; m <= numpoly; m++) first[m + 1] = first[m] + size[m];
+  const int maxbound = size[1] + 1;
+  int maxisland = numislands;
+  for (int m = 2; m <= numpoly; m++) maxisland += size[m];
+  const int nbounds = maxbound + maxisland - numislands - 1;
+  if (maxbound > cap || maxisland > cap || nbounds > cap) return LT_ERR_ARG;
+  auto xy = [&](const ltb::Point& p, double& x, double& y) {
+    if (p.onU) { x = x_u[(size_t)(p.i - 1) + (size_t)ui * (p.j - 1)]; y = y_u[(size_t)(p.i - 1) + (size_t)ui * (p.j - 1)]; }
+    else { x = x_v[(size_t)(p.i - 1) + (size_t)vi * (p.j - 1)]; y = y_v[(size_t)(p.i - 1) + (size_t)vi * (p.j - 1)]; }
+  };
+  // open ocean: a point on the rim of the grid next to a water node of the outermost ring (:1071-1079)
+  auto open_ocean = [&](const ltb::Point& p) {
+    if (p.onU) return (p.i == 1 && B.water(1, p.j)) || (p.i == vi - 1 && B.water(vi, p.j));
+    return (p.j == 1 && B.water(p.i, 1)) || (p.j == uj - 1 && B.water(p.i, uj));
+  };
+  std::vector<char> oo(maxbound, 0);
+  for (int k = 0; k < maxbound; k++) {   // the main polygon, closed by repeating its first point
+    const ltb::Point& p = P[first[1] + (k < size[1] ? k : 0)];
+    xy(p, bx[k], by[k]);
+    oo[k] = open_ocean(p);
+  }
+  int c = 0;
+  for (int m = 2; m <= numpoly; m++)
+    for (int k = 0; k <= size[m]; k++, c++) {
+      xy(P[first[m] + (k < size[m] ? k : 0)], hx[c], hy[c]);
+      hid[c] = m + 999;   // island ids start at 1001
+    }
+  for (int i = 0; i < maxbound - 1; i++) {
+    bnd_x[2 * i] = bx[i]; bnd_y[2 * i] = by[i]; bnd_x[2 * i + 1] = bx[i + 1]; bnd_y[2 * i + 1] = by[i + 1];
+    land[i] = (oo[i] && oo[i + 1]) ? 0 : 1;
+  }
+  int q = maxbound - 1;
+  for (int i = 0; i + 1 < maxisland; i++) {
+    if (hid[i] != hid[i + 1]) continue;   // (the closing point of one island and the first of the next)
+    bnd_x[2 * q] = hx[i]; bnd_y[2 * q] = hy[i]; bnd_x[2 * q + 1] = hx[i + 1]; bnd_y[2 * q + 1] = hy[i + 1];
+    land[q] = 1;
+    q++;
+  }
+  *nbounds_o = nbounds; *maxbound_o = maxbound; *maxisland_o = maxisland; *numislands_o = numislands;
+  return q == nbounds ? LT_OK : LT_ERR_ARG;
 }
 
 int lt_pack_positions(lt_engine* e, void* dst_device) {

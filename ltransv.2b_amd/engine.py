@@ -66,6 +66,30 @@ def _ip(a):
     return a.ctypes.data_as(abi.c_ip) if a is not None else None
 
 
+def create_bounds(vi, uj, mask_rho, x_u, y_u, x_v, y_v, lib=None):
+    """createBounds (boundary_module.f90:82-1215) on the host side of the library: -> the dict lt_set_bounds takes."""
+    lib = lib or load_hip_library()
+    m = np.asfortranarray(np.asarray(mask_rho, dtype=np.int32))
+    arr = [np.asfortranarray(np.asarray(a, dtype=np.float64)) for a in (x_u, y_u, x_v, y_v)]
+    cap = int(vi) * int(uj)
+    n = [C.c_int32() for _ in range(4)]
+    bx, by, hx, hy = (np.zeros(cap) for _ in range(4))
+    hid, land = np.zeros(cap, dtype=np.int32), np.zeros(cap, dtype=np.int32)
+    bnd_x, bnd_y = np.zeros(2 * cap), np.zeros(2 * cap)
+    f = lib.lt_create_bounds
+    f.restype = C.c_int
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    rc = f(C.c_int32(int(vi)), C.c_int32(int(uj)), vp(m), *[vp(a) for a in arr], C.c_int32(cap), *[C.byref(v) for v in n],
+           vp(bx), vp(by), vp(hx), vp(hy), vp(hid), vp(bnd_x), vp(bnd_y), vp(land))
+    if rc != 0:
+        raise LtError(rc, "lt_create_bounds")
+    nb, mb, mi, ni = (v.value for v in n)
+    return dict(nbounds=nb, maxbound=mb, maxisland=mi, numislands=ni,
+                bnd_x=np.asfortranarray(bnd_x[:2 * nb].reshape(2, nb, order="F")),
+                bnd_y=np.asfortranarray(bnd_y[:2 * nb].reshape(2, nb, order="F")), land=land[:nb].copy(),
+                bx=bx[:mb].copy(), by=by[:mb].copy(), hx=hx[:mi].copy(), hy=hy[:mi].copy(), hid=hid[:mi].copy())
+
+
 class Engine:
     """Device-resident replacement of the module state + update_particles()."""
 

@@ -309,6 +309,18 @@ module ltrans_hip
       integer(c_int) :: rc
     end function
     ! createPolySpecs (settlement_module.f90:245-480); the list members of h may be c_null_ptr
+    ! createBounds (boundary_module.f90:82-1215) on the host side of the library
+    function lt_create_bounds(vi, uj, mask_rho, x_u, y_u, x_v, y_v, cap, nbounds, maxbound, maxisland, numislands, &
+                              bx, by, hx, hy, hid, bnd_x, bnd_y, land) bind(C, name="lt_create_bounds") result(rc)
+      import :: c_int, c_int32_t, c_double
+      integer(c_int32_t), value :: vi, uj, cap
+      integer(c_int32_t), intent(in) :: mask_rho(*)
+      real(c_double), intent(in) :: x_u(*), y_u(*), x_v(*), y_v(*)
+      integer(c_int32_t), intent(out) :: nbounds, maxbound, maxisland, numislands
+      real(c_double), intent(out) :: bx(*), by(*), hx(*), hy(*), bnd_x(*), bnd_y(*)
+      integer(c_int32_t), intent(out) :: hid(*), land(*)
+      integer(c_int) :: rc
+    end function
     function lt_create_polyspecs(engine, h) bind(C, name="lt_create_polyspecs") result(rc)
       import :: c_int, c_ptr, lt_habitat
       type(c_ptr), value :: engine

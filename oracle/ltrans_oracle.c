@@ -777,3 +777,4 @@ double lto_hpval(double T, int N, const double *X, const double *Y, const double
 
 #include "ltrans_oracle_engine.inc"
 #include "ltrans_oracle_init.inc"
+#include "ltrans_oracle_bounds.inc"

@@ -60,6 +60,12 @@ int lto_locate_particles(lto_engine *e, int32_t n, const double *Xpar, const dou
                          int32_t *P_r_element, int32_t *P_u_element, int32_t *P_v_element,
                          int32_t *err, int32_t *par);
 int lto_create_polyspecs(lto_engine *e, const lt_habitat *h);
+/* createBounds (ltrans_oracle_bounds.inc): mask_rho(vi,uj), x_u/y_u(ui,uj), x_v/y_v(vi,vj) -> the arrays of
+ * lt_bounds; cap = capacity (points) of every output array (bnd_x / bnd_y: 2 x cap) */
+int lto_create_bounds(int32_t vi, int32_t uj, const int32_t *mask_rho, const double *x_u, const double *y_u,
+                      const double *x_v, const double *y_v, int32_t cap, int32_t *nbounds, int32_t *maxbound,
+                      int32_t *maxisland, int32_t *numislands, double *bx, double *by, double *hx, double *hy,
+                      int32_t *hid, double *bnd_x, double *bnd_y, int32_t *land);
 int lto_get_polyspecs(lto_engine *e, int32_t *polyspecs, int32_t *holespecs, int32_t *elepolys_ptr,
                       int32_t *elepolys_ids, int32_t elepolys_cap, int32_t *polyholes_ptr,
                       int32_t *polyholes_ids, int32_t polyholes_cap);

@@ -146,3 +146,30 @@ def engine(cfg, lib=None, prefix="lt_", **_):
     if prefix == "lto_":
         return OracleEngine(cfg, lib, prefix)
     return ltrans_amd.Engine(cfg)
+
+
+def create_bounds(lib, prefix, g, mask=None):
+    """createBounds through the C ABI form shared by the oracle (lto_) and the engine's host side (lt_):
+    -> dict like ltrans_amd.roms_synth.create_bounds"""
+    import ctypes as C
+    vi, uj = g["vi"], g["uj"]
+    m = np.asfortranarray((g["mask_rho"] if mask is None else mask).astype(np.int32))
+    F = lambda a: np.asfortranarray(a, dtype=np.float64)  # noqa: E731
+    xu, yu, xv, yv = F(g["x_u"]), F(g["y_u"]), F(g["x_v"]), F(g["y_v"])
+    cap = 2 * vi * uj
+    nb, mb, mi, ni = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    bx, by, hx, hy = (np.zeros(cap) for _ in range(4))
+    hid, land = np.zeros(cap, dtype=np.int32), np.zeros(cap, dtype=np.int32)
+    bnd_x, bnd_y = np.zeros(2 * cap), np.zeros(2 * cap)
+    f = getattr(lib, prefix + "create_bounds")
+    f.restype = C.c_int
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    rc = f(C.c_int32(vi), C.c_int32(uj), vp(m), vp(xu), vp(yu), vp(xv), vp(yv), C.c_int32(cap), C.byref(nb), C.byref(mb),
+           C.byref(mi), C.byref(ni), vp(bx), vp(by), vp(hx), vp(hy), vp(hid), vp(bnd_x), vp(bnd_y), vp(land))
+    if rc != 0:
+        raise RuntimeError(f"{prefix}create_bounds: rc = {rc}")
+    nb, mb, mi, ni = nb.value, mb.value, mi.value, ni.value
+    return dict(nbounds=nb, maxbound=mb, maxisland=mi, numislands=ni,
+                bnd_x=np.asfortranarray(bnd_x[:2 * nb].reshape(2, nb, order="F")),
+                bnd_y=np.asfortranarray(bnd_y[:2 * nb].reshape(2, nb, order="F")), land=land[:nb].copy(),
+                bx=bx[:mb].copy(), by=by[:mb].copy(), hx=hx[:mi].copy(), hy=hy[:mi].copy(), hid=hid[:mi].copy())
