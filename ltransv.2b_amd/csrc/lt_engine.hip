@@ -80,7 +80,9 @@ struct lt_engine {
   // periodic re-sort on the device (resort()): the host copy of perm is refreshed lazily
   bool perm_stale = false;
   int resort_every = 32, steps_since_sort = 0;
-  DevBuf sort_keys, sort_idx_in, sort_idx_out, sort_tmp, permute_tmp;
+  DevBuf sort_keys, sort_keys_in, sort_idx_in, sort_idx_out, sort_tmp, permute_tmp, tile_key;
+  std::vector<int32_t> h_tile_key;   // sort key of every rho element (tiles of 32 x 32 elements), host copy
+  int tile_key_bits = 1;
   DevBuf par, pr, pu, pv, P_behave, dead, oob, settle, endpoly, hitBottom, hitLand, err_code,
       P_swim, P_pediage, P_deadage, settletime, timer, P_Sprev, P_zprev, bottom, P_Salt, P_Temp;
   // rng: the reference's single serial MT19937 stream, materialised on the device
@@ -478,15 +480,17 @@ int resort(lt_engine* e) {
   TRY(dev_alloc(e, e->sort_idx_in, (size_t)n * 4));
   TRY(dev_alloc(e, e->sort_idx_out, (size_t)n * 4));
   TRY(dev_alloc(e, e->permute_tmp, (size_t)n * 13 * 8));
-  int bits = 1;
-  while (bits < 31 && (1 << bits) <= e->rho_elements) bits++;
+  TRY(dev_alloc(e, e->sort_keys_in, (size_t)n * 4));
+  const int bits = e->tile_key_bits;
+  hipLaunchKernelGGL(ltd::k_tile_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, (const int*)e->pr.p,
+                     (const int*)e->tile_key.p, (int*)e->sort_keys_in.p, n);
   size_t tmp_bytes = 0;
-  HIPCHK(e, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const int*)e->pr.p, (int*)e->sort_keys.p,
+  HIPCHK(e, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const int*)e->sort_keys_in.p, (int*)e->sort_keys.p,
                                                (const int*)e->sort_idx_in.p, (int*)e->sort_idx_out.p, n, 0, bits,
                                                e->stream));
   if (tmp_bytes > e->sort_tmp.bytes) TRY(dev_alloc(e, e->sort_tmp, tmp_bytes));
   hipLaunchKernelGGL(ltd::k_iota, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, (int*)e->sort_idx_in.p, n);
-  HIPCHK(e, hipcub::DeviceRadixSort::SortPairs(e->sort_tmp.p, tmp_bytes, (const int*)e->pr.p, (int*)e->sort_keys.p,
+  HIPCHK(e, hipcub::DeviceRadixSort::SortPairs(e->sort_tmp.p, tmp_bytes, (const int*)e->sort_keys_in.p, (int*)e->sort_keys.p,
                                                (const int*)e->sort_idx_in.p, (int*)e->sort_idx_out.p, n, 0, bits,
                                                e->stream));
   TRY(permute_buf<double>(e, e->par, 13));
@@ -765,7 +769,7 @@ int lt_destroy(lt_engine* e) {
                     &e->pv, &e->P_behave, &e->dead, &e->oob, &e->settle, &e->endpoly,
                     &e->hitBottom, &e->hitLand, &e->err_code, &e->P_swim, &e->P_pediage,
                     &e->P_deadage, &e->settletime, &e->timer, &e->P_Sprev, &e->P_zprev, &e->bottom, &e->P_Salt, &e->P_Temp, &e->S, &e->T, &e->counters, &e->ws_d, &e->ws_i, &e->orig, &e->ele_ok, &e->block_active, &e->count_slots, &e->out_cols, &e->out_hits, &e->rng_states, &e->rng_ring, &e->rng_gJ, &e->flag, &e->rank, &e->scan_tmp,
-                    &e->vt_tab, &e->vt_qS, &e->vt_qS1, &e->vt_qS2, &e->vt_qwl, &e->vt_qcount, &e->sort_keys, &e->sort_idx_in, &e->sort_idx_out,
+                    &e->vt_tab, &e->vt_qS, &e->vt_qS1, &e->vt_qS2, &e->vt_qwl, &e->vt_qcount, &e->sort_keys, &e->sort_keys_in, &e->tile_key, &e->sort_idx_in, &e->sort_idx_out,
                     &e->sort_tmp, &e->permute_tmp};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
@@ -828,6 +832,28 @@ int lt_set_grid(lt_engine* e, const lt_grid* g) {
   TRY(upload(e, e->rnode, rn.data(), rn.size() * sizeof(RhoNode)));
   TRY(upload(e, e->unode, un.data(), un.size() * sizeof(XYNode)));
   TRY(upload(e, e->vnode, vn.data(), vn.size() * sizeof(XYNode)));
+  {
+    // The internal particle order is by TILES of 32 x 32 rho elements (then rows inside a tile): the waves in
+    // flight on an XCD (each XCD works through a contiguous eighth of the order) then cover a few compact
+    // patches whose node columns stay in its L2, where whole rows of elements (the reference's element
+    // numbering) put the elements above and below a row hundreds of waves apart.  Row length from an
+    // element's own corners: (i,j), (i+1,j), (i+1,j+1), (i,j+1) -> node(4) - node(1) = vi.
+    const int T = getenv("LT_TILE") ? std::max(1, atoi(getenv("LT_TILE"))) : 32;   // (LT_TILE: experiments; 16 -> 1.33, 32 -> 1.30, 64 -> 1.29 GB per k_rk launch)
+    const int32_t* RE = g->RE;
+    const int vi_row = std::max(2, RE[3] - RE[0]);
+    const int ntx = (vi_row + T - 1) / T;
+    e->h_tile_key.resize((size_t)g->rho_elements);
+    int32_t kmax = 0;
+    for (int el = 0; el < g->rho_elements; el++) {
+      const int n1 = RE[(size_t)el * 4] - 1, i = n1 % vi_row, j = n1 / vi_row;
+      const int32_t key = (((j / T) * ntx + (i / T)) * T + (j % T)) * T + (i % T);
+      e->h_tile_key[(size_t)el] = key;
+      kmax = std::max(kmax, key);
+    }
+    e->tile_key_bits = 1;
+    while (e->tile_key_bits < 31 && (1 << e->tile_key_bits) <= kmax) e->tile_key_bits++;
+    TRY(upload(e, e->tile_key, e->h_tile_key.data(), e->h_tile_key.size() * 4));
+  }
   TRY(upload(e, e->RE, g->RE, (size_t)g->rho_elements * 16));
   TRY(upload(e, e->UE, g->UE, (size_t)g->u_elements * 16));
   TRY(upload(e, e->VE, g->VE, (size_t)g->v_elements * 16));
@@ -1297,8 +1323,9 @@ int lt_set_particles(lt_engine* e, const lt_particles* p) {
     e->perm.resize(n);
     for (size_t i = 0; i < n; i++) e->perm[i] = (int)i;
     if (e->sort_particles && p->P_r_element) {
-      const int32_t* key = p->P_r_element;
-      std::stable_sort(e->perm.begin(), e->perm.end(), [key](int a, int b) { return key[a] < key[b]; });
+      const int32_t* el = p->P_r_element;
+      const int32_t* tk = e->h_tile_key.data();
+      std::stable_sort(e->perm.begin(), e->perm.end(), [el, tk](int a, int b) { return tk[el[a] - 1] < tk[el[b] - 1]; });
     }
     TRY(upload(e, e->orig, e->perm.data(), n * 4));
     TRY(dev_alloc(e, e->ws_d, (size_t)WS_NDOUBLE * n * 8));
@@ -1871,10 +1898,11 @@ __global__ void k_test_spline_n(const double* in, double* out, double4* tab, int
   for (int k = 2; k <= n && !fail; k++) {
     const double DX = X[k - 1] - X[k - 2];
     if (DX <= 0.0) { fail = true; break; }
-    const double S = (Y[k - 1] - Y[k - 2]) / DX;
-    if (k == 3) { YPp = ypc1_end(Sp, Sp + DXp * (Sp - S) / (DXp + DX)); t[0].z = YPp; }
-    if (k >= 3) { const double YPc = ypc1_mid(DXp, DX, Sp, S); t[(size_t)(k - 2) * VT_TS].z = YPc; YPp = YPc; }
-    if (k == n) t[(size_t)(k - 1) * VT_TS].z = ypc1_end(S, S + DX * (S - Sp) / (DXp + DX));
+    const double S = div_prep(Y[k - 1] - Y[k - 2], prep_div(DX));
+    const Divisor dsum = prep_div(DXp + DX);
+    if (k == 3) { YPp = ypc1_end_b(Sp, Sp + div_prep(DXp * (Sp - S), dsum)); t[0].z = YPp; }
+    if (k >= 3) { const double YPc = ypc1_mid_b(DXp, DX, dsum, Sp, S); t[(size_t)(k - 2) * VT_TS].z = YPc; YPp = YPc; }
+    if (k == n) t[(size_t)(k - 1) * VT_TS].z = ypc1_end_b(S, S + div_prep(DX * (S - Sp), dsum));
     Sp = S; DXp = DX;
   }
   int sigerr = 0;

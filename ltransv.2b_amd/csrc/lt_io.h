@@ -164,6 +164,11 @@ __global__ void k_permute(const T* __restrict__ src, T* __restrict__ dst, const 
   const int j = idx[i];
   for (int c = 0; c < cols; c++) dst[(size_t)c * n + i] = src[(size_t)c * n + j];
 }
+// sort key of every particle: the tile key of its rho element (lt_set_grid)
+__global__ void k_tile_keys(const int* __restrict__ pr, const int* __restrict__ tile_key, int* __restrict__ keys, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) keys[i] = tile_key[pr[i] - 1];
+}
 __global__ void k_iota(int* __restrict__ v, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) v[i] = i;

@@ -302,8 +302,7 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
     LINE(s, wz1[s], WZ(s, 2), kh1[s], KH(s, 2));
     RAW(s, 3);  // ws >= 6
   }
-  auto NEWY = [&](int s, int j) -> double {  // newy{b,c,f}(j), j = 5..p2+3
-    const double xj = NEWX(s, j);
+  auto NEWY_AT = [&](int s, double xj) -> double {  // newy{b,c,f}(j) at its abscissa xj = newx(j), j = 5..p2+3
     while (!(wzhi[s] > xj) && jlo[s] < ws - 1) {
       jlo[s] += 1;
       double g1 = (double)rawn[s][0], g2 = (double)rawn[s][1], g3 = (double)rawn[s][2], g4 = (double)rawn[s][3];
@@ -321,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
 #pragma unroll
     for (int j = 1; j <= 4; j++) wring[s][j & 7][threadIdx.x] = kh1[0];
 #pragma unroll
-    for (int j = 5; j <= 8; j++) wring[s][j & 7][threadIdx.x] = NEWY(s, j);
+    for (int j = 5; j <= 8; j++) wring[s][j & 7][threadIdx.x] = NEWY_AT(s, NEWX(s, j));
   }
   // table layout: [wave][knot][lane] records {x, y, yp, sigma}; knot k-2 is written at iteration k
   double4* tab = P.vt_tab + (size_t)(na >> 6) * (size_t)p2 * VT_TS + (size_t)(na & 63);
@@ -352,6 +351,9 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
     ntask += __popcll(m);
     return sg_here;
   };
+  // newx(k+7) of the knot in hand is newx(k+8) of the one before: kept (the reference recomputes each newx
+  // three times: as the end of the 8-point window, as its last-but-one point, and as its start)
+  double x7[3] = {NEWX(0, 8), NEWX(1, 8), NEWX(2, 8)};
 #pragma unroll 1
   for (int k = 1; k <= p2; k++) {
     double xk = 0.0, yk = 0.0;
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
         const double av = (wring[s][k & 7][t] + wring[s][(k + 1) & 7][t] + wring[s][(k + 2) & 7][t] + wring[s][(k + 3) & 7][t] +
                            wring[s][(k + 4) & 7][t] + wring[s][(k + 5) & 7][t] + wring[s][(k + 6) & 7][t] + wring[s][(k + 7) & 7][t]) / 8.0;
         const double xa = NEWX(s, k);
-        const double xm = xa + (NEWX(s, k + 7) - xa) / 2.0;
+        const double xm = xa + (x7[s] - xa) / 2.0;
         // :197-210 pinned ends
         mx[s] = (k == 1) ? wz1[s] : (k == p2) ? wzN[s] : xm;
         my[s] = (k == 1) ? kh1[s] : (k == p2) ? khN[s] : av;
@@ -394,10 +396,12 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
       if (DX <= 0.0) {
         fail_now = true;
       } else {
-        S = (yk - ym1) / DX;  // S_{k-1}
-        if (k == 3) YPp = ypc1_end(Sp, Sp + DXp * (Sp - S) / (DXp + DX));  // YP(1)
-        if (k >= 3) YPc = ypc1_mid(DXp, DX, Sp, S);                         // YP(k-1)
-        if (k == p2) YPn = ypc1_end(S, S + DX * (S - Sp) / (DXp + DX));     // YP(N)
+        // (quotients through prepared reciprocals, sign cases as a flip / clamp / flip: lt_math.h, the forms of k_rk)
+        S = div_prep(yk - ym1, prep_div(DX));  // S_{k-1}
+        const Divisor dsum = prep_div(DXp + DX);
+        if (k == 3) YPp = ypc1_end_b(Sp, Sp + div_prep(DXp * (Sp - S), dsum));  // YP(1)
+        if (k >= 3) YPc = ypc1_mid_b(DXp, DX, dsum, Sp, S);                      // YP(k-1)
+        if (k == p2) YPn = ypc1_end_b(S, S + div_prep(DX * (S - Sp), dsum));     // YP(N)
       }
     }
     const bool ok = live && !fail_now;
@@ -430,7 +434,9 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
       if (k + 8 <= p2 + 7) {
 #pragma unroll
         for (int s = 0; s < 3; s++) {
-          wring[s][k & 7][threadIdx.x] = (k + 8 >= p2 + 4) ? khN[s] : NEWY(s, k + 8);  // high pads
+          const double x8 = NEWX(s, k + 8);
+          wring[s][k & 7][threadIdx.x] = (k + 8 >= p2 + 4) ? khN[s] : NEWY_AT(s, x8);  // high pads
+          x7[s] = x8;
         }
       }
     }
