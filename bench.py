@@ -523,19 +523,18 @@ def main():
             if send_done[b] is not None:
                 eng_stream.wait_event(send_done[b])   # the all-gather that last read this buffer
             e.pack_positions(send[b].data_ptr())
-            if backend == "nccl":
-                packed = torch.cuda.Event()
-                packed.record(eng_stream)
-                gather_stream.wait_event(packed)
-                with torch.cuda.stream(gather_stream):
+            packed = torch.cuda.Event()
+            packed.record(eng_stream)
+            gather_stream.wait_event(packed)
+            with torch.cuda.stream(gather_stream):
+                if backend == "nccl":
                     dist.all_gather_into_tensor(recv, send[b])
-                    send_done[b] = torch.cuda.Event()
-                    send_done[b].record(gather_stream)
-            else:                                       # rehearsal: through host memory
-                e.sync()
-                parts_ = [torch.empty(3 * nmax, dtype=torch.float64) for _ in range(world)]
-                dist.all_gather(parts_, send[b].cpu())
-                recv.copy_(torch.cat(parts_))
+                else:                                   # rehearsal: the same ordering, the collective through host memory
+                    parts_ = [torch.empty(3 * nmax, dtype=torch.float64) for _ in range(world)]
+                    dist.all_gather(parts_, send[b].cpu())      # (.cpu() on the gather stream: behind `packed`)
+                    recv.copy_(torch.cat(parts_), non_blocking=True)
+                send_done[b] = torch.cuda.Event()
+                send_done[b].record(gather_stream)
 
     def fence():
         e.sync()

@@ -70,3 +70,18 @@ def test_single_gpu_line_carries_config3_and_hash():
     assert t["value"] > 0 and t["roofline"]["kernel"] == "k_vt_table+k_vt_sigs+k_vt_walk"
     assert len(d["config"]["kernel_source_hash"]) == 16
     assert d["roofline"]["traffic"] is None          # not the profiled shape
+
+
+@pytest.mark.gpu
+def test_two_rank_rehearsal_under_torchrun():
+    """the way the driver starts it: python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["LT_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29611", BENCH, "--gpus", "2", "--workload", "config4",
+                        "--grid", "128x64x20", "--numpar", "40000", "--steps", "3", "--warmup", "1", "--no-single-ref"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["particles_this_rank"] == 20000
+    assert d["config"]["errors_last_step"] == 0 and d["value"] > 0
