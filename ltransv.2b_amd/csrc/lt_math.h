@@ -701,6 +701,91 @@ LT_DEV double sigs_newton(double T, bool& failed, int* nit_out = nullptr) {
   return (SIG > 0.0) ? SIG : 0.0;
 }
 
+// K Newton iterations of sigs_newton advanced in lockstep by one lane.  The arithmetic of each is
+// sigs_newton's operation for operation; what changes is the schedule: every step is evaluated in BOTH
+// forms (SIG <= .5: SNHCSH's rational form, tension_module.f90:822-834; else the exponential form) and the
+// operands of the two quotients are selected, so the 2K chains of a step interleave in the instruction
+// stream instead of running one after the other under exec masks -- the iteration is a serial chain
+// sigma -> exp / rational -> reciprocal -> sigma whose latency, not its issue slots, is what a round of the
+// cooperative pass costs.  A task that has stopped keeps its SIG; the lane leaves when all K have.
+template <int K>
+LT_DEV void sigs_newton_k(const double (&T)[K], const bool (&need)[K], double (&sg)[K], bool (&failed)[K]) {
+  const double SBIG = LT_SBIG, RTOL = LT_SIGS_RTOL, FTOL = 0.0;
+  const double P1 = -3.51754964808151394800e5, P2 = -1.15614435765005216044e4,
+               P3 = -1.63725857525983828727e2, P4 = -7.89474443963537015605e-1;
+  const double Q1 = -2.11052978884890840399e6, Q2 = 3.61578279834431989373e4,
+               Q3 = -2.77711081420602794433e2, Q4 = 1.0;
+  double SIG[K], TP1[K], mark[K];
+  int power[K], lam[K];
+  bool live[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    TP1[j] = T[j] + 1.0;
+    SIG[j] = need[j] ? sqrt(10.0 * T[j] - 20.0) : 1.0;
+    mark[j] = SIG[j]; power[j] = 1; lam[j] = 0;
+    live[j] = need[j];
+    failed[j] = false;
+  }
+  int NIT = 0;
+  for (;;) {
+    NIT = NIT + 1;
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const double s = SIG[j];
+      const bool small = s <= .5;
+      // SNHCSH, |X| <= .5 (skipped by the whole wave when none of its live tasks is there)
+      double SINHM = 1.0, COSHM = 1.0;
+#ifndef LT_NEWTON_NO_SKIP
+      if (__builtin_amdgcn_ballot_w64(small & live[j]) != 0ull)
+#endif
+      {
+        const double XS = s * s, XC = s * XS;
+        double P = ((P4 * XS + P3) * XS + P2) * XS + P1;
+        double Q = ((Q4 * XS + Q3) * XS + Q2) * XS + Q1;
+        SINHM = XC * (P / Q);
+        const double XSD4 = .25 * XS, XSD2 = XSD4 + XSD4;
+        P = ((P4 * XSD4 + P3) * XSD4 + P2) * XSD4 + P1;
+        Q = ((Q4 * XSD4 + Q3) * XSD4 + Q2) * XSD4 + Q1;
+        const double Fc = XSD4 * (P / Q);
+        const double COSHMM = XSD2 * Fc * (Fc + 2.0);
+        COSHM = COSHMM + XSD2;
+      }
+      // the exponential form
+      double EMS = exp_core((s < 512.0) ? -s : 0.0);
+      if (s >= 512.0) EMS = lt_exp(-s);  // T > 26000: rare
+      const double SSM = 1.0 - EMS * (EMS + s + s);
+      const double TM = (1.0 - EMS) * (1.0 - EMS);
+      const double N2 = 2.0 * s * EMS;
+      const Divisor ds = prep_div(small ? SINHM : SSM);
+      const double T1 = div_prep(small ? COSHM : TM, ds);
+      const double FP = T1 + s * (div_prep(small ? s : N2, ds) - T1 * T1 + 1.0);
+      const double F = s * T1 - TP1[j];
+      const bool capped = NIT > 10000;
+      const double DSIG = -F / FP;
+      const bool stop = (FP <= 0.0) | (fabs(DSIG) <= RTOL * s) | ((F >= 0.0) & (F <= FTOL)) | (fabs(F) <= RTOL);
+      const bool adv = live[j] & !capped & !stop;
+      const double nx = s + DSIG;
+      // NewtonCycle::repeats(nx) for a task that moves on
+      const bool rep = adv & ((nx == mark[j]) | (nx != nx));
+      const bool roll = adv & !rep & (lam[j] + 1 == power[j]);
+      lam[j] = roll ? 0 : (adv ? lam[j] + 1 : lam[j]);
+      mark[j] = roll ? nx : mark[j];
+      power[j] = roll ? (power[j] << 1) : power[j];
+      failed[j] = failed[j] | (live[j] & capped) | rep;
+      SIG[j] = adv ? nx : s;
+      live[j] = adv & !rep;
+      any = any | live[j];
+    }
+    if (!any) break;
+  }
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const double v = dmin(SIG[j], SBIG);
+    sg[j] = (failed[j] | !(v > 0.0)) ? 0.0 : v;
+  }
+}
+
 // monotonicity secant iteration, tension_module.f90:638-760 (out of line: rare)
 __device__ __noinline__ double sigs_secant(double S, double S1, double S2) {
   const double SBIG = LT_SBIG, RTOL = LT_SIGS_RTOL, FTOL = 0.0;

@@ -126,50 +126,61 @@ struct WaveScratch {
 // intervals and check intervals share the batches, so the wave runs ONE Newton loop per
 // batch whatever the mix (a separate loop for the few check intervals cost as much as the
 // one for the evaluation intervals).
+template <int K>
+LT_DEV void run_task_batch(WaveScratch& ws, int nev, int total, int t0) {
+  bool is_ev[K], valid[K], need[K], failed[K];
+  int tq[K], kind[K];
+  unsigned short o[K];
+  double sg[K], T[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const int t = t0 + 64 * j;
+    valid[j] = t < total;
+    is_ev[j] = t < nev;
+    tq[j] = is_ev[j] ? t : (valid[j] ? t - nev : 0);
+    o[j] = is_ev[j] ? ws.ev_owner[tq[j]] : ws.chk_owner[tq[j]];
+    sg[j] = 0.0; T[j] = 0.0;
+    kind[j] = SIGK_DONE;
+    if (is_ev[j]) {
+      // the evaluation interval: full SIGS decision
+      const double* e = ws.ev[tq[j]];
+      kind[j] = sigs_classify(e[5], e[3], e[4], sg[j], T[j]);
+    } else if (valid[j]) {
+      // a non-evaluation interval: only the convergence of its Newton iteration matters
+      T[j] = ws.chk[tq[j]][0] / ws.chk[tq[j]][1];
+      kind[j] = (T[j] > 2.0) ? SIGK_NEWTON : SIGK_DONE;
+    }
+    need[j] = kind[j] == SIGK_NEWTON;
+  }
+  double sgn[K];
+  sigs_newton_k<K>(T, need, sgn, failed);
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    if (need[j]) sg[j] = sgn[j];
+    else if (kind[j] == SIGK_SECANT) sg[j] = sigs_secant(ws.ev[tq[j]][5], ws.ev[tq[j]][3], ws.ev[tq[j]][4]);  // rare
+    if (is_ev[j]) {
+      const double* e = ws.ev[tq[j]];
+      ws.res[o[j] >> 6][o[j] & 63] = hval_interval_s(e[6], e[0], e[1], e[2], e[3], e[4], e[5], sg[j]);
+    }
+    if (need[j] && failed[j]) atomicOr(&ws.errmask[o[j] & 63], 1u << (o[j] >> 6));
+  }
+}
+
 LT_DEV void run_tasks(WaveScratch& ws, int nchk, int nev, int lane, int first) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const int total = nev + nchk;
+  int t0 = first;
+#ifdef LT_RK_PAIRS
+  // two tasks per lane and trip (measured: 3 % slower than one -- the rounds are bound by issue slots once
+  // the two forms of a Newton step interleave, and the second task costs registers)
 #pragma unroll 1
-  for (int t = first + lane; t < total; t += 64) {
-    const bool is_ev = t < nev;
-    const double* e = ws.ev[is_ev ? t : 0];
-    const int tc = is_ev ? 0 : (t - nev);
-    const unsigned short o = is_ev ? ws.ev_owner[t] : ws.chk_owner[tc];
-    double sg = 0.0, T = 0.0;
-    int kind;
-    if (is_ev) {
-      // the evaluation interval: full SIGS decision
-      kind = sigs_classify(e[5], e[3], e[4], sg, T);
-    } else {
-      // a non-evaluation interval: only the convergence of its Newton iteration matters
-      T = ws.chk[tc][0] / ws.chk[tc][1];
-      kind = (T > 2.0) ? SIGK_NEWTON : SIGK_DONE;
-    }
-    bool failed = false;
-#ifdef LT_RK_TIMING
-    int nit = 0;
-    if (kind == SIGK_NEWTON) sg = sigs_newton(T, failed, &nit);
-#else
-    if (kind == SIGK_NEWTON) sg = sigs_newton(T, failed);
+  for (; total - t0 > 64; t0 += 128) run_task_batch<2>(ws, nev, total, t0 + lane);
 #endif
-    else if (kind == SIGK_SECANT) sg = sigs_secant(e[5], e[3], e[4]);  // rare
-#ifdef LT_RK_TIMING
-    {
-      int mx = nit;
-      for (int off = 32; off > 0; off >>= 1) { int o2 = __shfl_xor(mx, off, 64); mx = (o2 > mx) ? o2 : mx; }
-      int sm = nit;
-      for (int off = 32; off > 0; off >>= 1) sm += __shfl_xor(sm, off, 64);
-      const unsigned long long mn = __ballot(kind == SIGK_NEWTON), msec = __ballot(kind == SIGK_SECANT);
-      const unsigned long long mlow = __ballot(is_ev && fabs(sg) > 1e-9 && fabs(sg) <= .5), mhigh = __ballot(is_ev && fabs(sg) > .5);
-      if (lane == 0) { ws.tim[8] += 1; ws.tim[9] += mx; ws.tim[10] += sm; ws.tim[11] += __popcll(mn); ws.tim[12] += __popcll(msec);
-                       ws.tim[13] += __popcll(mlow); ws.tim[14] += __popcll(mhigh); ws.tim[15] += (total - t + lane < 64) ? (total - t + lane) : 64; }
-    }
-#endif
-    if (is_ev) ws.res[o >> 6][o & 63] = hval_interval_s(e[6], e[0], e[1], e[2], e[3], e[4], e[5], sg);
-    if (failed) atomicOr(&ws.errmask[o & 63], 1u << (o >> 6));
-  }
+#pragma unroll 1
+  for (; t0 < total; t0 += 64)
+    if (t0 + lane < total) run_task_batch<1>(ws, nev, total, t0 + lane);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

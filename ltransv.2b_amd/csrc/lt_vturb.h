@@ -468,16 +468,21 @@ __global__ __launch_bounds__(256) void k_vt_sigs(const StepParams P) {
 #pragma unroll 1
   for (int t = lane; t - lane < count; t += 64) {
     rounds += 1;
-    if (t < count) {
-      const double S = Q.S[qb + t], S1 = Q.S1[qb + t], S2 = Q.S2[qb + t];
-      const unsigned wl = Q.wl[qb + t];
-      double sg = 0.0, T = 0.0;
-      bool failed = false;
-      const int kind = sigs_classify(S, S1, S2, sg, T);
-      if (kind == SIGK_NEWTON) sg = sigs_newton(T, failed);
-      else if (kind == SIGK_SECANT) sg = sigs_secant(S, S1, S2);
+    const bool have = t < count;
+    const size_t ti = qb + (have ? t : 0);
+    const double S = Q.S[ti], S1 = Q.S1[ti], S2 = Q.S2[ti];
+    const unsigned wl = Q.wl[ti];
+    double sg = 0.0;
+    double T[1] = {0.0}, sgn[1];
+    const int kind = have ? sigs_classify(S, S1, S2, sg, T[0]) : SIGK_DONE;
+    const bool need[1] = {kind == SIGK_NEWTON};
+    bool failed[1];
+    sigs_newton_k<1>(T, need, sgn, failed);      // the whole wave, lanes without a Newton task idle in it
+    if (need[0]) sg = sgn[0];
+    else if (kind == SIGK_SECANT) sg = sigs_secant(S, S1, S2);
+    if (have) {
       P.vt_tab[((size_t)wave * (size_t)p2 + (wl >> 6)) * VT_TS + (wl & 63u)].w = sg;
-      if (failed) atomicOr(&P.ws_i[(size_t)wave * 64 + (wl & 63u)], (int)FL_VT_SIGERR);
+      if (need[0] && failed[0]) atomicOr(&P.ws_i[(size_t)wave * 64 + (wl & 63u)], (int)FL_VT_SIGERR);
     }
   }
   if (lane == 0 && rounds) atomicAdd(&P.counters[CNT_VT_ROUNDS], (unsigned long long)rounds);

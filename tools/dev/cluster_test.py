@@ -1,7 +1,7 @@
 """development aid: k_rk time with all particles inside a few cells (every gather hits the
 caches) against the uniform distribution: how much of the kernel is memory latency"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import ltrans_amd

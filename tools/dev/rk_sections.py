@@ -1,6 +1,6 @@
 """development aid: wave cycles per section of k_rk (library built with -DLT_RK_TIMING)"""
 import ctypes as C, os, sys, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ["LT_HIP_LIBRARY"] = os.path.join(ROOT, "build", "libltrans_hip_timing.so")
 import numpy as np
