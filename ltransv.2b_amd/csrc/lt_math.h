@@ -708,6 +708,7 @@ LT_DEV double sigs_newton(double T, bool& failed, int* nit_out = nullptr) {
 // stream instead of running one after the other under exec masks -- the iteration is a serial chain
 // sigma -> exp / rational -> reciprocal -> sigma whose latency, not its issue slots, is what a round of the
 // cooperative pass costs.  A task that has stopped keeps its SIG; the lane leaves when all K have.
+#define LT_NEWTON_CYC_START 8
 template <int K>
 LT_DEV void sigs_newton_k(const double (&T)[K], const bool (&need)[K], double (&sg)[K], bool (&failed)[K]) {
   const double SBIG = LT_SBIG, RTOL = LT_SIGS_RTOL, FTOL = 0.0;
@@ -722,12 +723,15 @@ LT_DEV void sigs_newton_k(const double (&T)[K], const bool (&need)[K], double (&
   for (int j = 0; j < K; ++j) {
     TP1[j] = T[j] + 1.0;
     SIG[j] = need[j] ? sqrt(10.0 * T[j] - 20.0) : 1.0;
-    mark[j] = SIG[j]; power[j] = 1; lam[j] = 0;
+    mark[j] = 0.0; power[j] = 1; lam[j] = 0;
     live[j] = need[j];
     failed[j] = false;
   }
   int NIT = 0;
   for (;;) {
+#ifdef LT_RK_MARK
+    asm volatile("; MARK 30");
+#endif
     NIT = NIT + 1;
     bool any = false;
 #pragma unroll
@@ -766,17 +770,27 @@ LT_DEV void sigs_newton_k(const double (&T)[K], const bool (&need)[K], double (&
       const bool stop = (FP <= 0.0) | (fabs(DSIG) <= RTOL * s) | ((F >= 0.0) & (F <= FTOL)) | (fabs(F) <= RTOL);
       const bool adv = live[j] & !capped & !stop;
       const double nx = s + DSIG;
-      // NewtonCycle::repeats(nx) for a task that moves on
-      const bool rep = adv & ((nx == mark[j]) | (nx != nx));
-      const bool roll = adv & !rep & (lam[j] + 1 == power[j]);
-      lam[j] = roll ? 0 : (adv ? lam[j] + 1 : lam[j]);
-      mark[j] = roll ? nx : mark[j];
-      power[j] = roll ? (power[j] << 1) : power[j];
+      // Cycle detection (NewtonCycle) for a task that moves on.  A sequence that is going to repeat can be
+      // caught from any of its points, so the bookkeeping starts at the 8th step (the iteration takes 3.7
+      // on average; NIT is the same for the whole wave: a scalar branch) with that iterate as the mark.
+      bool rep = adv & (nx != nx);
+      if (NIT == LT_NEWTON_CYC_START) {
+        mark[j] = nx; power[j] = 1; lam[j] = 0;
+      } else if (NIT > LT_NEWTON_CYC_START) {
+        rep = rep | (adv & (nx == mark[j]));
+        const bool roll = adv & !rep & (lam[j] + 1 == power[j]);
+        lam[j] = roll ? 0 : (adv ? lam[j] + 1 : lam[j]);
+        mark[j] = roll ? nx : mark[j];
+        power[j] = roll ? (power[j] << 1) : power[j];
+      }
       failed[j] = failed[j] | (live[j] & capped) | rep;
       SIG[j] = adv ? nx : s;
       live[j] = adv & !rep;
       any = any | live[j];
     }
+#ifdef LT_RK_MARK
+    asm volatile("; MARK 31");
+#endif
     if (!any) break;
   }
 #pragma unroll

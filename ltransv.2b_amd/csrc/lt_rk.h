@@ -82,6 +82,11 @@ LT_DEV double level_at(const LevCoef& q, double zeta, double h, int Vtransform) 
 //   eval:  the evaluation interval's tension is not known without iterating:
 //          the task carries the interval, the lane that iterates evaluates HVAL.
 // Results of all 9 (variable, slot) fits of a stage are collected in res[][lane].
+#ifdef LT_RK_MARK
+#define TICKB(slot) asm volatile("; MARK " #slot)
+#else
+#define TICKB(slot) do { } while (0)
+#endif
 #ifdef LT_RK_TIMING
 // development aid: wave time per section, accumulated in the wave's LDS scratch and
 // added to g_tim once at the end of the kernel
@@ -153,7 +158,9 @@ LT_DEV void run_task_batch(WaveScratch& ws, int nev, int total, int t0) {
     need[j] = kind[j] == SIGK_NEWTON;
   }
   double sgn[K];
+  TICKB(20);
   sigs_newton_k<K>(T, need, sgn, failed);
+  TICKB(21);
 #pragma unroll
   for (int j = 0; j < K; ++j) {
     if (need[j]) sg[j] = sgn[j];
@@ -164,6 +171,7 @@ LT_DEV void run_task_batch(WaveScratch& ws, int nev, int total, int t0) {
     }
     if (need[j] && failed[j]) atomicOr(&ws.errmask[o[j] & 63], 1u << (o[j] >> 6));
   }
+  TICKB(22);
 }
 
 LT_DEV void run_tasks(WaveScratch& ws, int nchk, int nev, int lane, int first) {
