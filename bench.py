@@ -74,6 +74,9 @@ def parse(argv=None):
                     help="skip the updateHydro / print-step / init-geometry cost measurements")
     ap.add_argument("--no-turbulence-line", action="store_true",
                     help="N = 1, config2: skip the embedded configs[2] measurement (config.turbulence)")
+    ap.add_argument("--emulate-rank", default=None, metavar="R:W",
+                    help="one process does rank R's part of a W-rank run of the workload (its shard, its static window "
+                         "of the random stream; no all-gather): what one GPU of the N-rank job computes per step")
     ap.add_argument("--no-single-ref", action="store_true",
                     help="N > 1, strong scaling: skip rank 0's run of the WHOLE workload on one GPU afterwards")
     ap.add_argument("--cpu-sample", type=int, default=40000, help="particles of the bounded CPU-baseline sample")
@@ -455,13 +458,18 @@ def main():
 
     spec = resolve_workload(args, world)
     vi, uj, us = spec["vi"], spec["uj"], spec["us"]
-    lo, hi = sharding.shard_range(spec["total"], world, rank)
+    # (--emulate-rank: the shard and the stream window of rank R of W, computed by this one process)
+    em_rank, em_world = (int(x) for x in args.emulate_rank.split(":")) if args.emulate_rank else (rank, world)
+    if args.emulate_rank and (world != 1 or not 0 <= em_rank < em_world):
+        sys.stderr.write("bench.py: --emulate-rank R:W needs --gpus 1 and 0 <= R < W\n")
+        return 2
+    lo, hi = sharding.shard_range(spec["total"], em_world, em_rank)
     n = hi - lo
     g, geo, bounds = build_world(vi, uj, us, spec["reflect"])
     drift = (-0.2, -0.15) if spec["reflect"] else (0.0, 0.0)
     # every rank's shard is its own draw (seed + rank): the shards of a strong-scaling run are the
     # blocks of the global particle list that rank 0 re-assembles for the single-GPU reference
-    parts = make_parts(g, geo, bounds, n, 12345 + rank, spec["reflect"])
+    parts = make_parts(g, geo, bounds, n, 12345 + em_rank, spec["reflect"])
     rec_cache = {}
 
     def records(r, with_kh=None):
@@ -502,9 +510,12 @@ def main():
     # ranks exchange their counts before every step (one all-gather of one int64 each, one host read).
     static_window = (draws and not (1 <= spec["behavior"] <= 5) and not spec["settle"]
                      and float(parts["par"][:, 10].max()) <= 0.0)
-    if world > 1 and static_window:
-        sizes = sharding.shard_sizes(spec["total"], world)
-        e.set_rng_window(int(sum(sizes[:rank])), int(sum(sizes)), persistent=True)
+    if em_world > 1 and static_window:
+        sizes = sharding.shard_sizes(spec["total"], em_world)
+        e.set_rng_window(int(sum(sizes[:em_rank])), int(sum(sizes)), persistent=True)
+    elif em_world > world and draws:
+        sys.stderr.write("bench.py: --emulate-rank needs a workload with a static stream window\n")
+        return 2
 
     def one_step():
         ix = st.next_times()
@@ -558,7 +569,8 @@ def main():
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
     wall = float(wall_t.item())
 
-    total_particle_steps = float(spec["total"]) * args.steps
+    # (an emulated rank reports its own shard's particle-steps: one GPU's share of the job)
+    total_particle_steps = float(n if args.emulate_rank else spec["total"]) * args.steps
     value = total_particle_steps / wall
     A = algorithmic_bytes(args.slab, spec["turb"], us + 1)
     k_avg_s = (k_ms / max(k_n, 1)) * 1e-3
@@ -575,12 +587,14 @@ def main():
         "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak" if (spec["weak"] or world == 1) else "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": workload_text(spec, world, n), "baseline_config": spec["name"],
+        "config": {"workload": workload_text(spec, world, n) + (f"; THIS LINE: rank {em_rank} of {em_world} emulated by one "
+                   "process (its shard, its window of the random stream, no all-gather)" if args.emulate_rank else ""),
+                   "baseline_config": spec["name"],
                    "particles_total": spec["total"], "particles_this_rank": n, "grid": spec["grid"],
                    "slab_storage": args.slab, "kernel_source_hash": lib_hash,
                    "active_last_step": stats["active"], "errors_last_step": stats["errors"],
                    "sigerr_last_step": stats["sigerr"], "slab_rotation_s_excluded": upload_s,
-                   "rng_window": ("static" if static_window else "exchanged per step") if (world > 1 and draws) else None},
+                   "rng_window": ("static" if static_window else "exchanged per step") if (em_world > 1 and draws) else None},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "+".join(kernels), "kernel_ms_avg": k_avg_s * 1e3,

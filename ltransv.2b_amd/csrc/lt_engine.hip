@@ -11,6 +11,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <map>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -105,10 +106,17 @@ struct lt_engine {
   int64_t rng_static_before = 0, rng_static_total = -1;
   bool rng_ready = false;
   uint64_t rng_cur = 624;          // next stream word to be consumed
-  long long rng_next_block = 0;    // next block to generate
-  int rng_P = 128;                 // generator states
+  long long rng_next_block = 0;    // one past the highest block generated so far
+  int rng_P = 256;                 // generator states
   int rng_R = 0;                   // ring capacity in blocks (power of two)
-  DevBuf rng_states, rng_ring, rng_gJ;
+  DevBuf rng_states, rng_ring, rng_polys;
+  std::vector<long long> rng_pos;  // the block each generator state is positioned at
+  bool rng_gen0_raw = true;        // state 0 is still the given mt array (word 624, not a block start)
+  std::map<long long, int> rng_poly_slot;  // jump distance in blocks -> slot of x^(d*S) mod phi in rng_polys
+  std::vector<uint32_t> rng_g0;    // x^(S-624) mod phi: the mt array to the start of block 1
+  ltmt::BlockJob* rng_jobs = nullptr;  // pinned, mapped: RNG_JOB_SLOTS launches of up to P jobs
+  int rng_job_slot = 0;
+  int rng_wmax = 0;                // static windows: blocks generated per step (kept constant)
   DevBuf flag, rank, scan_tmp, vt_tab, vt_qS, vt_qS1, vt_qS2, vt_qwl, vt_qcount;
   int vt_qcap = 0;
   size_t scan_tmp_bytes = 0;
@@ -224,6 +232,7 @@ int check_particle_elements(lt_engine* e, const int32_t* pe, int numpar, int ele
 
 constexpr int RNG_LOG2_S = 20;
 constexpr size_t RNG_S = (size_t)1 << RNG_LOG2_S;  // MT19937 stream words per block
+constexpr int RNG_JOB_SLOTS = 32, RNG_MAX_POLYS = 64;
 
 size_t slab_elem(const lt_engine* e) { return e->cfg.slab_storage == LT_SLAB_F32 ? 4 : 8; }
 
@@ -526,21 +535,22 @@ int rng_configure_kernels(lt_engine* e) {
   return LT_OK;
 }
 
-// position the P generator states: state p at stream position p*S (p >= 1), state 0
-// = the given mt array (position 624; block 0 starts with those words themselves)
+// position the P generator states: state p at the start of block p (p >= 1), state 0
+// = the given mt array (word 624; block 0 starts with those words themselves)
 int rng_init_device(lt_engine* e) {
   TRY(rng_configure_kernels(e));
   const int P = e->rng_P;
   const ltmt::Poly& phi = mt_phi();
   if (phi.empty()) return fail(e, LT_ERR_DEVICE, "MT19937 characteristic polynomial failed");
-  std::vector<uint32_t> g0 = ltmt::jump_polynomial(phi, RNG_S - 624);
+  e->rng_g0 = ltmt::jump_polynomial(phi, RNG_S - 624);
   std::vector<uint32_t> gS = ltmt::jump_polynomial(phi, RNG_S);
-  std::vector<uint32_t> gJ = ltmt::jump_polynomial(phi, (uint64_t)(P - 1) * RNG_S);
   DevBuf d_g0, d_gS;
-  TRY(upload(e, d_g0, g0.data(), g0.size() * 4));
+  TRY(upload(e, d_g0, e->rng_g0.data(), e->rng_g0.size() * 4));
   TRY(upload(e, d_gS, gS.data(), gS.size() * 4));
-  TRY(upload(e, e->rng_gJ, gJ.data(), gJ.size() * 4));
-  TRY(dev_alloc(e, e->rng_states, (size_t)P * 624 * 4));
+  if (!e->rng_polys.p) TRY(dev_alloc(e, e->rng_polys, (size_t)RNG_MAX_POLYS * ltmt::GW * 4));
+  e->rng_poly_slot.clear();
+  if (!e->rng_states.p) TRY(dev_alloc(e, e->rng_states, (size_t)P * 624 * 4));
+  if (!e->rng_jobs) HIPCHK(e, hipHostMalloc((void**)&e->rng_jobs, sizeof(ltmt::BlockJob) * (size_t)RNG_JOB_SLOTS * P, hipHostMallocMapped));
   HIPCHK(e, hipMemcpyAsync(e->rng_states.p, e->mt, 624 * 4, hipMemcpyHostToDevice, e->stream));
   for (int p = 1; p < P; p++) {
     hipLaunchKernelGGL(ltmt::k_mt_jump, dim3(1), dim3(256), ltmt::LDS_BYTES, e->stream,
@@ -551,28 +561,61 @@ int rng_init_device(lt_engine* e) {
   HIPCHK(e, hipStreamSynchronize(e->stream));
   (void)hipFree(d_g0.p);
   (void)hipFree(d_gS.p);
+  e->rng_pos.assign(P, 0);
+  for (int p = 0; p < P; p++) e->rng_pos[p] = p;
+  e->rng_gen0_raw = true;
   e->rng_next_block = 0;
+  e->rng_wmax = 0;
   e->rng_cur = (uint64_t)e->mti;
   e->rng_ready = true;
   return LT_OK;
 }
 
-// make stream words [first, last] resident in the ring
+// the slot of the jump polynomial x^(d*S) mod phi (computed on the host at its first use: ~0.1 s)
+int rng_poly_for(lt_engine* e, long long d, int* slot) {
+  auto it = e->rng_poly_slot.find(d);
+  if (it != e->rng_poly_slot.end()) { *slot = it->second; return LT_OK; }
+  const int k = (int)e->rng_poly_slot.size();
+  if (k >= RNG_MAX_POLYS) return fail(e, LT_ERR_STATE, "MT19937 stream: more than %d distinct jump distances", RNG_MAX_POLYS);
+  const std::vector<uint32_t> g = ltmt::jump_polynomial(mt_phi(), (uint64_t)d * RNG_S);
+  HIPCHK(e, hipMemcpy((uint32_t*)e->rng_polys.p + (size_t)k * ltmt::GW, g.data(), (size_t)ltmt::GW * 4, hipMemcpyHostToDevice));
+  e->rng_poly_slot[d] = k;
+  *slot = k;
+  return LT_OK;
+}
+
+// make stream words [first, last] resident in the ring.  Blocks are produced by the pool of generator states
+// (lt_mt.h): a state already sitting at a needed block takes it; the others go to states that are jumped
+// ahead.  A single engine consumes the stream contiguously: every step continues where the last one ended
+// and a state that has written its block jumps over the P-1 blocks of the others.  A shard with a STATIC
+// window (lt_set_rng_window_static) needs the same few blocks of every step's part of the stream: its
+// states jump over the other shards' words (two distances, one polynomial each) instead of generating
+// them; with windows that change from step to step the blocks in between are generated and not stored.
 int rng_ensure(lt_engine* e, uint64_t first, uint64_t last, hipStream_t gen_stream = nullptr) {
   if (!gen_stream) gen_stream = e->stream;
   if (!e->rng_ready) TRY(rng_init_device(e));
-  const long long b_lo = (long long)(first >> RNG_LOG2_S) - 1;  // keep one block of history
-  const long long b_hi = (long long)(last >> RNG_LOG2_S);
-  long long need = b_hi - std::max<long long>(b_lo, 0) + 2;
+  const int P = e->rng_P;
+  const long long b_lo = std::max<long long>((long long)(first >> RNG_LOG2_S) - 1, 0);  // keep one block of history
+  long long b_hi = (long long)(last >> RNG_LOG2_S);
+  // blocks before rng_next_block that the window still touches are resident (the ring holds need + 2 blocks);
+  // a gap in front of the window is generated through, or -- static windows -- jumped over
+  const bool skip_by_jumping = e->rng_static && b_lo > e->rng_next_block;
+  const long long start = skip_by_jumping ? b_lo : e->rng_next_block;
+  if (skip_by_jumping) {
+    // the same number of blocks every step, so that the same states make the same jumps
+    const int cnt = (int)(b_hi - start + 1);
+    if (cnt > e->rng_wmax) e->rng_wmax = cnt;
+    if (start + e->rng_wmax - 1 > b_hi) b_hi = start + e->rng_wmax - 1;
+  }
+  const long long need = b_hi - b_lo + 2;
   int R = 4;
   while (R < need) R <<= 1;
   if (R > e->rng_R) {
-    // (re)allocate the ring; blocks still needed are regenerated from scratch only
-    // when the ring is first created, otherwise copied into the larger ring
+    // (re)allocate the ring; blocks still needed are copied into the larger ring
     DevBuf nr;
     TRY(dev_alloc(e, nr, (size_t)R * RNG_S * 4));
     if (e->rng_ring.p) {
-      for (long long b = std::max<long long>(b_lo, 0); b < e->rng_next_block; b++) {
+      for (long long b = b_lo; b < e->rng_next_block; b++) {
         HIPCHK(e, hipMemcpyAsync((uint32_t*)nr.p + (size_t)(b % R) * RNG_S,
                                  (uint32_t*)e->rng_ring.p + (size_t)(b % e->rng_R) * RNG_S,
                                  RNG_S * 4, hipMemcpyDeviceToDevice, e->stream));
@@ -583,16 +626,80 @@ int rng_ensure(lt_engine* e, uint64_t first, uint64_t last, hipStream_t gen_stre
     e->rng_ring = nr;
     e->rng_R = R;
   }
-  while (e->rng_next_block <= b_hi) {
-    const int P = e->rng_P;
-    long long nb = std::min<long long>(P, b_hi - e->rng_next_block + 1);
-    hipLaunchKernelGGL(ltmt::k_mt_block, dim3((unsigned)nb), dim3(256), ltmt::LDS_BYTES, gen_stream,
-                       (uint32_t*)e->rng_states.p, (uint32_t*)e->rng_ring.p, e->rng_next_block,
-                       std::max<long long>(b_lo, 0), P,
-                       e->rng_R, (const uint32_t*)e->rng_gJ.p, (int)RNG_S, P > 1 ? 1 : 0);
-    HIPCHK(e, hipGetLastError());
-    e->rng_next_block += nb;
+  if (e->rng_gen0_raw && start > 0) {
+    // block 0 is not going to be written by this engine: state 0 moves from the mt array to block 1
+    DevBuf d_g0;
+    TRY(upload(e, d_g0, e->rng_g0.data(), e->rng_g0.size() * 4));
+    hipLaunchKernelGGL(ltmt::k_mt_jump, dim3(1), dim3(256), ltmt::LDS_BYTES, e->stream, (uint32_t*)e->rng_states.p, 0, 0,
+                       (const uint32_t*)d_g0.p);
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    (void)hipFree(d_g0.p);
+    e->rng_pos[0] = 1;
+    e->rng_gen0_raw = false;
   }
+  int launches = 0;
+  for (long long c0 = start; c0 <= b_hi; c0 += P) {
+    const int nb = (int)std::min<long long>(P, b_hi - c0 + 1);
+    if (launches == RNG_JOB_SLOTS) {  // every job slot is in flight
+      HIPCHK(e, hipStreamSynchronize(gen_stream));
+      launches = 0;
+    }
+    ltmt::BlockJob* jobs = e->rng_jobs + (size_t)e->rng_job_slot * P;
+    e->rng_job_slot = (e->rng_job_slot + 1) % RNG_JOB_SLOTS;
+    std::vector<int> owner(nb, -1);
+    std::vector<char> used(P, 0);
+    // A contiguous stream: block b belongs to state b mod P (it sits at b, or P-1 blocks behind it in the
+    // steady state).  Otherwise a state that sits at a needed block takes it and, behind a gap that was
+    // jumped over, the others go highest block first to the free state closest behind (the states of the
+    // step before, all at the same distance).  Whatever is left (the two ways of use mixed): lowest block
+    // first, to the free state furthest behind.
+    if (!skip_by_jumping)
+      for (int o = 0; o < nb; o++) {
+        const int p = (int)((c0 + o) % P);
+        if (e->rng_pos[p] <= c0 + o) { owner[o] = p; used[p] = 1; }
+      }
+    for (int p = 0; p < P; p++) {
+      const long long o = e->rng_pos[p] - c0;
+      if (!used[p] && o >= 0 && o < nb && owner[o] < 0) { owner[o] = p; used[p] = 1; }
+    }
+    std::vector<int> order;
+    for (int p = 0; p < P; p++) if (!used[p]) order.push_back(p);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return e->rng_pos[a] < e->rng_pos[b]; });
+    std::vector<int> rest;
+    for (int o = 0; o < nb; o++) if (owner[o] < 0) rest.push_back(o);
+    if (rest.size() > order.size()) return fail(e, LT_ERR_STATE, "MT19937 stream: no free generator state");
+    if (skip_by_jumping) {
+      int q = (int)order.size() - 1;
+      for (int r = (int)rest.size() - 1; r >= 0; r--) {
+        while (q >= 0 && e->rng_pos[order[q]] > c0 + rest[r]) q--;
+        if (q < 0) return fail(e, LT_ERR_STATE, "MT19937 stream: block %lld lies behind every generator state", c0 + rest[r]);
+        owner[rest[r]] = order[q--];
+      }
+    } else {
+      for (size_t r = 0; r < rest.size(); r++) {
+        if (e->rng_pos[order[r]] > c0 + rest[r])
+          return fail(e, LT_ERR_STATE, "MT19937 stream: block %lld lies behind every generator state", c0 + rest[r]);
+        owner[rest[r]] = order[r];
+      }
+    }
+    for (int o = 0; o < nb; o++) {
+      const int p = owner[o];
+      const long long blk = c0 + o, d = blk - e->rng_pos[p];
+      int slot = -1;
+      if (d > 0) TRY(rng_poly_for(e, d, &slot));
+      jobs[o].blk = blk; jobs[o].state = p; jobs[o].poly = slot; jobs[o].store = (blk >= b_lo) ? 1 : 0; jobs[o].pad_ = 0;
+      e->rng_pos[p] = blk + 1;
+      if (p == 0) e->rng_gen0_raw = false;
+    }
+    ltmt::BlockJob* djobs = nullptr;
+    HIPCHK(e, hipHostGetDevicePointer((void**)&djobs, jobs, 0));
+    hipLaunchKernelGGL(ltmt::k_mt_block, dim3((unsigned)nb), dim3(256), ltmt::LDS_BYTES, gen_stream,
+                       (uint32_t*)e->rng_states.p, (uint32_t*)e->rng_ring.p, (const ltmt::BlockJob*)djobs, e->rng_R,
+                       (const uint32_t*)e->rng_polys.p, (int)RNG_S);
+    HIPCHK(e, hipGetLastError());
+    launches++;
+  }
+  if (b_hi + 1 > e->rng_next_block) e->rng_next_block = b_hi + 1;
   return LT_OK;
 }
 
@@ -768,7 +875,7 @@ int lt_destroy(lt_engine* e) {
                     &e->ep_ptr, &e->ep_ids, &e->ph_ptr, &e->ph_ids, &e->par, &e->pr, &e->pu,
                     &e->pv, &e->P_behave, &e->dead, &e->oob, &e->settle, &e->endpoly,
                     &e->hitBottom, &e->hitLand, &e->err_code, &e->P_swim, &e->P_pediage,
-                    &e->P_deadage, &e->settletime, &e->timer, &e->P_Sprev, &e->P_zprev, &e->bottom, &e->P_Salt, &e->P_Temp, &e->S, &e->T, &e->counters, &e->ws_d, &e->ws_i, &e->orig, &e->ele_ok, &e->block_active, &e->count_slots, &e->out_cols, &e->out_hits, &e->rng_states, &e->rng_ring, &e->rng_gJ, &e->flag, &e->rank, &e->scan_tmp,
+                    &e->P_deadage, &e->settletime, &e->timer, &e->P_Sprev, &e->P_zprev, &e->bottom, &e->P_Salt, &e->P_Temp, &e->S, &e->T, &e->counters, &e->ws_d, &e->ws_i, &e->orig, &e->ele_ok, &e->block_active, &e->count_slots, &e->out_cols, &e->out_hits, &e->rng_states, &e->rng_ring, &e->rng_polys, &e->flag, &e->rank, &e->scan_tmp,
                     &e->vt_tab, &e->vt_qS, &e->vt_qS1, &e->vt_qS2, &e->vt_qwl, &e->vt_qcount, &e->sort_keys, &e->sort_keys_in, &e->tile_key, &e->sort_idx_in, &e->sort_idx_out,
                     &e->sort_tmp, &e->permute_tmp};
   for (DevBuf* b : bufs)
@@ -788,6 +895,7 @@ int lt_destroy(lt_engine* e) {
   if (e->compute_mark) (void)hipEventDestroy(e->compute_mark);
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
   if (e->rng_done) (void)hipEventDestroy(e->rng_done);
+  if (e->rng_jobs) (void)hipHostFree(e->rng_jobs);
   if (e->rng_stream) (void)hipStreamDestroy(e->rng_stream);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;

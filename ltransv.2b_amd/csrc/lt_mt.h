@@ -4,11 +4,14 @@
 //
 // The reference draws every random number of a run from ONE generator in
 // particle order.  Here the same stream is MATERIALISED in HBM in blocks of
-// LT_MT_BLOCK raw words: block b holds stream words [b*S, (b+1)*S).  P
-// generator workgroups each own the blocks b = p (mod P): after writing its
-// block (which advances its state by S words) a workgroup jumps ahead by
-// (P-1)*S words with the polynomial method of Haramoto, Matsumoto, Nishimura,
-// Panneton & L'Ecuyer (2008): F^J s = g(F) s with g(x) = x^J mod phi(x), phi =
+// S raw words: block b holds stream words [b*S, (b+1)*S).  A pool of P
+// generator states, each positioned at the start of some block, produces the
+// blocks a step needs, one workgroup per block: a state that does not sit at
+// its block yet first jumps ahead by a whole number of blocks with the polynomial
+// method of Haramoto, Matsumoto, Nishimura, Panneton & L'Ecuyer (2008) (in the
+// steady state of a single engine: by P-1 blocks after every block written; a
+// shard of a multi-GPU run jumps over the other shards' part of the stream
+// instead of generating it): F^J s = g(F) s with g(x) = x^J mod phi(x), phi =
 // characteristic polynomial of the MT19937 recurrence (degree 19937), evaluated
 // as  XOR_{i: g_i = 1} window_i(E)  over the sequence E generated from s.
 //
@@ -193,29 +196,31 @@ __device__ inline void jump_in_lds(uint32_t* lds, const uint32_t* __restrict__ g
   __syncthreads();
 }
 
-// One workgroup (256 threads) per generator state:
-//   1. write `count` raw stream words, starting with the word that follows the
-//      history window `state`, to out[0..count);
-//   2. leave the state advanced by `count` words, then (do_jump) jump it ahead
-//      with polynomial g.
-// Stream block 0 starts with the 624 words of the state itself (= the words
-// already in the reference's mt array, "virtual stream" V[0..623]).
+// One workgroup (256 threads) per job: generator state `state` is positioned at the start of some stream
+// block; the job jumps it ahead with polynomial `poly` (slot in `polys`, -1: it already sits at block `blk`),
+// writes the `count` raw words of stream block `blk` to the block's ring slot (store = 0: only advances the
+// state) and leaves the state positioned at block blk + 1.
+// Stream block 0 starts with the 624 words of the state itself (= the words already in the reference's mt
+// array, "virtual stream" V[0..623]).
+struct BlockJob {
+  long long blk;
+  int state, poly, store, pad_;
+};
 __global__ __launch_bounds__(256) void k_mt_block(uint32_t* __restrict__ states,
                                                   uint32_t* __restrict__ ring,
-                                                  long long first_block,  // stream block of workgroup 0
-                                                  long long keep_from,    // blocks before this one are not stored
-                                                  int nstates, int ring_blocks,
-                                                  const uint32_t* __restrict__ g, int count,
-                                                  int do_jump) {
+                                                  const BlockJob* __restrict__ jobs, int ring_blocks,
+                                                  const uint32_t* __restrict__ polys, int count) {
   extern __shared__ uint32_t lds[];  // max(N + CHUNK, DEG + N) words
   const int tid = threadIdx.x;
-  const long long blk = first_block + blockIdx.x;
-  uint32_t* st = states + (size_t)(blk % nstates) * N;
+  const BlockJob job = jobs[blockIdx.x];
+  const long long blk = job.blk;
+  uint32_t* st = states + (size_t)job.state * N;
   uint32_t* out = ring + (size_t)(blk % ring_blocks) * (size_t)count;
   const int first_copy = (blk == 0) ? N : 0;  // block 0 begins with the words of the mt array
-  const bool store = blk >= keep_from;        // skipped blocks only advance the state
+  const bool store = job.store != 0;
   for (int i = tid; i < N; i += blockDim.x) lds[i] = st[i];
   __syncthreads();
+  if (job.poly >= 0) jump_in_lds(lds, polys + (size_t)job.poly * GW, tid);
   int done = 0;
   if (first_copy > 0) {
     if (store)
@@ -249,7 +254,6 @@ __global__ __launch_bounds__(256) void k_mt_block(uint32_t* __restrict__ states,
     __syncthreads();
     done += todo;
   }
-  if (do_jump) jump_in_lds(lds, g, tid);
   for (int i = tid; i < N; i += blockDim.x) st[i] = lds[i];
 }
 

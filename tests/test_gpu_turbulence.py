@@ -92,6 +92,42 @@ def test_turbulence_sharded_windows(oracle, resort_every):
         e.close()
 
 
+def test_static_windows_jump_over_the_other_shards_words(oracle):
+    """three shards with a STATIC window (lt_set_rng_window_static): each shard's generator states jump over
+    the other shards' part of the serial stream (a step of 60k particles is 7 blocks of 2^20 words) instead
+    of generating it; the particles are those of the unsharded run -- which walks the stream block by block --
+    bit for bit, and the cursor every shard hands back is the same stream position"""
+    from ltrans_amd import sharding
+    from ltrans_amd.driver import LtransRun
+    case = cases.build_case("tiny_turb", numpar=60000)
+    N, steps, world = case["cfg"].numpar, 6, 3
+    full = _run(case, {}, 1, steps)
+    engines, runs = [], []
+    sizes = [sharding.shard_range(N, world, r) for r in range(world)]
+    for r, (lo, hi) in enumerate(sizes):
+        shard = dict(case)
+        shard["cfg"] = case["cfg"].copy(numpar=hi - lo)
+        shard["parts"] = {k: (v[lo:hi] if v.ndim == 1 else v[lo:hi, :]) for k, v in case["parts"].items()}
+        e = cases.make_engine(shard, ltrans_amd.Engine, {})
+        run = LtransRun(e, 3600, 120, case["record"])
+        run.init_hydro()
+        e.set_rng_window(lo, N, persistent=True)
+        engines.append(e)
+        runs.append(run)
+    ex = runs[0].external_times(1)
+    for it in range(1, steps + 1):
+        ix = runs[0].internal_times(ex, it)
+        for e in engines:
+            assert e.count_active(ix) == e.cfg.numpar       # what makes the static window valid
+            e.update_particles(ex, ix, 1, it)
+    got = np.vstack([e.get_particles(fields=("par",))["par"] for e in engines])
+    assert np.array_equal(got, full["par"])
+    want = _next_draws(oracle, *full["rng"])
+    for e in engines:
+        assert _next_draws(oracle, *e.get_rng()) == want
+        e.close()
+
+
 @pytest.mark.parametrize("name", ["tiny_turb", "tiny_adv"])
 def test_long_horizon_is_bit_identical(oracle, name):
     """300 internal steps: with the host-libm-exact functions of lt_libm.h the trajectories are the
