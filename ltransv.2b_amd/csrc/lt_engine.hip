@@ -528,7 +528,7 @@ const ltmt::Poly& mt_phi() {
 int rng_configure_kernels(lt_engine* e) {
   if (!e->rng_kernels_configured) {
     HIPCHK(e, hipSetDevice(e->device));
-    HIPCHK(e, hipFuncSetAttribute((const void*)ltmt::k_mt_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ltmt::LDS_BYTES));
+    HIPCHK(e, hipFuncSetAttribute((const void*)ltmt::k_mt_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ltmt::LDS_BYTES * ltmt::GEN_PER_WG)));
     HIPCHK(e, hipFuncSetAttribute((const void*)ltmt::k_mt_jump, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ltmt::LDS_BYTES));
     e->rng_kernels_configured = true;
   }
@@ -693,9 +693,15 @@ int rng_ensure(lt_engine* e, uint64_t first, uint64_t last, hipStream_t gen_stre
     }
     ltmt::BlockJob* djobs = nullptr;
     HIPCHK(e, hipHostGetDevicePointer((void**)&djobs, jobs, 0));
-    hipLaunchKernelGGL(ltmt::k_mt_block, dim3((unsigned)nb), dim3(256), ltmt::LDS_BYTES, gen_stream,
-                       (uint32_t*)e->rng_states.p, (uint32_t*)e->rng_ring.p, (const ltmt::BlockJob*)djobs, e->rng_R,
-                       (const uint32_t*)e->rng_polys.p, (int)RNG_S);
+    // (block 0 -- it starts with the words of the mt array -- goes alone: its loop counts differ)
+    for (int j0 = 0; j0 < nb;) {
+      const int nj = (c0 + j0 == 0) ? 1 : nb - j0;
+      const unsigned wgs = (unsigned)((nj + ltmt::GEN_PER_WG - 1) / ltmt::GEN_PER_WG);
+      hipLaunchKernelGGL(ltmt::k_mt_block, dim3(wgs), dim3(ltmt::GEN_THREADS * ltmt::GEN_PER_WG),
+                         ltmt::LDS_BYTES * ltmt::GEN_PER_WG, gen_stream, (uint32_t*)e->rng_states.p, (uint32_t*)e->rng_ring.p,
+                         (const ltmt::BlockJob*)(djobs + j0), nj, e->rng_R, (const uint32_t*)e->rng_polys.p, (int)RNG_S);
+      j0 += nj;
+    }
     HIPCHK(e, hipGetLastError());
     launches++;
   }

@@ -165,66 +165,105 @@ inline void host_jump(const uint32_t* h, const uint32_t* g, uint32_t* out) {
 }
 
 // ---------------------------------------------------------------- device side
-constexpr int CHUNK = 227 * 16;  // words generated per LDS pass (227 = N - M independent words)
+constexpr int CHUNK = 227 * 16;      // words generated per LDS pass (227 = N - M independent words)
+constexpr int JUMP_CHUNK = 112 * 32;  // coefficients of the jump polynomial handled per LDS pass (whole words, <= CHUNK)
+constexpr int GEN_THREADS = 256;      // threads that drive one generator state
+constexpr int GEN_PER_WG = 4;         // generator states per workgroup of k_mt_block
+constexpr int GEN_LDS_WORDS = N + CHUNK;
 
-// window (lds[0..N)) <- g(F) window; needs DEG + N words of LDS
-__device__ inline void jump_in_lds(uint32_t* lds, const uint32_t* __restrict__ g, int tid) {
-  // E = sequence generated from the window: DEG more words
-  for (int base = 0; base < DEG; base += (N - M)) {
-    const int i = base + tid;
-    if (tid < (N - M) && i < DEG) lds[N + i] = lds[M + i] ^ twist(lds[i], lds[i + 1]);
+// window (lds[0..N)) <- g(F) window, for the GEN_THREADS threads t of one generator.  The sequence E generated
+// from the window is produced JUMP_CHUNK words at a time behind a sliding window (N + JUMP_CHUNK words of LDS
+// instead of DEG + N): new window[j] = XOR_{i: g_i = 1} E[i + j]; thread t owns j = t, t+256, t+512.
+// Every thread of the workgroup calls it (barriers); `active` = this generator really jumps.
+__device__ inline void jump_in_lds(uint32_t* lds, const uint32_t* __restrict__ g, int t, bool active) {
+  uint32_t acc0 = 0, acc1 = 0, acc2 = 0;
+  for (int c = 0; c < DEG; c += JUMP_CHUNK) {
+    const int todo = (DEG - c < JUMP_CHUNK) ? (DEG - c) : JUMP_CHUNK;
+    for (int base = 0; base < todo; base += (N - M)) {
+      const int i = base + t;
+      if (active && t < (N - M) && i < todo) lds[N + i] = lds[M + i] ^ twist(lds[i], lds[i + 1]);
+      __syncthreads();
+    }
+    if (active) {
+      const int w1 = (c + todo + 31) >> 5;  // (the bits of the last word beyond DEG - 1 are zero: degree < DEG)
+      for (int w = c >> 5; w < w1; w++) {
+        uint32_t bits = g[w];
+        const int i0 = w * 32 - c;
+        while (bits) {
+          const int b = __ffs(bits) - 1;
+          bits &= bits - 1;
+          const int i = i0 + b;
+          acc0 ^= lds[i + t];
+          acc1 ^= lds[i + t + 256];
+          if (t + 512 < N) acc2 ^= lds[i + t + 512];
+        }
+      }
+    }
+    __syncthreads();
+    // slide the window by todo words
+    uint32_t keep[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const int i = t + q * 256;
+      keep[q] = (active && i < N) ? lds[todo + i] : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const int i = t + q * 256;
+      if (active && i < N) lds[i] = keep[q];
+    }
     __syncthreads();
   }
-  // new window[j] = XOR_{i: g_i} E[i+j]; thread t owns j = t, t+256, t+512
-  uint32_t acc0 = 0, acc1 = 0, acc2 = 0;
-  for (int w = 0; w < GW; w++) {
-    uint32_t bits = g[w];
-    const int i0 = w * 32;
-    while (bits) {
-      const int b = __ffs(bits) - 1;
-      bits &= bits - 1;
-      const int i = i0 + b;
-      acc0 ^= lds[i + tid];
-      acc1 ^= lds[i + tid + 256];
-      if (tid + 512 < N) acc2 ^= lds[i + tid + 512];
-    }
+  if (active) {
+    lds[t] = acc0;
+    lds[t + 256] = acc1;
+    if (t + 512 < N) lds[t + 512] = acc2;
   }
-  __syncthreads();
-  lds[tid] = acc0;
-  lds[tid + 256] = acc1;
-  if (tid + 512 < N) lds[tid + 512] = acc2;
   __syncthreads();
 }
 
-// One workgroup (256 threads) per job: generator state `state` is positioned at the start of some stream
+// GEN_THREADS threads per job, GEN_PER_WG jobs per workgroup (the 16 waves of a workgroup fill the wave slots of
+// ONE compute unit with four generators, where a workgroup per generator spread them over four times as many
+// compute units, each of which then lost a wave slot per SIMD -- half of k_rk's occupancy, which runs beside
+// this kernel -- to a generator's wave).  Generator state `state` is positioned at the start of some stream
 // block; the job jumps it ahead with polynomial `poly` (slot in `polys`, -1: it already sits at block `blk`),
 // writes the `count` raw words of stream block `blk` to the block's ring slot (store = 0: only advances the
 // state) and leaves the state positioned at block blk + 1.
 // Stream block 0 starts with the 624 words of the state itself (= the words already in the reference's mt
-// array, "virtual stream" V[0..623]).
+// array, "virtual stream" V[0..623]); the host launches that job alone (its loop counts differ).
 struct BlockJob {
   long long blk;
   int state, poly, store, pad_;
 };
-__global__ __launch_bounds__(256) void k_mt_block(uint32_t* __restrict__ states,
-                                                  uint32_t* __restrict__ ring,
-                                                  const BlockJob* __restrict__ jobs, int ring_blocks,
-                                                  const uint32_t* __restrict__ polys, int count) {
-  extern __shared__ uint32_t lds[];  // max(N + CHUNK, DEG + N) words
-  const int tid = threadIdx.x;
-  const BlockJob job = jobs[blockIdx.x];
+__global__ __launch_bounds__(GEN_THREADS * GEN_PER_WG) void k_mt_block(uint32_t* __restrict__ states,
+                                                                       uint32_t* __restrict__ ring,
+                                                                       const BlockJob* __restrict__ jobs, int njobs,
+                                                                       int ring_blocks,
+                                                                       const uint32_t* __restrict__ polys, int count) {
+  extern __shared__ uint32_t lds_all[];  // GEN_PER_WG x GEN_LDS_WORDS
+  const int sub = threadIdx.x / GEN_THREADS, tid = threadIdx.x % GEN_THREADS;
+  uint32_t* lds = lds_all + (size_t)sub * GEN_LDS_WORDS;
+  const int jn = blockIdx.x * GEN_PER_WG + sub;
+  const bool active = jn < njobs;
+  BlockJob job;
+  job.blk = 1; job.state = 0; job.poly = -1; job.store = 0; job.pad_ = 0;
+  if (active) job = jobs[jn];
   const long long blk = job.blk;
   uint32_t* st = states + (size_t)job.state * N;
   uint32_t* out = ring + (size_t)(blk % ring_blocks) * (size_t)count;
-  const int first_copy = (blk == 0) ? N : 0;  // block 0 begins with the words of the mt array
-  const bool store = job.store != 0;
-  for (int i = tid; i < N; i += blockDim.x) lds[i] = st[i];
+  // (workgroup-uniform: block 0 comes alone)
+  const int first_copy = __syncthreads_or(active && blk == 0) ? N : 0;
+  const bool store = active && job.store != 0;
+  if (active)
+    for (int i = tid; i < N; i += GEN_THREADS) lds[i] = st[i];
   __syncthreads();
-  if (job.poly >= 0) jump_in_lds(lds, polys + (size_t)job.poly * GW, tid);
+  if (__syncthreads_or(active && job.poly >= 0))
+    jump_in_lds(lds, polys + (size_t)(job.poly >= 0 ? job.poly : 0) * GW, tid, active && job.poly >= 0);
   int done = 0;
   if (first_copy > 0) {
     if (store)
-      for (int i = tid; i < first_copy; i += blockDim.x) out[i] = lds[N - first_copy + i];
+      for (int i = tid; i < first_copy; i += GEN_THREADS) out[i] = lds[N - first_copy + i];
     done = first_copy;
   }
   while (done < count) {
@@ -232,29 +271,30 @@ __global__ __launch_bounds__(256) void k_mt_block(uint32_t* __restrict__ states,
     // rounds of up to 227 independent words: E[N+i] = E[M+i] ^ twist(E[i], E[i+1])
     for (int base = 0; base < todo; base += (N - M)) {
       const int i = base + tid;
-      if (tid < (N - M) && i < todo) lds[N + i] = lds[M + i] ^ twist(lds[i], lds[i + 1]);
+      if (active && tid < (N - M) && i < todo) lds[N + i] = lds[M + i] ^ twist(lds[i], lds[i + 1]);
       __syncthreads();
     }
     if (store)
-      for (int i = tid; i < todo; i += blockDim.x) out[done + i] = lds[N + i];
+      for (int i = tid; i < todo; i += GEN_THREADS) out[done + i] = lds[N + i];
     __syncthreads();
     // slide the history window
     uint32_t keep[3];
 #pragma unroll
     for (int q = 0; q < 3; q++) {
       int i = tid + q * 256;
-      keep[q] = (i < N) ? lds[todo + i] : 0u;
+      keep[q] = (active && i < N) ? lds[todo + i] : 0u;
     }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 3; q++) {
       int i = tid + q * 256;
-      if (i < N) lds[i] = keep[q];
+      if (active && i < N) lds[i] = keep[q];
     }
     __syncthreads();
     done += todo;
   }
-  for (int i = tid; i < N; i += blockDim.x) st[i] = lds[i];
+  if (active)
+    for (int i = tid; i < N; i += GEN_THREADS) st[i] = lds[i];
 }
 
 // states[dst] = g(F) states[src]   (positioning of the generator states at start-up)
@@ -264,10 +304,10 @@ __global__ __launch_bounds__(256) void k_mt_jump(uint32_t* __restrict__ states, 
   const int tid = threadIdx.x;
   for (int i = tid; i < N; i += blockDim.x) lds[i] = states[(size_t)src * N + i];
   __syncthreads();
-  jump_in_lds(lds, g, tid);
+  jump_in_lds(lds, g, tid, true);
   for (int i = tid; i < N; i += blockDim.x) states[(size_t)dst * N + i] = lds[i];
 }
 
-constexpr size_t LDS_BYTES = (size_t)(DEG + N) * 4;  // > (N + CHUNK) * 4
+constexpr size_t LDS_BYTES = (size_t)GEN_LDS_WORDS * 4;  // per generator state
 
 }  // namespace ltmt
