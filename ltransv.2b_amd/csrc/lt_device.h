@@ -146,6 +146,9 @@ struct StepParams {
   const int* orig;                // [numpar] reference index of internal slot i
   double4* vt_tab;  // VTurb spline table [wave][4*ws][lane] of {x, y, yp, sigma}
   VtQueue vt_q;     // per-wave task lists of the SIGS iterations (lt_vturb.h)
+  // the walks that met an interval with a tension factor and are finished by k_vt_walk (lt_vturb.h):
+  // their number, the particle slots, the sub-step each resumes at
+  int *vt_wl_count, *vt_wl_list, *vt_wl_resume;
   // ---- per-step workspace exchanged between k_pre / k_rk / k_post
   unsigned char* ele_ok;  // [numpar] 1: the stored elements were found for the CURRENT position
                           //     by the setEle at the end of the previous step (LTRANS.f90:1317)

@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
   __shared__ double wring[3][8][256];
   for (int i = threadIdx.x; i < 6 * LT_LEV_STRIDE; i += blockDim.x) lev[i] = P.lev[i];
   exp_table_load();
+  if (blockIdx.x == 0 && threadIdx.x == 0) *P.vt_wl_count = 0;  // the walk kernels' list (they run after this one)
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const int wave = n >> 6;
@@ -488,40 +489,85 @@ __global__ __launch_bounds__(256) void k_vt_sigs(const StepParams P) {
   if (lane == 0 && rounds) atomicAdd(&P.counters[CNT_VT_ROUNDS], (unsigned long long)rounds);
 }
 
-// :282-335 random displacement model, idt/2 sub-steps of 2 s
+// ---- the walk, in two kernels
+// 80 % of the walks never leave the zero-tension intervals (~9 % of the intervals carry a tension factor and
+// a walk stays within a knot or two of its start), but a wave of 64 walks meets a tension factor at nearly
+// every evaluation, and the exponential / rational forms of HVAL and HPVAL -- with SNHCSH -- are 60 % of the
+// instructions of a sub-step executed for five or six lanes.  k_vt_walk_fast therefore knows the cubic form
+// only: a walk that enters an interval with a tension factor (or whose table is not a proper spline: SigErr,
+// YPC1's failure) stops at the beginning of that sub-step and is listed; k_vt_walk takes the listed walks,
+// one lane each, from the sub-step they stopped at, with every form.  Same operations per walk either way.
 struct __attribute__((packed, aligned(4))) RawWords4 { uint32_t a, b, c, d; };
-__global__ __launch_bounds__(256) void k_vt_walk(const StepParams P) {
+struct VtLite {          // the cached interval without the tension-dependent parts
+  int I;
+  double X1, X2, Y1, Y2, P1, P2, SG, SGhi;
+  double S, D1, D2;
+  Divisor dx;
+};
+LT_DEV void vt_seek_lite(VtLite& c, double T, int n, const double4* tab) {
+  bool moved = false;
+  if (c.I == 0) {  // first use: bisection
+    int lo = 1, hi = n;
+    while (hi > lo + 1) {
+      const int kk = (lo + hi) >> 1;
+      if (T < tab[(size_t)(kk - 1) * VT_TS].x) hi = kk; else lo = kk;
+    }
+    c.I = lo;
+    const double4 ra = tab[(size_t)(lo - 1) * VT_TS], rb = tab[(size_t)lo * VT_TS];
+    c.X1 = ra.x; c.Y1 = ra.y; c.P1 = ra.z; c.SG = ra.w;
+    c.X2 = rb.x; c.Y2 = rb.y; c.P2 = rb.z; c.SGhi = rb.w;
+    moved = true;
+  }
+  while (T < c.X1 && c.I > 1) {
+    c.I -= 1;
+    const double4 r = tab[(size_t)(c.I - 1) * VT_TS];
+    c.X2 = c.X1; c.Y2 = c.Y1; c.P2 = c.P1; c.SGhi = c.SG;
+    c.X1 = r.x; c.Y1 = r.y; c.P1 = r.z; c.SG = r.w;
+    moved = true;
+  }
+  while (T >= c.X2 && c.I < n - 1) {
+    c.I += 1;
+    const double4 r = tab[(size_t)c.I * VT_TS];
+    c.X1 = c.X2; c.Y1 = c.Y2; c.P1 = c.P2; c.SG = c.SGhi;
+    c.X2 = r.x; c.Y2 = r.y; c.P2 = r.z; c.SGhi = r.w;
+    moved = true;
+  }
+  if (moved) {  // vt_prepare without SNHCSH
+    const double DX = c.X2 - c.X1;
+    c.dx = prep_div(DX);
+    c.S = (c.Y2 - c.Y1) / DX;
+    c.D1 = c.S - c.P1;
+    c.D2 = c.P2 - c.S;
+  }
+}
+__global__ __launch_bounds__(256) void k_vt_walk_fast(const StepParams P) {
   __shared__ uint2 rbuf[8][256];
-  libm_tables_load<LM_EXP | LM_LOG | LM_POW | LM_SINCOS>();
+  libm_tables_load<LM_EXP | LM_LOG | LM_POW | LM_SINCOS>();  // (pow takes the exp table too)
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= P.numpar) return;
   const int fl = P.ws_i[n];
   if (!(fl & FL_ACT)) return;
-  const bool ypc_fail = (fl & FL_VT_YPCFAIL) != 0;
-  const int sigerr = (fl & FL_VT_SIGERR) ? 1 : 0;
+  const int lane = threadIdx.x & 63;
   const size_t N = (size_t)P.numpar;
   double* wsd = P.ws_d + n;
   const int p2 = 4 * P.ws;
   const double4* tab = P.vt_tab + (size_t)(n >> 6) * (size_t)p2 * VT_TS + (size_t)(n & 63);
   const double P_depth = wsd[(size_t)WS_PDEPTH * N], P_zc = wsd[(size_t)WS_PZ1 * N];
   const double P_zetac = wsd[(size_t)WS_ZETA1 * N];
-  // :282-335 random displacement model, idt/2 sub-steps of 2 s
   const double background = (double)1.0E-6f, deltat = 2.0;
   const int loop = P.idt / (int)deltat;
-  // this particle's window of the serial stream: HTurb's 4 draws come first (:1087,1098)
   unsigned long long di = P.rng_base + (unsigned long long)(unsigned)P.rank[P.orig[n]] +
                           (P.HTurbOn ? 4ull : 0ull);
   double ParZc = P_zc;
-  int il = 1;
-  VtInterval ci;
+  VtLite ci;
   ci.I = 0; ci.X1 = ci.X2 = ci.Y1 = ci.Y2 = ci.P1 = ci.P2 = ci.SG = ci.SGhi = 0.0;
-  ci.S = ci.D1 = ci.D2 = ci.SM = ci.CM = ci.CMM = 0.0; ci.dx.b = 1.0; ci.dx.y = 1.0;
-  const bool cached = (sigerr == 0) && !ypc_fail;
+  ci.S = ci.D1 = ci.D2 = 0.0; ci.dx.b = 1.0; ci.dx.y = 1.0;
+  // (a table that is not a proper spline is walked by k_vt_walk from the first sub-step)
+  bool stopped = (fl & (FL_VT_YPCFAIL | FL_VT_SIGERR)) != 0;
+  int stop_i = 1;
 #pragma unroll 1
   for (int i = 1; i <= loop; i++) {
-    // The particle's raw words are consecutive in the ring: 16 of them (8 sub-steps,
-    // one 64-B line) are fetched at a time with four 16-byte loads and parked in this
-    // thread's LDS column; word-by-word loads re-fetched the line for every sub-step.
+    if (stopped) break;
     const int sub = (i - 1) & 7;
     if (sub == 0) {
       const unsigned long long o = di & P.rng_mask;
@@ -543,6 +589,111 @@ __global__ __launch_bounds__(256) void k_vt_walk(const StepParams P) {
     const uint2 rw = rbuf[sub][threadIdx.x];
     const uint32_t raw1 = rw.x, raw2 = rw.y;
     di += 2;
+    double Kprimec = 0.0;
+    bool tens = false;
+    if (!(ParZc < P_depth || ParZc > P_zetac)) {
+      vt_seek_lite(ci, ParZc, p2, tab);
+      tens = !(fabs(ci.SG) < 1.e-9);
+      const double B1 = div_prep(ci.X2 - ParZc, ci.dx), B2 = 1.0 - B1;  // HPVAL's cubic form, :1222
+      Kprimec = ci.P1 + B2 * (ci.D1 + ci.D2 - 3.0 * B1 * (ci.D2 - ci.D1));
+    }
+    const double KprimeZc = -1.0 * Kprimec * deltat;
+    const double Z3rdc = ParZc + 0.5 * KprimeZc;
+    double KH3rdc = background;
+    if (!tens && !(Z3rdc < P_depth || Z3rdc > P_zetac)) {
+      vt_seek_lite(ci, Z3rdc, p2, tab);
+      tens = !(fabs(ci.SG) < 1.e-9);
+      const double U = Z3rdc - ci.X1;                                   // HVAL's cubic form, :1083
+      const double B2 = div_prep(U, ci.dx), B1 = 1.0 - B2;
+      KH3rdc = ci.Y1 + U * (ci.P1 + B2 * (ci.D1 + B1 * (ci.D1 - ci.D2)));
+      if (KH3rdc < background) KH3rdc = background;
+    }
+    if (tens) {  // this sub-step is k_vt_walk's
+      stopped = true;
+      stop_i = i;
+      break;
+    }
+    // norm(), norm_module.f90:25-39
+    const double dev1 = ((double)ltmt_temper(raw1) + 0.5) / 4294967296.0;
+    const double dev2 = ((double)ltmt_temper(raw2) + 0.5) / 4294967296.0;
+    const double DEV = sqrt(-2.0 * lt_log(dev1)) * lt_cos(2.0 * P.PI * dev2);
+    // (2/r * KH3rd * deltat)**0.5 with r = 1
+    ParZc = ParZc + KprimeZc + DEV * lt_pow_half(2.0 / 1.0 * KH3rdc * deltat);
+  }
+  if (!stopped) {
+    wsd[(size_t)WS_TURBV * N] = P_zc - ParZc;  // :342
+  } else {
+    wsd[(size_t)WS_TURBV * N] = ParZc;         // the depth at the beginning of sub-step stop_i
+    P.vt_wl_resume[n] = stop_i;
+  }
+  // the list of the stopped walks (one atomic per wave)
+  const unsigned long long m = __ballot(stopped);
+  if (m) {
+    const int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(P.vt_wl_count, __popcll(m));
+    base = __shfl(base, leader, 64);
+    if (stopped) P.vt_wl_list[base + __popcll(m & ((1ull << lane) - 1ull))] = n;
+  }
+}
+
+// :282-335 random displacement model, idt/2 sub-steps of 2 s: the listed walks, every form of HVAL / HPVAL
+__global__ __launch_bounds__(256) void k_vt_walk(const StepParams P) {
+  __shared__ uint2 rbuf[8][256];
+  const int nlisted = *P.vt_wl_count;
+  if ((int)(blockIdx.x * blockDim.x) >= nlisted) return;   // (the whole workgroup: launched for the worst case)
+  libm_tables_load<LM_EXP | LM_LOG | LM_POW | LM_SINCOS>();
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nlisted) return;
+  const int n = P.vt_wl_list[t];
+  const int fl = P.ws_i[n];
+  const int i0 = P.vt_wl_resume[n];     // the sub-step the walk stopped at (1: nothing done yet)
+  const bool ypc_fail = (fl & FL_VT_YPCFAIL) != 0;
+  const int sigerr = (fl & FL_VT_SIGERR) ? 1 : 0;
+  const size_t N = (size_t)P.numpar;
+  double* wsd = P.ws_d + n;
+  const int p2 = 4 * P.ws;
+  const double4* tab = P.vt_tab + (size_t)(n >> 6) * (size_t)p2 * VT_TS + (size_t)(n & 63);
+  const double P_depth = wsd[(size_t)WS_PDEPTH * N], P_zc = wsd[(size_t)WS_PZ1 * N];
+  const double P_zetac = wsd[(size_t)WS_ZETA1 * N];
+  // :282-335 random displacement model, idt/2 sub-steps of 2 s
+  const double background = (double)1.0E-6f, deltat = 2.0;
+  const int loop = P.idt / (int)deltat;
+  // this particle's window of the serial stream: HTurb's 4 draws come first (:1087,1098); two words per sub-step
+  const unsigned long long di0 = P.rng_base + (unsigned long long)(unsigned)P.rank[P.orig[n]] +
+                                 (P.HTurbOn ? 4ull : 0ull);
+  double ParZc = wsd[(size_t)WS_TURBV * N];   // left there by k_vt_walk_fast
+  int il = 1;
+  VtInterval ci;
+  ci.I = 0; ci.X1 = ci.X2 = ci.Y1 = ci.Y2 = ci.P1 = ci.P2 = ci.SG = ci.SGhi = 0.0;
+  ci.S = ci.D1 = ci.D2 = ci.SM = ci.CM = ci.CMM = 0.0; ci.dx.b = 1.0; ci.dx.y = 1.0;
+  const bool cached = (sigerr == 0) && !ypc_fail;
+#pragma unroll 1
+  for (int i = i0; i <= loop; i++) {
+    // The particle's raw words are consecutive in the ring: 16 of them (8 sub-steps,
+    // one 64-B line) are fetched at a time with four 16-byte loads and parked in this
+    // thread's LDS column; word-by-word loads re-fetched the line for every sub-step.
+    const int sub = (i - 1) & 7;
+    if (sub == 0 || i == i0) {
+      const unsigned long long di = di0 + 2ull * (unsigned long long)((i - 1) & ~7);   // the group of 8 sub-steps i is in
+      const unsigned long long o = di & P.rng_mask;
+      if (o + 16 <= P.rng_mask + 1ull) {
+        const RawWords4* src = (const RawWords4*)(P.rng_ring + o);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const RawWords4 w = src[j];
+          rbuf[2 * j][threadIdx.x] = make_uint2(w.a, w.b);
+          rbuf[2 * j + 1][threadIdx.x] = make_uint2(w.c, w.d);
+        }
+      } else {  // the window wraps around the end of the ring
+#pragma unroll 1
+        for (int j = 0; j < 8; j++)
+          rbuf[j][threadIdx.x] = make_uint2(P.rng_ring[(di + 2 * j) & P.rng_mask],
+                                            P.rng_ring[(di + 2 * j + 1) & P.rng_mask]);
+      }
+    }
+    const uint2 rw = rbuf[sub][threadIdx.x];
+    const uint32_t raw1 = rw.x, raw2 = rw.y;
     double Kprimec = 0.0;
     if (!(ParZc < P_depth || ParZc > P_zetac)) {
       if (cached) {

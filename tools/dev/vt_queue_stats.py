@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0, ".")
+import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, ltrans_amd
 from ltrans_amd import roms_synth as rs
 from ltrans_amd.driver import LtransRun
