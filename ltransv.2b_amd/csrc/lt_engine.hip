@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <map>
+#include <type_traits>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>

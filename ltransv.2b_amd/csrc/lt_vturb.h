@@ -355,8 +355,11 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
   // newx(k+7) of the knot in hand is newx(k+8) of the one before: kept (the reference recomputes each newx
   // three times: as the end of the 8-point window, as its last-but-one point, and as its start)
   double x7[3] = {NEWX(0, 8), NEWX(1, 8), NEWX(2, 8)};
-#pragma unroll 1
-  for (int k = 1; k <= p2; k++) {
+  // One knot.  MID = a knot in 4 .. p2-5 (all but seven of them): none of the end cases -- pinned end points,
+  // YP(1) / YP(N), the last interval, the pads of the window -- applies, and the compiler drops their tests,
+  // selects and the second screening from the loop that runs 120 times.
+  auto knot = [&](const int k, auto mid_tag) {
+    constexpr bool MID = decltype(mid_tag)::value;
     double xk = 0.0, yk = 0.0;
     if (act) {
       double mx[3], my[3];
@@ -369,8 +372,8 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
         const double xa = NEWX(s, k);
         const double xm = xa + (x7[s] - xa) / 2.0;
         // :197-210 pinned ends
-        mx[s] = (k == 1) ? wz1[s] : (k == p2) ? wzN[s] : xm;
-        my[s] = (k == 1) ? kh1[s] : (k == p2) ? khN[s] : av;
+        mx[s] = MID ? xm : (k == 1) ? wz1[s] : (k == p2) ? wzN[s] : xm;
+        my[s] = MID ? av : (k == 1) ? kh1[s] : (k == p2) ? khN[s] : av;
       }
       // :220-275 interpolation to the internal times, clamp, Simpson in time
       // (selects on values, not on array elements: those would turn into stack indexing)
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
     bool fail_now = false;
     double S = 0.0, DX = 0.0, YPc = 0.0, YPn = 0.0;
     const bool live = act && !ypc_fail;
-    if (live && k >= 2) {
+    if (live && (MID || k >= 2)) {
       DX = xk - xm1;  // DX_{k-1}
       if (DX <= 0.0) {
         fail_now = true;
@@ -400,48 +403,55 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
         // (quotients through prepared reciprocals, sign cases as a flip / clamp / flip: lt_math.h, the forms of k_rk)
         S = div_prep(yk - ym1, prep_div(DX));  // S_{k-1}
         const Divisor dsum = prep_div(DXp + DX);
-        if (k == 3) YPp = ypc1_end_b(Sp, Sp + div_prep(DXp * (Sp - S), dsum));  // YP(1)
-        if (k >= 3) YPc = ypc1_mid_b(DXp, DX, dsum, Sp, S);                      // YP(k-1)
-        if (k == p2) YPn = ypc1_end_b(S, S + div_prep(DX * (S - Sp), dsum));     // YP(N)
+        if (!MID && k == 3) YPp = ypc1_end_b(Sp, Sp + div_prep(DXp * (Sp - S), dsum));  // YP(1)
+        if (MID || k >= 3) YPc = ypc1_mid_b(DXp, DX, dsum, Sp, S);                      // YP(k-1)
+        if (!MID && k == p2) YPn = ypc1_end_b(S, S + div_prep(DX * (S - Sp), dsum));     // YP(N)
       }
     }
     const bool ok = live && !fail_now;
     // interval (k-2, k-1): chord slope S_{k-2} (still in Sp), derivatives YP(k-2), YP(k-1)
-    const double sgA = SIGMA(ok && k >= 3, Sp, YPp, YPc, k - 3);
+    const double sgA = SIGMA(ok && (MID || k >= 3), Sp, YPp, YPc, k - 3);
     // (the last interval (N-1, N) with YP(N-1), YP(N))
-    const double sgB = SIGMA(ok && k == p2, S, YPc, YPn, p2 - 2);
+    double sgB = 0.0;
+    if (!MID) sgB = SIGMA(ok && k == p2, S, YPc, YPn, p2 - 2);
     if (act) {
       if (ok) {
-        if (k >= 3) tab[(size_t)(k - 3) * VT_TS] = make_double4(xm2, ym2, YPp, sgA);           // knot k-2, interval (k-2, k-1)
-        if (k == p2) {
+        if (MID || k >= 3) tab[(size_t)(k - 3) * VT_TS] = make_double4(xm2, ym2, YPp, sgA);           // knot k-2, interval (k-2, k-1)
+        if (!MID && k == p2) {
           tab[(size_t)(p2 - 2) * VT_TS] = make_double4(xm1, ym1, YPc, sgB);
           tab[(size_t)(p2 - 1) * VT_TS] = make_double4(xk, yk, YPn, 0.0);
         }
       } else if (fail_now) {
-        if (k >= 3) tab[(size_t)(k - 3) * VT_TS] = make_double4(xm2, ym2, (k >= 4) ? YPp : 0.0, 0.0);
-        if (k >= 2) tab[(size_t)(k - 2) * VT_TS] = make_double4(xm1, ym1, 0.0, 0.0);
+        if (MID || k >= 3) tab[(size_t)(k - 3) * VT_TS] = make_double4(xm2, ym2, (MID || k >= 4) ? YPp : 0.0, 0.0);
+        if (MID || k >= 2) tab[(size_t)(k - 2) * VT_TS] = make_double4(xm1, ym1, 0.0, 0.0);
         tab[(size_t)(k - 1) * VT_TS] = make_double4(xk, yk, 0.0, 0.0);
         ypc_fail = true;
       } else {  // after a failure: abscissa and ordinate only
         tab[(size_t)(k - 1) * VT_TS] = make_double4(xk, yk, 0.0, 0.0);
       }
-      if (ok && k >= 2) {
-        if (k >= 3) YPp = YPc;
+      if (ok && (MID || k >= 2)) {
+        if (MID || k >= 3) YPp = YPc;
         Sp = S; DXp = DX;
       }
       xm2 = xm1; ym2 = ym1;
       xm1 = xk; ym1 = yk;
       // slide the 8-point window: drop newy(k), append newy(k+8)
-      if (k + 8 <= p2 + 7) {
+      if (MID || k + 8 <= p2 + 7) {
 #pragma unroll
         for (int s = 0; s < 3; s++) {
           const double x8 = NEWX(s, k + 8);
-          wring[s][k & 7][threadIdx.x] = (k + 8 >= p2 + 4) ? khN[s] : NEWY_AT(s, x8);  // high pads
+          wring[s][k & 7][threadIdx.x] = (!MID && k + 8 >= p2 + 4) ? khN[s] : NEWY_AT(s, x8);  // high pads
           x7[s] = x8;
         }
       }
     }
-  }
+  };
+#pragma unroll 1
+  for (int k = 1; k <= 3; k++) knot(k, std::false_type{});
+#pragma unroll 1
+  for (int k = 4; k <= p2 - 5; k++) knot(k, std::true_type{});
+#pragma unroll 1
+  for (int k = p2 - 4; k <= p2; k++) knot(k, std::false_type{});
   if (lane == 0) {
     Q.count[wave] = (ntask < Q.cap) ? ntask : Q.cap;
     if (ntask) atomicAdd(&P.counters[CNT_VT_QUEUED], (unsigned long long)ntask);
