@@ -575,7 +575,7 @@ def main():
     A = algorithmic_bytes(args.slab, spec["turb"], us + 1)
     k_avg_s = (k_ms / max(k_n, 1)) * 1e-3
     achieved = (A * n / k_avg_s) / 1e9 if k_avg_s > 0 else 0.0
-    kernels = ["k_vt_table", "k_vt_sigs", "k_vt_walk"] if spec["turb"] else ["k_rk"]
+    kernels = ["k_vt_table", "k_vt_sigs", "k_vt_walk_fast", "k_vt_walk"] if spec["turb"] else ["k_rk"]
     default_shape = (n == 1_000_000 and spec["grid"] == "512x256x30" and args.slab == "f32" and not spec["reflect"])
     traffic = traffic_src = valu = None
     if default_shape:
@@ -625,7 +625,7 @@ def main():
         kt_ms, kt_n = e_t.profile_end()
         A_t = algorithmic_bytes(args.slab, True, us + 1)
         kt_avg = (kt_ms / max(kt_n, 1)) * 1e-3
-        kern_t = ["k_vt_table", "k_vt_sigs", "k_vt_walk"]
+        kern_t = ["k_vt_table", "k_vt_sigs", "k_vt_walk_fast", "k_vt_walk"]
         tr_t, src_t, valu_t = pmc_traffic("r02_turb", kern_t, lib_hash) if default_shape else (None, None, None)
         out["config"]["turbulence"] = {
             "workload": "BASELINE configs[2]: the same + HTurb + VTurb (MT19937 stream on device)",
