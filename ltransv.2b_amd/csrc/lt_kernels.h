@@ -7,7 +7,7 @@
 //   k_beh_pre   the deterministic part of behave(), salinity cue, draw counts    (lt_rk.h)
 //   k_rk        RK4 over find_currents / WCTS_ITPI, wave-cooperative             (lt_rk.h)
 //   k_rk_slow   reference-shaped redo of the rare SigErr / degenerate cases      (lt_rk.h)
-//   k_vt_table / k_vt_sigs / k_vt_walk   VTurb                                    (lt_vturb.h)
+//   k_vt_table / k_vt_sigs / k_vt_walk_fast / k_vt_walk   VTurb                   (lt_vturb.h)
 //   k_post      HTurb, behaviour, reflection, boundaries, setEle, settlement, commit (lt_post.h)
 // plus the upload / download kernels of lt_io.h and the init-time geometry kernels of lt_init.h.  No MFMA: the path is gather + scalar fp64
 // spline arithmetic with data-dependent iteration.

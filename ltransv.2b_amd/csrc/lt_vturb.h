@@ -205,12 +205,13 @@ __device__ __noinline__ double sigs_in_lane(double S, double S1, double S2, int*
   return sg;
 }
 
-// VTurb, ver_turb_module.f90:30-380, as three kernels:
+// VTurb, ver_turb_module.f90:30-380, as four kernels:
 //   k_vt_table  one lane per particle: builds the spline table of the time-interpolated, smoothed Kh
 //               profile (TSPSI's YPC1) and settles every tension factor that needs no iteration in the
 //               same stream over the knots;
 //   k_vt_sigs   one wave per task list: the SIGS iterations of the intervals that need one;
-//   k_vt_walk   one lane per particle: the idt/2 random-walk sub-steps on the table.
+//   k_vt_walk_fast / k_vt_walk   one lane per particle: the idt/2 random-walk sub-steps on the table (the
+//               walks on zero-tension intervals; the rest of the walks that met a tension factor).
 // The ~30 work arrays of the reference are never materialised: the proliferated /
 // smoothed profile is produced as a stream over k (8-point window in an LDS ring),
 // the YPC1 derivative of knot k-1 is formed as soon as knot k exists, the interval (k-2, k-1)
