@@ -67,7 +67,7 @@ def test_single_gpu_line_carries_config3_and_hash():
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 1 and d["config"]["baseline_config"] == "config2"
     t = d["config"]["turbulence"]
-    assert t["value"] > 0 and t["roofline"]["kernel"] == "k_vt_table+k_vt_sigs+k_vt_walk"
+    assert t["value"] > 0 and t["roofline"]["kernel"] == "k_vt_table+k_vt_sigs+k_vt_walk_fast+k_vt_walk"
     assert len(d["config"]["kernel_source_hash"]) == 16
     assert d["roofline"]["traffic"] is None          # not the profiled shape
 
