@@ -107,7 +107,6 @@ struct lt_engine {
   int64_t rng_static_before = 0, rng_static_total = -1;
   bool rng_ready = false;
   uint64_t rng_cur = 624;          // next stream word to be consumed
-  long long rng_next_block = 0;    // one past the highest block generated so far
   int rng_P = 256;                 // generator states
   int rng_R = 0;                   // ring capacity in blocks (power of two)
   DevBuf rng_states, rng_ring, rng_polys;
@@ -117,7 +116,7 @@ struct lt_engine {
   std::vector<uint32_t> rng_g0;    // x^(S-624) mod phi: the mt array to the start of block 1
   ltmt::BlockJob* rng_jobs = nullptr;  // pinned, mapped: RNG_JOB_SLOTS launches of up to P jobs
   int rng_job_slot = 0;
-  int rng_wmax = 0;                // static windows: blocks generated per step (kept constant)
+  std::vector<long long> rng_ring_blk;  // the stream block each ring slot holds (-1: none)
   DevBuf flag, rank, scan_tmp, vt_tab, vt_qS, vt_qS1, vt_qS2, vt_qwl, vt_qcount, vt_wl;
   int vt_qcap = 0;
   size_t scan_tmp_bytes = 0;
@@ -568,8 +567,7 @@ int rng_init_device(lt_engine* e) {
   e->rng_pos.assign(P, 0);
   for (int p = 0; p < P; p++) e->rng_pos[p] = p;
   e->rng_gen0_raw = true;
-  e->rng_next_block = 0;
-  e->rng_wmax = 0;
+  e->rng_ring_blk.assign((size_t)e->rng_R, -1);
   e->rng_cur = (uint64_t)e->mti;
   e->rng_ready = true;
   return LT_OK;
@@ -588,50 +586,50 @@ int rng_poly_for(lt_engine* e, long long d, int* slot) {
   return LT_OK;
 }
 
-// make stream words [first, last] resident in the ring.  Blocks are produced by the pool of generator states
-// (lt_mt.h): a state already sitting at a needed block takes it; the others go to states that are jumped
-// ahead.  A single engine consumes the stream contiguously: every step continues where the last one ended
-// and a state that has written its block jumps over the P-1 blocks of the others.  A shard with a STATIC
-// window (lt_set_rng_window_static) needs the same few blocks of every step's part of the stream: its
-// states jump over the other shards' words (two distances, one polynomial each) instead of generating
-// them; with windows that change from step to step the blocks in between are generated and not stored.
+// make stream words [first, last] resident in the ring.  Block b belongs to generator state b mod P, which is
+// positioned at the start of the block it wrote last + 1 -- or further back: a block nobody asks for is never
+// generated.  A single engine asks for every block in turn, so its states jump over the P-1 blocks of the others
+// after every block written.  A SHARD's window (lt_set_rng_window*) touches a few blocks of every step's part
+// of the stream: the blocks of the other shards in between are skipped, and the owner of a needed block jumps
+// k*P - 1 blocks, k = the number of turns it was not asked -- a handful of distinct distances whatever the
+// windows do, one polynomial each (rng_poly_for).  (Before: a rank of the 8-rank run of BASELINE configs[3]
+// generated all 1183 blocks of a step to keep 150 of them.)
 int rng_ensure(lt_engine* e, uint64_t first, uint64_t last, hipStream_t gen_stream = nullptr) {
   if (!gen_stream) gen_stream = e->stream;
   if (!e->rng_ready) TRY(rng_init_device(e));
   const int P = e->rng_P;
   const long long b_lo = std::max<long long>((long long)(first >> RNG_LOG2_S) - 1, 0);  // keep one block of history
-  long long b_hi = (long long)(last >> RNG_LOG2_S);
-  // blocks before rng_next_block that the window still touches are resident (the ring holds need + 2 blocks);
-  // a gap in front of the window is generated through, or -- static windows -- jumped over
-  const bool skip_by_jumping = e->rng_static && b_lo > e->rng_next_block;
-  const long long start = skip_by_jumping ? b_lo : e->rng_next_block;
-  if (skip_by_jumping) {
-    // the same number of blocks every step, so that the same states make the same jumps
-    const int cnt = (int)(b_hi - start + 1);
-    if (cnt > e->rng_wmax) e->rng_wmax = cnt;
-    if (start + e->rng_wmax - 1 > b_hi) b_hi = start + e->rng_wmax - 1;
-  }
+  const long long b_hi = (long long)(last >> RNG_LOG2_S);
   const long long need = b_hi - b_lo + 2;
   int R = 4;
   while (R < need) R <<= 1;
   if (R > e->rng_R) {
-    // (re)allocate the ring; blocks still needed are copied into the larger ring
+    // (re)allocate the ring; resident blocks still needed are copied into the larger ring
     DevBuf nr;
     TRY(dev_alloc(e, nr, (size_t)R * RNG_S * 4));
+    std::vector<long long> nblk((size_t)R, -1);
     if (e->rng_ring.p) {
-      for (long long b = b_lo; b < e->rng_next_block; b++) {
-        HIPCHK(e, hipMemcpyAsync((uint32_t*)nr.p + (size_t)(b % R) * RNG_S,
-                                 (uint32_t*)e->rng_ring.p + (size_t)(b % e->rng_R) * RNG_S,
+      for (int sl = 0; sl < e->rng_R; sl++) {
+        const long long b = e->rng_ring_blk[sl];
+        if (b < b_lo || b > b_hi) continue;
+        HIPCHK(e, hipMemcpyAsync((uint32_t*)nr.p + (size_t)(b % R) * RNG_S, (uint32_t*)e->rng_ring.p + (size_t)sl * RNG_S,
                                  RNG_S * 4, hipMemcpyDeviceToDevice, e->stream));
+        nblk[(size_t)(b % R)] = b;
       }
       HIPCHK(e, hipStreamSynchronize(e->stream));
       (void)hipFree(e->rng_ring.p);
     }
     e->rng_ring = nr;
     e->rng_R = R;
+    e->rng_ring_blk.swap(nblk);
   }
-  if (e->rng_gen0_raw && start > 0) {
-    // block 0 is not going to be written by this engine: state 0 moves from the mt array to block 1
+  std::vector<long long> todo;
+  for (long long b = b_lo; b <= b_hi; b++)
+    if (e->rng_ring_blk[(size_t)(b % e->rng_R)] != b) todo.push_back(b);
+  if (todo.empty()) return LT_OK;
+  if (e->rng_gen0_raw && todo.front() > 0) {
+    // block 0 is not going to be written by this engine: state 0 moves from the mt array (word 624) to block P,
+    // its next turn (x^(S-624) to block 1, then P-1 blocks)
     DevBuf d_g0;
     TRY(upload(e, d_g0, e->rng_g0.data(), e->rng_g0.size() * 4));
     hipLaunchKernelGGL(ltmt::k_mt_jump, dim3(1), dim3(256), ltmt::LDS_BYTES, e->stream, (uint32_t*)e->rng_states.p, 0, 0,
@@ -642,64 +640,36 @@ int rng_ensure(lt_engine* e, uint64_t first, uint64_t last, hipStream_t gen_stre
     e->rng_gen0_raw = false;
   }
   int launches = 0;
-  for (long long c0 = start; c0 <= b_hi; c0 += P) {
-    const int nb = (int)std::min<long long>(P, b_hi - c0 + 1);
+  for (size_t next = 0; next < todo.size();) {
     if (launches == RNG_JOB_SLOTS) {  // every job slot is in flight
       HIPCHK(e, hipStreamSynchronize(gen_stream));
       launches = 0;
     }
     ltmt::BlockJob* jobs = e->rng_jobs + (size_t)e->rng_job_slot * P;
     e->rng_job_slot = (e->rng_job_slot + 1) % RNG_JOB_SLOTS;
-    std::vector<int> owner(nb, -1);
-    std::vector<char> used(P, 0);
-    // A contiguous stream: block b belongs to state b mod P (it sits at b, or P-1 blocks behind it in the
-    // steady state).  Otherwise a state that sits at a needed block takes it and, behind a gap that was
-    // jumped over, the others go highest block first to the free state closest behind (the states of the
-    // step before, all at the same distance).  Whatever is left (the two ways of use mixed): lowest block
-    // first, to the free state furthest behind.
-    if (!skip_by_jumping)
-      for (int o = 0; o < nb; o++) {
-        const int p = (int)((c0 + o) % P);
-        if (e->rng_pos[p] <= c0 + o) { owner[o] = p; used[p] = 1; }
-      }
-    for (int p = 0; p < P; p++) {
-      const long long o = e->rng_pos[p] - c0;
-      if (!used[p] && o >= 0 && o < nb && owner[o] < 0) { owner[o] = p; used[p] = 1; }
-    }
-    std::vector<int> order;
-    for (int p = 0; p < P; p++) if (!used[p]) order.push_back(p);
-    std::sort(order.begin(), order.end(), [&](int a, int b) { return e->rng_pos[a] < e->rng_pos[b]; });
-    std::vector<int> rest;
-    for (int o = 0; o < nb; o++) if (owner[o] < 0) rest.push_back(o);
-    if (rest.size() > order.size()) return fail(e, LT_ERR_STATE, "MT19937 stream: no free generator state");
-    if (skip_by_jumping) {
-      int q = (int)order.size() - 1;
-      for (int r = (int)rest.size() - 1; r >= 0; r--) {
-        while (q >= 0 && e->rng_pos[order[q]] > c0 + rest[r]) q--;
-        if (q < 0) return fail(e, LT_ERR_STATE, "MT19937 stream: block %lld lies behind every generator state", c0 + rest[r]);
-        owner[rest[r]] = order[q--];
-      }
-    } else {
-      for (size_t r = 0; r < rest.size(); r++) {
-        if (e->rng_pos[order[r]] > c0 + rest[r])
-          return fail(e, LT_ERR_STATE, "MT19937 stream: block %lld lies behind every generator state", c0 + rest[r]);
-        owner[rest[r]] = order[r];
-      }
-    }
-    for (int o = 0; o < nb; o++) {
-      const int p = owner[o];
-      const long long blk = c0 + o, d = blk - e->rng_pos[p];
+    // one launch: the next blocks as long as their owners differ (P consecutive blocks at most)
+    int nj_total = 0;
+    std::vector<char> used((size_t)P, 0);
+    for (; next < todo.size(); next++) {
+      const long long blk = todo[next];
+      const int p = (int)(blk % P);
+      if (used[(size_t)p]) break;
+      used[(size_t)p] = 1;
+      const long long d = blk - e->rng_pos[(size_t)p];
+      if (d < 0) return fail(e, LT_ERR_STATE, "MT19937 stream: block %lld lies behind its generator state", blk);
       int slot = -1;
       if (d > 0) TRY(rng_poly_for(e, d, &slot));
-      jobs[o].blk = blk; jobs[o].state = p; jobs[o].poly = slot; jobs[o].store = (blk >= b_lo) ? 1 : 0; jobs[o].pad_ = 0;
-      e->rng_pos[p] = blk + 1;
+      ltmt::BlockJob& jb = jobs[nj_total++];
+      jb.blk = blk; jb.state = p; jb.poly = slot; jb.store = 1; jb.pad_ = 0;
+      e->rng_pos[(size_t)p] = blk + 1;
       if (p == 0) e->rng_gen0_raw = false;
+      e->rng_ring_blk[(size_t)(blk % e->rng_R)] = blk;
     }
     ltmt::BlockJob* djobs = nullptr;
     HIPCHK(e, hipHostGetDevicePointer((void**)&djobs, jobs, 0));
     // (block 0 -- it starts with the words of the mt array -- goes alone: its loop counts differ)
-    for (int j0 = 0; j0 < nb;) {
-      const int nj = (c0 + j0 == 0) ? 1 : nb - j0;
+    for (int j0 = 0; j0 < nj_total;) {
+      const int nj = (jobs[j0].blk == 0) ? 1 : nj_total - j0;
       const unsigned wgs = (unsigned)((nj + ltmt::GEN_PER_WG - 1) / ltmt::GEN_PER_WG);
       hipLaunchKernelGGL(ltmt::k_mt_block, dim3(wgs), dim3(ltmt::GEN_THREADS * ltmt::GEN_PER_WG),
                          ltmt::LDS_BYTES * ltmt::GEN_PER_WG, gen_stream, (uint32_t*)e->rng_states.p, (uint32_t*)e->rng_ring.p,
@@ -709,7 +679,6 @@ int rng_ensure(lt_engine* e, uint64_t first, uint64_t last, hipStream_t gen_stre
     HIPCHK(e, hipGetLastError());
     launches++;
   }
-  if (b_hi + 1 > e->rng_next_block) e->rng_next_block = b_hi + 1;
   return LT_OK;
 }
 
@@ -1720,7 +1689,6 @@ int lt_set_rng(lt_engine* e, const int32_t* mt624, int32_t mti) {
   e->mti = mti;
   e->rng_ready = false;  // the generator states are re-positioned at the next use
   e->rng_cur = (uint64_t)mti;
-  e->rng_next_block = 0;
   return LT_OK;
 }
 

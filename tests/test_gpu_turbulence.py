@@ -92,11 +92,13 @@ def test_turbulence_sharded_windows(oracle, resort_every):
         e.close()
 
 
-def test_static_windows_jump_over_the_other_shards_words(oracle):
-    """three shards with a STATIC window (lt_set_rng_window_static): each shard's generator states jump over
-    the other shards' part of the serial stream (a step of 60k particles is 7 blocks of 2^20 words) instead
-    of generating it; the particles are those of the unsharded run -- which walks the stream block by block --
-    bit for bit, and the cursor every shard hands back is the same stream position"""
+@pytest.mark.parametrize("static", [True, False])
+def test_windows_jump_over_the_other_shards_words(oracle, static):
+    """three shards with windows (static: lt_set_rng_window_static once; else lt_set_rng_window before every
+    step): each shard's generator states jump over the other shards' part of the serial stream (a step of 60k
+    particles is 7 blocks of 2^20 words) instead of generating it; the particles are those of the unsharded
+    run -- which walks the stream block by block -- bit for bit, and the cursor every shard hands back is the
+    same stream position"""
     from ltrans_amd import sharding
     from ltrans_amd.driver import LtransRun
     case = cases.build_case("tiny_turb", numpar=60000)
@@ -111,14 +113,17 @@ def test_static_windows_jump_over_the_other_shards_words(oracle):
         e = cases.make_engine(shard, ltrans_amd.Engine, {})
         run = LtransRun(e, 3600, 120, case["record"])
         run.init_hydro()
-        e.set_rng_window(lo, N, persistent=True)
+        if static:
+            e.set_rng_window(lo, N, persistent=True)
         engines.append(e)
         runs.append(run)
     ex = runs[0].external_times(1)
     for it in range(1, steps + 1):
         ix = runs[0].internal_times(ex, it)
-        for e in engines:
+        for (lo, hi), e in zip(sizes, engines):
             assert e.count_active(ix) == e.cfg.numpar       # what makes the static window valid
+            if not static:
+                e.set_rng_window(lo, N)
             e.update_particles(ex, ix, 1, it)
     got = np.vstack([e.get_particles(fields=("par",))["par"] for e in engines])
     assert np.array_equal(got, full["par"])
