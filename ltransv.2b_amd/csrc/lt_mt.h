@@ -4,13 +4,13 @@
 //
 // The reference draws every random number of a run from ONE generator in
 // particle order.  Here the same stream is MATERIALISED in HBM in blocks of
-// S raw words: block b holds stream words [b*S, (b+1)*S).  A pool of P
-// generator states, each positioned at the start of some block, produces the
-// blocks a step needs, one workgroup per block: a state that does not sit at
-// its block yet first jumps ahead by a whole number of blocks with the polynomial
-// method of Haramoto, Matsumoto, Nishimura, Panneton & L'Ecuyer (2008) (in the
-// steady state of a single engine: by P-1 blocks after every block written; a
-// shard of a multi-GPU run jumps over the other shards' part of the stream
+// S raw words: block b holds stream words [b*S, (b+1)*S).  Block b belongs to
+// generator state b mod P, positioned at the start of the block after the one it
+// wrote last; a block nobody asks for is never generated.  The owner of a needed
+// block first jumps ahead by a whole number of blocks with the polynomial method
+// of Haramoto, Matsumoto, Nishimura, Panneton & L'Ecuyer (2008) (a single engine:
+// by P-1 blocks after every block written; a shard of a multi-GPU run: k*P-1
+// blocks, over the other shards' part of the stream
 // instead of generating it): F^J s = g(F) s with g(x) = x^J mod phi(x), phi =
 // characteristic polynomial of the MT19937 recurrence (degree 19937), evaluated
 // as  XOR_{i: g_i = 1} window_i(E)  over the sequence E generated from s.
