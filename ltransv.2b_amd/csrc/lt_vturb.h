@@ -69,6 +69,17 @@ LT_DEV double polintd_shared(double xa1, double xa2, double xa3, double ya1, dou
   const double dns = (ns == 1) ? d1 : (ns == 2) ? d2 : d3;
   return yns + dns * a + bb * c;
 }
+// (NS > 0: the node is known at compile time and the selects go -- within an external step the three internal
+// times usually share their closest record, so polintd3x3 asks once per call, a scalar branch)
+template <bool FD, int NS>
+LT_DEV void polintd3x3_ns(const StepParams& P, double ya1, double ya2, double ya3, double q32, double q21,
+                          double& rb, double& rc, double& rf) {
+  const double xa1 = P.ex0, xa2 = P.ex1, xa3 = P.ex2;
+  constexpr bool fd = FD;
+  rb = polintd_shared(xa1, xa2, xa3, ya1, ya2, ya3, q32, q21, P.r_d13, fd, P.ix0, NS > 0 ? NS : P.pns0);
+  rc = polintd_shared(xa1, xa2, xa3, ya1, ya2, ya3, q32, q21, P.r_d13, fd, P.ix1, NS > 0 ? NS : P.pns1);
+  rf = polintd_shared(xa1, xa2, xa3, ya1, ya2, ya3, q32, q21, P.r_d13, fd, P.ix2, NS > 0 ? NS : P.pns2);
+}
 template <bool FD>
 LT_DEV void polintd3x3(const StepParams& P, double ya1, double ya2, double ya3,
                        double& rb, double& rc, double& rf) {
@@ -76,9 +87,10 @@ LT_DEV void polintd3x3(const StepParams& P, double ya1, double ya2, double ya3,
   constexpr bool fd = FD;
   const double q32 = div_by(ya3 - ya2, xa2 - xa3, P.r_d23, fd);
   const double q21 = div_by(ya2 - ya1, xa1 - xa2, P.r_d12, fd);
-  rb = polintd_shared(xa1, xa2, xa3, ya1, ya2, ya3, q32, q21, P.r_d13, fd, P.ix0, P.pns0);
-  rc = polintd_shared(xa1, xa2, xa3, ya1, ya2, ya3, q32, q21, P.r_d13, fd, P.ix1, P.pns1);
-  rf = polintd_shared(xa1, xa2, xa3, ya1, ya2, ya3, q32, q21, P.r_d13, fd, P.ix2, P.pns2);
+  const int ns = (P.pns0 == P.pns1 && P.pns1 == P.pns2) ? P.pns0 : 0;
+  if (ns == 2) polintd3x3_ns<FD, 2>(P, ya1, ya2, ya3, q32, q21, rb, rc, rf);
+  else if (ns == 3) polintd3x3_ns<FD, 3>(P, ya1, ya2, ya3, q32, q21, rb, rc, rf);
+  else polintd3x3_ns<FD, 0>(P, ya1, ya2, ya3, q32, q21, rb, rc, rf);
 }
 
 // The interval of the VTurb spline table a walk is in, kept in registers: HVAL and
