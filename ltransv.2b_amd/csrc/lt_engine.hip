@@ -114,6 +114,9 @@ struct lt_engine {
   bool rng_gen0_raw = true;        // state 0 is still the given mt array (word 624, not a block start)
   std::map<long long, int> rng_poly_slot;  // jump distance in blocks -> slot of x^(d*S) mod phi in rng_polys
   std::vector<uint32_t> rng_g0;    // x^(S-624) mod phi: the mt array to the start of block 1
+  std::vector<uint32_t> rng_gS, rng_gPm1;            // x^S, x^((P-1)*S)
+  std::vector<std::vector<uint32_t>> rng_pow_PS;     // x^(j*P*S), j = 1, 2, ...
+  bool rng_family_done = false, rng_rebased = false, rng_chain_done = false;
   ltmt::BlockJob* rng_jobs = nullptr;  // pinned, mapped: RNG_JOB_SLOTS launches of up to P jobs
   int rng_job_slot = 0;
   std::vector<long long> rng_ring_blk;  // the stream block each ring slot holds (-1: none)
@@ -232,7 +235,7 @@ int check_particle_elements(lt_engine* e, const int32_t* pe, int numpar, int ele
 
 constexpr int RNG_LOG2_S = 20;
 constexpr size_t RNG_S = (size_t)1 << RNG_LOG2_S;  // MT19937 stream words per block
-constexpr int RNG_JOB_SLOTS = 32, RNG_MAX_POLYS = 64;
+constexpr int RNG_JOB_SLOTS = 32, RNG_MAX_POLYS = 512;  // (a polynomial is 2.5 KB; distances are k*P-1 and k*P, k up to a step's blocks / P + 1)
 
 size_t slab_elem(const lt_engine* e) { return e->cfg.slab_storage == LT_SLAB_F32 ? 4 : 8; }
 
@@ -533,6 +536,7 @@ int rng_configure_kernels(lt_engine* e) {
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipFuncSetAttribute((const void*)ltmt::k_mt_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ltmt::LDS_BYTES * ltmt::GEN_PER_WG)));
     HIPCHK(e, hipFuncSetAttribute((const void*)ltmt::k_mt_jump, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ltmt::LDS_BYTES));
+    HIPCHK(e, hipFuncSetAttribute((const void*)ltmt::k_mt_jump_each, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ltmt::LDS_BYTES));
     e->rng_kernels_configured = true;
   }
   return LT_OK;
@@ -546,12 +550,15 @@ int rng_init_device(lt_engine* e) {
   const ltmt::Poly& phi = mt_phi();
   if (phi.empty()) return fail(e, LT_ERR_DEVICE, "MT19937 characteristic polynomial failed");
   e->rng_g0 = ltmt::jump_polynomial(phi, RNG_S - 624);
-  std::vector<uint32_t> gS = ltmt::jump_polynomial(phi, RNG_S);
+  e->rng_gS = ltmt::jump_polynomial(phi, RNG_S);
+  const std::vector<uint32_t>& gS = e->rng_gS;
   DevBuf d_g0, d_gS;
   TRY(upload(e, d_g0, e->rng_g0.data(), e->rng_g0.size() * 4));
   TRY(upload(e, d_gS, gS.data(), gS.size() * 4));
   if (!e->rng_polys.p) TRY(dev_alloc(e, e->rng_polys, (size_t)RNG_MAX_POLYS * ltmt::GW * 4));
   e->rng_poly_slot.clear();
+  e->rng_family_done = false;
+  e->rng_rebased = false;
   if (!e->rng_states.p) TRY(dev_alloc(e, e->rng_states, (size_t)P * 624 * 4));
   if (!e->rng_jobs) HIPCHK(e, hipHostMalloc((void**)&e->rng_jobs, sizeof(ltmt::BlockJob) * (size_t)RNG_JOB_SLOTS * P, hipHostMallocMapped));
   HIPCHK(e, hipMemcpyAsync(e->rng_states.p, e->mt, 624 * 4, hipMemcpyHostToDevice, e->stream));
@@ -573,16 +580,54 @@ int rng_init_device(lt_engine* e) {
   return LT_OK;
 }
 
-// the slot of the jump polynomial x^(d*S) mod phi (computed on the host at its first use: ~0.1 s)
+// x^(d*S) mod phi on the host.  The distances that occur are j*P - 1 (a state's turn came again after j rounds)
+// and j*P (from its first position): products of x^(P*S), kept by power, with x^((P-1)*S) -- one or two modular
+// multiplications (~8 ms each) instead of the 50 ms of a square-and-multiply from scratch.
+const std::vector<uint32_t>& rng_pow_round(lt_engine* e, long long j) {  // x^(j*P*S), j >= 1
+  if (e->rng_pow_PS.empty()) {
+    e->rng_gPm1 = ltmt::jump_polynomial(mt_phi(), (uint64_t)(e->rng_P - 1) * RNG_S);
+    e->rng_pow_PS.push_back(ltmt::poly_mulmod(mt_phi(), e->rng_gPm1, e->rng_gS));
+  }
+  while ((long long)e->rng_pow_PS.size() < j)
+    e->rng_pow_PS.push_back(ltmt::poly_mulmod(mt_phi(), e->rng_pow_PS.back(), e->rng_pow_PS[0]));
+  return e->rng_pow_PS[(size_t)j - 1];
+}
+std::vector<uint32_t> rng_jump_poly(lt_engine* e, long long d) {
+  const long long P = e->rng_P;
+  if (d >= P - 1 && d <= 64 * P) {
+    if (d % P == 0) return rng_pow_round(e, d / P);
+    if ((d + 1) % P == 0) {
+      const long long j = (d + 1) / P;
+      (void)rng_pow_round(e, 1);
+      return j == 1 ? e->rng_gPm1 : ltmt::poly_mulmod(mt_phi(), rng_pow_round(e, j - 1), e->rng_gPm1);
+    }
+  }
+  return ltmt::jump_polynomial(mt_phi(), (uint64_t)d * RNG_S);
+}
+// the slot of the jump polynomial of d blocks (computed at its first use and kept)
 int rng_poly_for(lt_engine* e, long long d, int* slot) {
   auto it = e->rng_poly_slot.find(d);
   if (it != e->rng_poly_slot.end()) { *slot = it->second; return LT_OK; }
   const int k = (int)e->rng_poly_slot.size();
   if (k >= RNG_MAX_POLYS) return fail(e, LT_ERR_STATE, "MT19937 stream: more than %d distinct jump distances", RNG_MAX_POLYS);
-  const std::vector<uint32_t> g = ltmt::jump_polynomial(mt_phi(), (uint64_t)d * RNG_S);
+  const std::vector<uint32_t> g = rng_jump_poly(e, d);
   HIPCHK(e, hipMemcpy((uint32_t*)e->rng_polys.p + (size_t)k * ltmt::GW, g.data(), (size_t)ltmt::GW * 4, hipMemcpyHostToDevice));
   e->rng_poly_slot[d] = k;
   *slot = k;
+  return LT_OK;
+}
+// A shard's first jump over other shards' words (j*P - 1 blocks, j > 1) says what the later ones will be: the
+// same state comes back after j-1, j or j+1 rounds, or twice that when a window misses it once.  Those are
+// computed with it, so that no step after the first two pays for a polynomial.
+int rng_prefetch_family(lt_engine* e, long long d) {
+  const long long P = e->rng_P;
+  if ((d + 1) % P != 0 || d < 2 * P - 1 || e->rng_family_done) return LT_OK;
+  e->rng_family_done = true;
+  const long long j = (d + 1) / P;
+  for (long long m : {j - 1, j, j + 1, 2 * j - 1, 2 * j, 2 * j + 1, 2 * j + 2}) {
+    int slot;
+    if (m >= 1 && m <= 64) TRY(rng_poly_for(e, m * P - 1, &slot));
+  }
   return LT_OK;
 }
 
@@ -639,6 +684,32 @@ int rng_ensure(lt_engine* e, uint64_t first, uint64_t last, hipStream_t gen_stre
     e->rng_pos[0] = 1;
     e->rng_gen0_raw = false;
   }
+  if (!e->rng_chain_done && todo.front() >= (long long)P) {
+    // a window that does not start where the stream starts: this engine is a shard.  Its states will be asked
+    // after ever longer pauses until each has had its first turn (j*P blocks from where it sits, j growing by
+    // a step's rounds per step): the powers of x^(P*S) are formed now (~0.4 s, once) instead of a few in each
+    // of the first steps.
+    (void)rng_pow_round(e, 48);
+    e->rng_chain_done = true;
+  }
+  if (!e->rng_rebased && todo.front() >= 2 * (long long)P) {
+    // A shard whose window starts far into the stream: the whole pool moves j0 rounds ahead at once (one
+    // polynomial, one launch), so that afterwards every distance is a small j*P or j*P - 1 -- otherwise each
+    // state would make its first jump from its initial position, a longer one every step.
+    bool fresh = true;
+    for (int p = 0; p < P; p++) fresh = fresh && e->rng_pos[(size_t)p] == (p == 0 ? 1 : p);
+    if (fresh) {
+      const long long j0 = todo.front() / P - 1;   // (every state stays behind the first block it owns in the window)
+      int slot;
+      TRY(rng_poly_for(e, j0 * P, &slot));
+      hipLaunchKernelGGL(ltmt::k_mt_jump_each, dim3((unsigned)P), dim3(256), ltmt::LDS_BYTES, e->stream,
+                         (uint32_t*)e->rng_states.p, (const uint32_t*)e->rng_polys.p + (size_t)slot * ltmt::GW);
+      HIPCHK(e, hipGetLastError());
+      HIPCHK(e, hipStreamSynchronize(e->stream));
+      for (int p = 0; p < P; p++) e->rng_pos[(size_t)p] += j0 * P;
+    }
+    e->rng_rebased = true;
+  }
   int launches = 0;
   for (size_t next = 0; next < todo.size();) {
     if (launches == RNG_JOB_SLOTS) {  // every job slot is in flight
@@ -658,7 +729,10 @@ int rng_ensure(lt_engine* e, uint64_t first, uint64_t last, hipStream_t gen_stre
       const long long d = blk - e->rng_pos[(size_t)p];
       if (d < 0) return fail(e, LT_ERR_STATE, "MT19937 stream: block %lld lies behind its generator state", blk);
       int slot = -1;
-      if (d > 0) TRY(rng_poly_for(e, d, &slot));
+      if (d > 0) {
+        TRY(rng_poly_for(e, d, &slot));
+        TRY(rng_prefetch_family(e, d));
+      }
       ltmt::BlockJob& jb = jobs[nj_total++];
       jb.blk = blk; jb.state = p; jb.poly = slot; jb.store = 1; jb.pad_ = 0;
       e->rng_pos[(size_t)p] = blk + 1;
@@ -835,6 +909,9 @@ int lt_create(const lt_config* cfg, lt_engine** out) {
   e->resort_every = (cfg->resort_every == 0) ? 32 : cfg->resort_every;
   const char* envr = getenv("LT_RESORT_EVERY");
   if (envr) e->resort_every = atoi(envr);
+  // (tests: a small pool of generator states makes short runs go round it many times)
+  const char* envp = getenv("LT_RNG_STATES");
+  if (envp && atoi(envp) >= 2 && atoi(envp) <= 1024) e->rng_P = atoi(envp);
   const char* env = getenv("LT_BRUTE_BOUNDS");
   if (env && atoi(env) != 0) { e->use_seg_index = 0; e->use_pip_index = 0; }
   // init_genrand(seed), random_module.f90:108-119 / LTRANS.f90:241

@@ -153,6 +153,35 @@ inline std::vector<uint32_t> jump_polynomial(const Poly& phi, uint64_t e) {
   return g;
 }
 
+// a(x) * b(x) mod phi(x), polynomials as GW uint32 words (bit i = coefficient of x^i, degree < DEG):
+// the jump over m + n words is the product of the jumps over m and over n words
+inline std::vector<uint32_t> poly_mulmod(const Poly& phi, const std::vector<uint32_t>& a, const std::vector<uint32_t>& b) {
+  const int W2 = (2 * DEG + 64) / 64 + 2;
+  Poly bb(W2, 0), r(W2, 0);
+  for (int i = 0; i < GW; i++) bb[i >> 1] |= (uint64_t)b[i] << (32 * (i & 1));
+  const int bw = (DEG + 63) / 64;
+  for (int i = 0; i < DEG; i++) {
+    if (!((a[i >> 5] >> (i & 31)) & 1u)) continue;
+    const int ws = i >> 6, bs = i & 63;
+    for (int w = 0; w < bw; w++) {
+      r[w + ws] ^= bb[w] << bs;
+      if (bs) r[w + ws + 1] ^= bb[w] >> (64 - bs);
+    }
+  }
+  for (int i = 2 * DEG - 1; i >= DEG; i--) {  // mod phi
+    if (!pbit(r, i)) continue;
+    const int sh = i - DEG, ws = sh >> 6, bs = sh & 63;
+    for (size_t w = 0; w < phi.size() && w + ws < r.size(); w++) {
+      r[w + ws] ^= phi[w] << bs;
+      if (bs && w + ws + 1 < r.size()) r[w + ws + 1] ^= phi[w] >> (64 - bs);
+    }
+  }
+  std::vector<uint32_t> g(GW, 0);
+  for (int i = 0; i < DEG; i++)
+    if (pbit(r, i)) g[i >> 5] |= 1u << (i & 31);
+  return g;
+}
+
 // host reference of the jump: out = g(F) h  (linear windows, h[0] oldest)
 inline void host_jump(const uint32_t* h, const uint32_t* g, uint32_t* out) {
   std::vector<uint32_t> E(DEG + N);
@@ -306,6 +335,17 @@ __global__ __launch_bounds__(256) void k_mt_jump(uint32_t* __restrict__ states, 
   __syncthreads();
   jump_in_lds(lds, g, tid, true);
   for (int i = tid; i < N; i += blockDim.x) states[(size_t)dst * N + i] = lds[i];
+}
+
+// states[b] = g(F) states[b] for every state b = blockIdx.x (a shard moves its whole pool to its part of the stream)
+__global__ __launch_bounds__(256) void k_mt_jump_each(uint32_t* __restrict__ states, const uint32_t* __restrict__ g) {
+  extern __shared__ uint32_t lds[];
+  const int tid = threadIdx.x;
+  uint32_t* st = states + (size_t)blockIdx.x * N;
+  for (int i = tid; i < N; i += blockDim.x) lds[i] = st[i];
+  __syncthreads();
+  jump_in_lds(lds, g, tid, true);
+  for (int i = tid; i < N; i += blockDim.x) st[i] = lds[i];
 }
 
 constexpr size_t LDS_BYTES = (size_t)GEN_LDS_WORDS * 4;  // per generator state

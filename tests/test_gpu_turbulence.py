@@ -92,17 +92,22 @@ def test_turbulence_sharded_windows(oracle, resort_every):
         e.close()
 
 
-@pytest.mark.parametrize("static", [True, False])
-def test_windows_jump_over_the_other_shards_words(oracle, static):
+@pytest.mark.parametrize("static,states,world", [(True, 8, 3), (False, 8, 3), (True, 0, 3), (False, 5, 3), (True, 2, 5)])
+def test_windows_jump_over_the_other_shards_words(oracle, static, states, world, monkeypatch):
     """three shards with windows (static: lt_set_rng_window_static once; else lt_set_rng_window before every
     step): each shard's generator states jump over the other shards' part of the serial stream (a step of 60k
     particles is 7 blocks of 2^20 words) instead of generating it; the particles are those of the unsharded
     run -- which walks the stream block by block -- bit for bit, and the cursor every shard hands back is the
-    same stream position"""
+    same stream position.  LT_RNG_STATES: a pool of 8 (5) generator states instead of 256, so that the 43 blocks
+    of the run go round it five (eight) times: the unsharded run jumps P-1 blocks after every block, a shard's
+    states j*P-1 blocks (j = 1, 2) from their last block and j*P from their first position; five shards on a
+    pool of 2: the last shard's first window lies two rounds into the stream and its whole pool moves there first."""
     from ltrans_amd import sharding
     from ltrans_amd.driver import LtransRun
+    if states:
+        monkeypatch.setenv("LT_RNG_STATES", str(states))
     case = cases.build_case("tiny_turb", numpar=60000)
-    N, steps, world = case["cfg"].numpar, 6, 3
+    N, steps = case["cfg"].numpar, 6
     full = _run(case, {}, 1, steps)
     engines, runs = [], []
     sizes = [sharding.shard_range(N, world, r) for r in range(world)]
@@ -131,6 +136,12 @@ def test_windows_jump_over_the_other_shards_words(oracle, static):
     for e in engines:
         assert _next_draws(oracle, *e.get_rng()) == want
         e.close()
+    if states:
+        # and the same run with the 256 states of the product, none of which jumps within 43 blocks
+        monkeypatch.delenv("LT_RNG_STATES")
+        plain = _run(case, {}, 1, steps)
+        assert np.array_equal(plain["par"], full["par"])
+        assert _next_draws(oracle, *plain["rng"]) == want
 
 
 @pytest.mark.parametrize("name", ["tiny_turb", "tiny_adv"])

@@ -35,7 +35,3 @@ nwaves = (n + 63) // 64
 for i in range(6):
     print(f"{names[i]:32s} {v[i]/K/nwaves:10.0f} cyc/wave/step  {100.0*v[i]/tot:5.1f} %")
 print("total cyc/wave/step", tot / K / nwaves, " queued eval intervals/particle-step", v[6] / K / n, " regime>=3 lanes per particle-step (of 12)", (v[7] & 0xffffffff) / K / n, " var setups (of 12 per wave-step) with such a lane", (v[7] >> 32) / K / nwaves)
-
-r = v[8] / K / nwaves
-print("pass B rounds per wave-step %.2f; wave-level Newton trip count per round %.2f; mean iterations of an iterating lane %.2f; per round: tasks %.1f newton %.1f secant %.2f  eval sigma<=.5 %.1f  sigma>.5 %.1f" % (
-    r, v[9] / max(v[8], 1), v[10] / max(v[11], 1), v[15] / max(v[8], 1), v[11] / max(v[8], 1), v[12] / max(v[8], 1), v[13] / max(v[8], 1), v[14] / max(v[8], 1)))
