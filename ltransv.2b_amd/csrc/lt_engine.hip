@@ -1816,6 +1816,15 @@ int lt_test_mt_stream(const int32_t* mt624, int32_t mti, uint64_t offset, int32_
   return LT_OK;
 }
 
+/* test aid (host only): 1 when x^a * x^b mod phi (poly_mulmod, how the engine forms the jump polynomials of a shard)
+ * equals x^(a+b) mod phi formed from scratch, else 0. */
+int lt_test_mt_mulmod(uint64_t a, uint64_t b) {
+  const ltmt::Poly& phi = mt_phi();
+  if (phi.empty()) return LT_ERR_DEVICE;
+  const std::vector<uint32_t> ga = ltmt::jump_polynomial(phi, a), gb = ltmt::jump_polynomial(phi, b);
+  return ltmt::poly_mulmod(phi, ga, gb) == ltmt::jump_polynomial(phi, a + b) ? 1 : 0;
+}
+
 /* test aid (device): q_fast[i] = div_prep(a[i], prep_div(b[i])), q_ref[i] = a[i] / b[i]
  * (host pointers), to check that the prepared-divisor division of lt_math.h is
  * bit-identical to the compiler's division on the operand ranges it is used for. */

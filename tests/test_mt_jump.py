@@ -38,3 +38,13 @@ def test_host_jump_matches_sequential(oracle, seed, burn, offset):
                                C.c_int32(out.size), out.ctypes.data_as(C.c_void_p))
     assert rc == 0
     assert np.array_equal(out, _oracle_words(oracle, st, offset, out.size))
+
+
+@pytest.mark.parametrize("a,b", [(1, 1), (624, 19937), ((1 << 20) * 255, 1 << 20), ((1 << 20) * 1279, (1 << 20) * 256),
+                                 (123456789, 987654321)])
+def test_product_of_jumps_is_the_jump_over_the_sum(a, b):
+    """poly_mulmod: the engine forms the jump polynomials of a shard (j*P and j*P-1 blocks) as products of kept
+    powers of x^(P*S) with x^((P-1)*S)"""
+    lib = hip_test_lib.load()
+    lib.lt_test_mt_mulmod.restype = C.c_int
+    assert lib.lt_test_mt_mulmod(C.c_uint64(a), C.c_uint64(b)) == 1
