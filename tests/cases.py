@@ -27,6 +27,10 @@ CASES = {
                        cfg=dict(Behavior=0, HTurbOn=1, VTurbOn=0, ConstantHTurb=20.0)),
     "tiny_vturb": dict(grid=(24, 16, 8), islands=[(10, 12, 6, 8)], numpar=512, near_land=0.3,
                        cfg=dict(Behavior=6, sink=-0.001, HTurbOn=0, VTurbOn=1)),
+    "tiny_turb_vt2": dict(grid=(24, 16, 8), islands=[(10, 12, 6, 8)], numpar=512, near_land=0.3,
+                          cfg=dict(Behavior=0, HTurbOn=1, VTurbOn=1, ConstantHTurb=1.0, Vtransform=2, hc=5.0)),
+    "tiny_turb_vt3": dict(grid=(24, 16, 8), islands=[(10, 12, 6, 8)], numpar=512, near_land=0.3,
+                          cfg=dict(Behavior=0, HTurbOn=1, VTurbOn=1, ConstantHTurb=1.0, Vtransform=3)),
     "small_turb": dict(grid=(100, 100, 20), islands=[(40, 44, 50, 53), (70, 71, 20, 30)],
                        numpar=608, near_land=0.2, cfg=dict(Behavior=0, HTurbOn=1, VTurbOn=1)),
     # biological behaviours 1-5 and 7 (behavior_module.f90:181-551): genrand_real1 draws in

@@ -33,7 +33,7 @@ def _next_draws(oracle, mt, mti, n=8):
     return [oracle.lto_genrand_int32(C.byref(st)) for _ in range(n)]
 
 
-@pytest.mark.parametrize("name", ["tiny_hturb", "tiny_vturb", "tiny_turb", "small_turb"])
+@pytest.mark.parametrize("name", ["tiny_hturb", "tiny_vturb", "tiny_turb", "small_turb", "tiny_turb_vt2", "tiny_turb_vt3"])
 def test_parity_turbulence(oracle, name):
     case = cases.build_case(name)
     hip = _run(case, {}, 2, 6)
