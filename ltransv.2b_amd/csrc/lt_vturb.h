@@ -371,8 +371,16 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
   // One knot.  MID = a knot in 4 .. p2-5 (all but seven of them): none of the end cases -- pinned end points,
   // YP(1) / YP(N), the last interval, the pads of the window -- applies, and the compiler drops their tests,
   // selects and the second screening from the loop that runs 120 times.
+#ifdef LT_RK_TIMING
+  // development aid (tools/dev/vt_sections.py): wave cycles per section of a knot, summed into g_tim[8..13]
+  unsigned long long vt_acc[6] = {0, 0, 0, 0, 0, 0}, vt_prev = __builtin_readcyclecounter();
+#define VTICK(sec) do { const unsigned long long t_ = __builtin_readcyclecounter(); vt_acc[sec] += t_ - vt_prev; vt_prev = __builtin_readcyclecounter(); } while (0)
+#else
+#define VTICK(sec) do { } while (0)
+#endif
   auto knot = [&](const int k, auto mid_tag) {
     constexpr bool MID = decltype(mid_tag)::value;
+    VTICK(5);
     double xk = 0.0, yk = 0.0;
     if (act) {
       double mx[3], my[3];
@@ -388,6 +396,7 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
         mx[s] = MID ? xm : (k == 1) ? wz1[s] : (k == p2) ? wzN[s] : xm;
         my[s] = MID ? av : (k == 1) ? kh1[s] : (k == p2) ? khN[s] : av;
       }
+      VTICK(0);
       // :220-275 interpolation to the internal times, clamp, Simpson in time
       // (selects on values, not on array elements: those would turn into stack indexing)
       const double mx0 = mx[0], mx1 = mx[1], mx2 = mx[2], my0 = my[0], my1 = my[1], my2 = my[2];
@@ -402,6 +411,7 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
       yk = div_by(fyb + 4.0 * fyc + fyf, 6.0, P.r_6, FD);
       xk = div_by(fxb + 4.0 * fxc + fxf, 6.0, P.r_6, FD);
     }
+    VTICK(1);
     // TSPSI(p2) as a stream: YPC1 (tension_module.f90:852-977), SIGS (:314-781).  YPC1 stops at the
     // first non-increasing abscissa (IER = -4 of TSPSI, SIGS never runs): the derivatives found so
     // far stay, the others and every tension factor are 0 (the walk ignores the stored tensions then).
@@ -422,11 +432,13 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
       }
     }
     const bool ok = live && !fail_now;
+    VTICK(2);
     // interval (k-2, k-1): chord slope S_{k-2} (still in Sp), derivatives YP(k-2), YP(k-1)
     const double sgA = SIGMA(ok && (MID || k >= 3), Sp, YPp, YPc, k - 3);
     // (the last interval (N-1, N) with YP(N-1), YP(N))
     double sgB = 0.0;
     if (!MID) sgB = SIGMA(ok && k == p2, S, YPc, YPn, p2 - 2);
+    VTICK(3);
     if (act) {
       if (ok) {
         if (MID || k >= 3) tab[(size_t)(k - 3) * VT_TS] = make_double4(xm2, ym2, YPp, sgA);           // knot k-2, interval (k-2, k-1)
@@ -448,6 +460,7 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
       }
       xm2 = xm1; ym2 = ym1;
       xm1 = xk; ym1 = yk;
+      VTICK(4);
       // slide the 8-point window: drop newy(k), append newy(k+8)
       if (MID || k + 8 <= p2 + 7) {
 #pragma unroll
@@ -465,6 +478,10 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
   for (int k = 4; k <= p2 - 5; k++) knot(k, std::true_type{});
 #pragma unroll 1
   for (int k = p2 - 4; k <= p2; k++) knot(k, std::false_type{});
+#ifdef LT_RK_TIMING
+  if (lane == 0)
+    for (int q = 0; q < 6; q++) atomicAdd(&g_tim[8 + q], vt_acc[q]);
+#endif
   if (lane == 0) {
     Q.count[wave] = (ntask < Q.cap) ? ntask : Q.cap;
     if (ntask) atomicAdd(&P.counters[CNT_VT_QUEUED], (unsigned long long)ntask);
