@@ -44,6 +44,7 @@ sys.path.insert(0, ROOT)
 A_ADV_F32 = 96 + 256 + 48 + 576          # = 976 B
 A_ADV_F64 = 96 + 256 + 96 + 1152         # = 1600 B
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PROFILE_ADV, PROFILE_TURB = "r03_adv", "r03_turb"   # profiles/<tag>/pmc.json of the default workloads
 
 WORKLOADS = {
     # name: (grid, total particles, turbulence, reflect/behaviour-6/settlement)
@@ -79,6 +80,8 @@ def parse(argv=None):
                          "of the random stream; no all-gather): what one GPU of the N-rank job computes per step")
     ap.add_argument("--no-single-ref", action="store_true",
                     help="N > 1, strong scaling: skip rank 0's run of the WHOLE workload on one GPU afterwards")
+    ap.add_argument("--single-ref-budget", type=float, default=150.0,
+                    help="seconds after which rank 0's single-GPU reference run is skipped (keeps --gpus 8 within minutes)")
     ap.add_argument("--cpu-sample", type=int, default=40000, help="particles of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-steps", type=int, default=30)
     ap.add_argument("--selftest-launch", choices=["ok", "fail"], default=None,
@@ -211,6 +214,29 @@ def algorithmic_bytes(slab, turb, ws):
         # of 4 B written once and read once)
         A += (48 if slab == "f32" else 96) * ws + 124 * 4 * 2
     return A
+
+
+VT_KERNELS = ["k_vt_table", "k_vt_sigs", "k_vt_walk_fast", "k_vt_walk"]
+
+
+def roofline_block(slab, turb, ws, n, k_avg_s, step_s, traffic, traffic_src, valu):
+    """Bytes and time of one figure cover the SAME kernels.  RK4 only: the timed kernel is k_rk, which touches all of
+    A_adv.  With turbulence the timed kernels are the VTurb group, whose algorithmic bytes are A_turb - A_adv (the Kh
+    columns and the materialised stream); the whole step -- every kernel, launch gaps included -- is A_turb over the
+    wall time of a step (`whole_step`)."""
+    A_all = algorithmic_bytes(slab, turb, ws)
+    A_k = A_all - algorithmic_bytes(slab, False, ws) if turb else A_all
+    kernels = VT_KERNELS if turb else ["k_rk"]
+    ach = (A_k * n / k_avg_s) / 1e9 if k_avg_s > 0 else 0.0
+    ach_step = (A_all * n / step_s) / 1e9 if step_s > 0 else 0.0
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "traffic_over_algorithmic": (traffic / (A_k * n)) if traffic else None,
+            "kernel": "+".join(kernels), "kernel_ms_avg": k_avg_s * 1e3,
+            "algorithmic_bytes_per_launch": A_k * n, "algorithmic_bytes_per_particle_step": A_k,
+            "valu_pmc": valu, "valu_issue": valu_issue(valu, kernels, n, k_avg_s),
+            "whole_step": {"algorithmic_bytes_per_particle_step": A_all, "ms": step_s * 1e3, "achieved": ach_step,
+                           "frac": ach_step / HBM_PEAK_GBS}}
 
 
 ISLANDS_B = [(200, 215, 100, 140), (600, 640, 300, 310), (820, 830, 80, 90), (400, 402, 400, 460)]
@@ -403,7 +429,7 @@ def resolve_workload(args, world):
                 settle=settle, total=total, weak=weak)
 
 
-def workload_text(spec, world, n_local):
+def workload_text(spec, world, n_local, backend="nccl"):
     s = (f"{spec['total']} particles in total" if not spec["weak"] else f"{n_local} particles per GPU")
     s += f", synthetic {spec['grid']} ROMS grid, "
     s += ("RK4 + HTurb + VTurb (MT19937 stream on device), idt=120 s" if spec["turb"]
@@ -412,12 +438,14 @@ def workload_text(spec, world, n_local):
     s += (", islands + drift into the coast (reflection), settlement + mortality" if spec["reflect"]
           else (", settlement + mortality" if spec["settle"] else ""))
     if world > 1:
-        s += f", sharded over {world} GPUs by contiguous index block, RCCL all-gather of (x,y,z) per step"
+        coll = "RCCL" if backend == "nccl" else f"{backend} (host memory: a rehearsal, not RCCL)"
+        s += f", sharded over {world} GPUs by contiguous index block, {coll} all-gather of (x,y,z) per step"
     return s
 
 
 # ----------------------------------------------------------------------------- main
 def main():
+    t_start = time.perf_counter()
     args = parse()
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
@@ -471,11 +499,12 @@ def main():
     # blocks of the global particle list that rank 0 re-assembles for the single-GPU reference
     parts = make_parts(g, geo, bounds, n, 12345 + em_rank, spec["reflect"])
     rec_cache = {}
+    needs_st = spec["behavior"] not in (0, 6)     # salinity / temperature only for the behaviours that read them
 
     def records(r, with_kh=None):
         k = (r, bool(spec["turb"] if with_kh is None else with_kh))
         if k not in rec_cache:
-            rec_cache[k] = rs.make_record(g, geo, r, with_kh=k[1], drift=drift)
+            rec_cache[k] = rs.make_record(g, geo, r, with_kh=k[1], drift=drift, with_st=needs_st)
         return rec_cache[k]
 
     def config_for(numpar, turb):
@@ -508,9 +537,17 @@ def main():
     # A shard's window of the single serial random stream is static while no particle can stop drawing:
     # nothing is unreleased (DOB <= 0), settles, dies or leaves through an open boundary.  Otherwise the
     # ranks exchange their counts before every step (one all-gather of one int64 each, one host read).
+    # The choice is the JOB's, not the rank's (a rank that exchanged counts while another did not would wait for
+    # ever): the minimum over the ranks of the local predicate.  The engine checks it on the device in every step
+    # (lt_set_rng_window_static: a step whose draw total differs makes e.counters() fail below).
     static_window = (draws and not (1 <= spec["behavior"] <= 5) and not spec["settle"]
                      and float(parts["par"][:, 10].max()) <= 0.0)
-    if em_world > 1 and static_window:
+    if world > 1:
+        sw = torch.tensor([1 if static_window else 0], dtype=torch.int64, device=coll_dev)
+        dist.all_reduce(sw, op=dist.ReduceOp.MIN)
+        static_window = bool(int(sw.item()))
+    if static_window:
+        # (one engine alone: its window is the whole stream -- set once, no step waits for the device)
         sizes = sharding.shard_sizes(spec["total"], em_world)
         e.set_rng_window(int(sum(sizes[:em_rank])), int(sum(sizes)), persistent=True)
     elif em_world > world and draws:
@@ -554,15 +591,20 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    setup_s = time.perf_counter() - t_start
     for _ in range(args.warmup):
         if st.needs_rotation():
             st.rotate()
         one_step()
     fence()
+    resorts0 = e.counters()["resorts"]
     e.profile_begin(args.steps)
     wall, upload_s = timed_steps(st, args.steps, one_step, fence)
     k_ms, k_n = e.profile_end()
-    stats = e.counters()
+    stats = e.counters()      # (fails if a static stream window did not hold)
+    if static_window and stats["active"] != n:
+        sys.stderr.write(f"bench.py: static stream window, but {stats['active']} of {n} particles were tracked\n")
+        return 3
 
     wall_t = torch.tensor([wall], dtype=torch.float64, device=coll_dev)
     if world > 1:
@@ -572,14 +614,12 @@ def main():
     # (an emulated rank reports its own shard's particle-steps: one GPU's share of the job)
     total_particle_steps = float(n if args.emulate_rank else spec["total"]) * args.steps
     value = total_particle_steps / wall
-    A = algorithmic_bytes(args.slab, spec["turb"], us + 1)
     k_avg_s = (k_ms / max(k_n, 1)) * 1e-3
-    achieved = (A * n / k_avg_s) / 1e9 if k_avg_s > 0 else 0.0
-    kernels = ["k_vt_table", "k_vt_sigs", "k_vt_walk_fast", "k_vt_walk"] if spec["turb"] else ["k_rk"]
+    kernels = VT_KERNELS if spec["turb"] else ["k_rk"]
     default_shape = (n == 1_000_000 and spec["grid"] == "512x256x30" and args.slab == "f32" and not spec["reflect"])
     traffic = traffic_src = valu = None
     if default_shape:
-        traffic, traffic_src, valu = pmc_traffic("r02_turb" if spec["turb"] else "r02_adv", kernels, lib_hash)
+        traffic, traffic_src, valu = pmc_traffic(PROFILE_TURB if spec["turb"] else PROFILE_ADV, kernels, lib_hash)
 
     out = {
         "metric": "particle-steps/s", "value": value, "unit": "particle-steps/s",
@@ -587,26 +627,34 @@ def main():
         "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak" if (spec["weak"] or world == 1) else "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": workload_text(spec, world, n) + (f"; THIS LINE: rank {em_rank} of {em_world} emulated by one "
+        "config": {"workload": workload_text(spec, world, n, backend) + (f"; THIS LINE: rank {em_rank} of {em_world} emulated by one "
                    "process (its shard, its window of the random stream, no all-gather)" if args.emulate_rank else ""),
                    "baseline_config": spec["name"],
                    "particles_total": spec["total"], "particles_this_rank": n, "grid": spec["grid"],
                    "slab_storage": args.slab, "kernel_source_hash": lib_hash,
                    "active_last_step": stats["active"], "errors_last_step": stats["errors"],
                    "sigerr_last_step": stats["sigerr"], "slab_rotation_s_excluded": upload_s,
-                   "rng_window": ("static" if static_window else "exchanged per step") if (em_world > 1 and draws) else None},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "+".join(kernels), "kernel_ms_avg": k_avg_s * 1e3,
-                     "valu_pmc": valu, "valu_issue": valu_issue(valu, kernels, n, k_avg_s),
-                     "algorithmic_bytes_per_launch": A * n, "algorithmic_bytes_per_particle_step": A},
+                   # the device-side re-sort of the particle order (every `resort_every` = 32 steps inside lt_step):
+                   # how many fell into the timed region -- they are part of `value` -- and what one costs
+                   "resorts_in_timed_region": stats["resorts"] - resorts0, "resort_every_steps": 32,
+                   "resort_ms_each": stats["last_resort_ms"] if stats["resorts"] else None,
+                   "rng_window": (("static (validated on the device every step)" if static_window
+                                   else "exchanged per step") if draws else None),
+                   "collective_backend": (backend if world > 1 else None), "device_index": dev_index,
+                   "setup_s": setup_s},
+        "roofline": roofline_block(args.slab, spec["turb"], us + 1, n, k_avg_s, wall / args.steps, traffic, traffic_src,
+                                   valu),
     }
 
     if world == 1 and spec["name"] == "config2" and not args.no_turbulence_line:
         # BASELINE configs[2] in the same line: the same particles with HTurb + VTurb, same number of steps
         cfg_t = config_for(n, True)
+        t_create = time.perf_counter()
         e_t, run_t = make_engine(ltrans_amd, cfg_t, g, geo, bounds, parts, lambda r: records(r, True))
         st_t = Stepper(e_t, run_t, cfg_t)
+        static_t = float(parts["par"][:, 10].max()) <= 0.0 and not spec["settle"]
+        if static_t:
+            e_t.set_rng_window(0, n, persistent=True)
 
         def step_t():
             e_t.update_particles(st_t.ex, st_t.next_times(), st_t.p, st_t.it)
@@ -615,28 +663,29 @@ def main():
             e_t.sync()
             torch.cuda.synchronize()
 
-        for _ in range(args.warmup):
+        step_t()                  # the first step carries the start-up of the random stream (generator states, ring)
+        fence_t()
+        first_step_s = time.perf_counter() - t_create
+        for _ in range(max(args.warmup - 1, 0)):
             if st_t.needs_rotation():
                 st_t.rotate()
             step_t()
         fence_t()
+        rs0 = e_t.counters()["resorts"]
         e_t.profile_begin(args.steps)
         wall_tb, _ = timed_steps(st_t, args.steps, step_t, fence_t)
         kt_ms, kt_n = e_t.profile_end()
-        A_t = algorithmic_bytes(args.slab, True, us + 1)
         kt_avg = (kt_ms / max(kt_n, 1)) * 1e-3
-        kern_t = ["k_vt_table", "k_vt_sigs", "k_vt_walk_fast", "k_vt_walk"]
-        tr_t, src_t, valu_t = pmc_traffic("r02_turb", kern_t, lib_hash) if default_shape else (None, None, None)
+        tr_t, src_t, valu_t = pmc_traffic(PROFILE_TURB, VT_KERNELS, lib_hash) if default_shape else (None, None, None)
+        cnt_t = e_t.counters()
         out["config"]["turbulence"] = {
             "workload": "BASELINE configs[2]: the same + HTurb + VTurb (MT19937 stream on device)",
             "value": n * args.steps / wall_tb, "unit": "particle-steps/s", "ms_per_step": wall_tb / args.steps * 1e3,
-            "steps": args.steps, "sigerr_last_step": e_t.counters()["sigerr"],
-            "roofline": {"bound": "hbm", "achieved": (A_t * n / kt_avg) / 1e9 if kt_avg > 0 else 0.0,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ((A_t * n / kt_avg) / 1e9 / HBM_PEAK_GBS) if kt_avg > 0 else 0.0,
-                         "traffic": tr_t, "traffic_source": src_t, "kernel": "+".join(kern_t),
-                         "kernel_ms_avg": kt_avg * 1e3, "valu_issue": valu_issue(valu_t, kern_t, n, kt_avg),
-                         "algorithmic_bytes_per_particle_step": A_t}}
+            "steps": args.steps, "sigerr_last_step": cnt_t["sigerr"],
+            "rng_window": "static (validated on the device every step)" if static_t else "the engine's own draws, read back per step",
+            "resorts_in_timed_region": cnt_t["resorts"] - rs0,
+            "create_to_first_step_s": first_step_s,
+            "roofline": roofline_block(args.slab, True, us + 1, n, kt_avg, wall_tb / args.steps, tr_t, src_t, valu_t)}
         e_t.close()
 
     if world == 1 and not args.no_hydro_timing:
@@ -665,12 +714,27 @@ def main():
 
     if world > 1 and not spec["weak"] and not args.no_single_ref:
         # strong scaling needs its one-GPU point on the SAME workload: rank 0 alone runs all the
-        # particles (the concatenation of the ranks' shards) for a few steps; reported raw, beside `value`
+        # particles (the concatenation of the ranks' shards) for a few steps; reported raw, beside `value`.
+        # It costs rank 0 the generation of every shard's particles and a whole-workload engine: skipped (and
+        # said so) when the run has already used more than --single-ref-budget seconds; --no-single-ref skips it.
+        # (the other ranks hand their shards over through files in the node's temporary directory: generating
+        # them again on rank 0 took longer than everything else together)
+        import tempfile
+        shard_dir = os.path.join(tempfile.gettempdir(), "ltbench_%s" % os.environ.get("MASTER_PORT", "0"))
+        if rank > 0:
+            os.makedirs(shard_dir, exist_ok=True)
+            np.savez(os.path.join(shard_dir, f"rank{rank}.npz"), **parts)
         torch.cuda.synchronize()
         dist.barrier()
-        if rank == 0:
-            sizes = sharding.shard_sizes(spec["total"], world)
-            shards = [parts] + [make_parts(g, geo, bounds, sizes[r], 12345 + r, spec["reflect"]) for r in range(1, world)]
+        elapsed = time.perf_counter() - t_start
+        if rank == 0 and elapsed > args.single_ref_budget:
+            out["config"]["single_gpu_same_workload"] = {"skipped": f"{elapsed:.0f} s used, budget {args.single_ref_budget} s"}
+        elif rank == 0:
+            t_ref = time.perf_counter()
+            shards = [parts]
+            for r in range(1, world):
+                with np.load(os.path.join(shard_dir, f"rank{r}.npz")) as z:
+                    shards.append({k: z[k] for k in parts})
             allp = {k: np.concatenate([s[k] for s in shards]) if shards[0][k].ndim == 1
                     else np.asfortranarray(np.vstack([s[k] for s in shards])) for k in parts}
             del shards
@@ -689,9 +753,16 @@ def main():
             w1, _ = timed_steps(st1, k1, step1, fence1)
             out["config"]["single_gpu_same_workload"] = {
                 "value": spec["total"] * k1 / w1, "unit": "particle-steps/s", "ms_per_step": w1 / k1 * 1e3, "steps": k1,
-                "note": "all the particles on rank 0's GPU alone, no all-gather"}
+                "note": "all the particles on rank 0's GPU alone, no all-gather",
+                "wall_s_incl_setup": time.perf_counter() - t_ref}
             e1.close()
         dist.barrier()
+        if rank > 0:
+            try:
+                os.remove(os.path.join(shard_dir, f"rank{rank}.npz"))
+                os.rmdir(shard_dir)
+            except OSError:
+                pass
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ltrans_amd, args, spec, g, geo, bounds, records)
@@ -701,6 +772,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        out["config"]["total_s"] = time.perf_counter() - t_start
         print(json.dumps(out))
     return 0
 

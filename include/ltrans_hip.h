@@ -316,7 +316,11 @@ int lt_count_active(lt_engine *e, const double *ix3, int64_t *n_active);
 int lt_set_rng_window(lt_engine *e, int64_t active_before, int64_t active_total);
 /* The same window for every following step, until a window is set again: for runs in which no
  * particle can stop drawing (nothing unreleased, no settlement, mortality or open boundary), where
- * the shards' counts never change and need not be exchanged before each step. */
+ * the shards' counts never change and need not be exchanged before each step.  The shard's draws are
+ * read back in the first step after this call only; the following lt_step calls enqueue the step
+ * without waiting for the device, and the device compares every step's draw total with that figure:
+ * if a particle did stop (or start) drawing, lt_get_stats / lt_get_counters / lt_get_particles return
+ * LT_ERR_STATE. */
 int lt_set_rng_window_static(lt_engine *e, int64_t active_before, int64_t active_total);
 /* Behaviours 1-5 draw a data-dependent number of deviates per particle
  * (genrand_real1, behavior_module.f90:256-452), so a shard's place in the stream is a
@@ -356,15 +360,21 @@ void *lt_stream(lt_engine *e);
  *   lt_comm_unique_id   (rank 0) 128 opaque bytes that every rank must pass to lt_comm_init; how they
  *                       travel is the host's business (a file, MPI_Bcast, ...)
  *   lt_comm_init_file   the same through a file: rank 0 creates `path` (atomically), the others wait
- *                       for it up to timeout_s seconds
+ *                       for it up to timeout_s seconds; rank 0 removes the file once the communicator
+ *                       exists, and a file older than (process start - timeout_s) -- left by a crashed
+ *                       run -- is ignored.  Use a path that is unique per run.
  *   lt_allgather_positions  counts(nranks) = numpar of every rank; result xyz(sum(counts),3), column-major,
  *                       shards in rank order, each in the reference's particle order, into host memory
- *                       (xyz_host, synchronous) and / or device memory (xyz_device, asynchronous on the
- *                       engine's stream); either may be NULL. */
+ *                       (xyz_host: the call returns when the array is complete) and / or device memory
+ *                       (xyz_device: asynchronous); either may be NULL.  The collective runs on a stream
+ *                       of its own behind the packing of the shard: an lt_step enqueued after the call
+ *                       runs beside the transfer.
+ *   lt_allgather_wait   returns when the last lt_allgather_positions has delivered (xyz_device complete). */
 int lt_comm_unique_id(void *id128);
 int lt_comm_init(lt_engine *e, const void *id128, int32_t nranks, int32_t rank);
 int lt_comm_init_file(lt_engine *e, const char *path, int32_t nranks, int32_t rank, int32_t timeout_s);
 int lt_allgather_positions(lt_engine *e, const int32_t *counts, double *xyz_host, void *xyz_device);
+int lt_allgather_wait(lt_engine *e);
 int lt_comm_destroy(lt_engine *e);
 
 /* init-time geometry on the device ------------------------ */
@@ -426,7 +436,9 @@ int lt_get_phase_times(lt_engine *e, double *ms4, int32_t reset);
 int lt_profile_begin(lt_engine *e, int32_t max_steps);
 int lt_profile_end(lt_engine *e, double *total_ms, int32_t *launches);
 /* diagnostics of the last step: [0] active [1] errors [2] SigErr fallbacks
- * [3] brute-force boundary scans [4] full point-in-polygon evaluations */
+ * [3] brute-force boundary scans [4] full point-in-polygon evaluations [5] VTurb spline intervals
+ * iterated [6] rounds of that iteration; [7] (not per step) device-side re-sorts of the particle
+ * order so far << 32 | GPU microseconds of the last one */
 int lt_get_counters(lt_engine *e, uint64_t *out8);
 
 #ifdef __cplusplus

@@ -59,9 +59,13 @@ def read_result(path):
                   "dead", "oob", "settle"):
             out[k] = np.frombuffer(fh.read(4 * n), dtype=np.int32)
         rest = fh.read()
-        if len(rest) == 8 * 5 * n:      # the print-step columns of lt_get_output
-            cols = np.frombuffer(rest, dtype=np.float64).reshape(5, n)
+        if len(rest) >= 8 * 5 * n:      # the print-step columns of lt_get_output
+            cols = np.frombuffer(rest[:8 * 5 * n], dtype=np.float64).reshape(5, n)
             out.update(lon=cols[0], lat=cols[1], z=cols[2], age=cols[3], status=cols[4])
+            rest = rest[8 * 5 * n:]
+        if len(rest) >= 4:              # a sharded run: the gathered xyz(N,3) of all ranks
+            ng = int(np.frombuffer(rest[:4], dtype=np.int32)[0])
+            out["xyz_all"] = np.frombuffer(rest[4:4 + 8 * 3 * ng], dtype=np.float64).reshape(ng, 3, order="F")
     return out
 
 

@@ -28,7 +28,11 @@ enum Counter : int {
   CNT_PIP_SLOW = 4,   // point-in-polygon queries that used the full algorithm
   CNT_VT_QUEUED = 5,  // VTurb spline intervals whose tension factor needed the batched SIGS iteration
   CNT_VT_ROUNDS = 6,  // rounds (of up to 64 intervals) of that iteration, summed over the waves
-  CNT_COUNT = 8
+  CNT_COUNT = 8,
+  // (not a per-step counter -- k_pre does not clear it: steps whose draw total differed from the one the host
+  // assumed under a static stream window, lt_set_rng_window_static)
+  CNT_STATIC_MISS = 8,
+  CNT_ALLOC = 9
 };
 
 // uniform-grid index over boundary segments: cell (cx,cy) lists, ascending and
@@ -144,6 +148,7 @@ struct StepParams {
   const int* rank;                // [numpar] offset of the particle's first draw behind rng_base: exclusive
                                   // sum, in reference order, of the draws of the tracked particles
   const int* orig;                // [numpar] reference index of internal slot i
+  long long expect_own;           // >= 0: the shard's draw total the host assumed (static window); k_post checks rank[numpar]
   double4* vt_tab;  // VTurb spline table [wave][4*ws][lane] of {x, y, yp, sigma}
   VtQueue vt_q;     // per-wave task lists of the SIGS iterations (lt_vturb.h)
   // the walks that met an interval with a tension factor and are finished by k_vt_walk (lt_vturb.h):

@@ -8,6 +8,8 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types only: the library is opened at lt_comm_init (no link-time dependency)
 #include <unistd.h>
+#include <sys/stat.h>
+#include <ctime>
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -103,8 +105,15 @@ struct lt_engine {
   ncclComm_t comm = nullptr;
   int comm_nranks = 0, comm_rank = 0;
   DevBuf comm_send, comm_recv, comm_out, comm_counts;
+  hipStream_t comm_stream = nullptr;   // the collective runs beside the next step
+  hipEvent_t comm_packed = nullptr, comm_done = nullptr;
+  bool comm_busy = false;              // comm_done has been recorded
   bool rng_static = false;  // lt_set_rng_window_static: the window holds until it is set again
   int64_t rng_static_before = 0, rng_static_total = -1;
+  int64_t rng_static_own = -1;     // the shard's draws per step under the static window, read back ONCE (the first
+                                   // step after the window was set); the device checks every later step against it
+  hipEvent_t step_done = nullptr;  // end of the last lt_step on `stream`: the generators of the next step wait for it
+  std::vector<hipEvent_t> rng_job_ev;  // per job slot: the launch that read it has finished
   bool rng_ready = false;
   uint64_t rng_cur = 624;          // next stream word to be consumed
   int rng_P = 256;                 // generator states
@@ -147,10 +156,13 @@ struct lt_engine {
   StepParams pre_P;
   bool pre_valid = false;
   int64_t pre_own = 0;
+  bool pre_synced = true;   // step_prepare waited for the device (everything earlier on `stream` has completed)
   double pre_sig[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   hipStream_t rng_stream = nullptr;  // the MT19937 blocks of a step are generated beside k_rk
   hipEvent_t rng_done = nullptr;
-  bool rng_pending = false;
+  bool rng_pending = false, step_done_valid = false;
+  hipEvent_t resort_ev[2] = {nullptr, nullptr};  // around the last device-side re-sort (lt_get_counters reports its time)
+  unsigned resorts = 0;
   size_t prof_used = 0;
 };
 
@@ -297,6 +309,7 @@ void fill_params(lt_engine* e, StepParams& P) {
   P.rng_mask = e->rng_R ? ((unsigned long long)e->rng_R * RNG_S - 1ull) : 0ull;
   P.rng_draws = (c.HTurbOn ? 4 : 0) + (c.VTurbOn ? 2 * (c.idt / 2) : 0);
   P.rank = (const int*)e->rank.p; P.orig = (const int*)e->orig.p;
+  P.expect_own = -1;
   P.vt_tab = (double4*)e->vt_tab.p;
   P.vt_q.S = (double*)e->vt_qS.p; P.vt_q.S1 = (double*)e->vt_qS1.p; P.vt_q.S2 = (double*)e->vt_qS2.p;
   P.vt_q.wl = (unsigned short*)e->vt_qwl.p; P.vt_q.count = (int*)e->vt_qcount.p; P.vt_q.cap = e->vt_qcap;
@@ -497,6 +510,11 @@ int resort(lt_engine* e) {
   TRY(dev_alloc(e, e->permute_tmp, (size_t)n * 13 * 8));
   TRY(dev_alloc(e, e->sort_keys_in, (size_t)n * 4));
   const int bits = e->tile_key_bits;
+  if (!e->resort_ev[0]) {
+    HIPCHK(e, hipEventCreate(&e->resort_ev[0]));
+    HIPCHK(e, hipEventCreate(&e->resort_ev[1]));
+  }
+  HIPCHK(e, hipEventRecord(e->resort_ev[0], e->stream));
   hipLaunchKernelGGL(ltd::k_tile_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, (const int*)e->pr.p,
                      (const int*)e->tile_key.p, (int*)e->sort_keys_in.p, n);
   size_t tmp_bytes = 0;
@@ -519,6 +537,8 @@ int resort(lt_engine* e) {
   // "this particle's stored elements are verified" is per slot: verify again
   if (e->ele_ok.p) HIPCHK(e, hipMemsetAsync(e->ele_ok.p, 0, e->ele_ok.bytes, e->stream));
   HIPCHK(e, hipGetLastError());
+  HIPCHK(e, hipEventRecord(e->resort_ev[1], e->stream));
+  e->resorts += 1;
   e->perm_stale = true;
   return LT_OK;
 }
@@ -537,6 +557,7 @@ int rng_configure_kernels(lt_engine* e) {
     HIPCHK(e, hipFuncSetAttribute((const void*)ltmt::k_mt_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ltmt::LDS_BYTES * ltmt::GEN_PER_WG)));
     HIPCHK(e, hipFuncSetAttribute((const void*)ltmt::k_mt_jump, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ltmt::LDS_BYTES));
     HIPCHK(e, hipFuncSetAttribute((const void*)ltmt::k_mt_jump_each, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ltmt::LDS_BYTES));
+    HIPCHK(e, hipFuncSetAttribute((const void*)ltmt::k_mt_jump_fan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ltmt::LDS_BYTES));
     e->rng_kernels_configured = true;
   }
   return LT_OK;
@@ -551,10 +572,18 @@ int rng_init_device(lt_engine* e) {
   if (phi.empty()) return fail(e, LT_ERR_DEVICE, "MT19937 characteristic polynomial failed");
   e->rng_g0 = ltmt::jump_polynomial(phi, RNG_S - 624);
   e->rng_gS = ltmt::jump_polynomial(phi, RNG_S);
-  const std::vector<uint32_t>& gS = e->rng_gS;
-  DevBuf d_g0, d_gS;
-  TRY(upload(e, d_g0, e->rng_g0.data(), e->rng_g0.size() * 4));
-  TRY(upload(e, d_gS, gS.data(), gS.size() * 4));
+  // State 1 = the mt array moved to the start of block 1; then by doubling: with the states 1 .. h at the starts
+  // of blocks 1 .. h, ONE launch of the jump over h blocks places the next h of them (x^(2h*S) = the square of
+  // x^(h*S): one modular product on the host per round, beside the device's work).  log2(P) launches -- a launch
+  // per state, each waiting for the one before, was 169 ms of a turbulence engine's start-up at P = 256.
+  std::vector<std::vector<uint32_t>> pw;  // x^(S), x^(2S), x^(4S), ...
+  pw.push_back(e->rng_gS);
+  for (int h = 2; h < P - 1; h *= 2) pw.push_back(ltmt::poly_mulmod(phi, pw.back(), pw.back()));
+  std::vector<uint32_t> flat((size_t)(pw.size() + 1) * ltmt::GW);
+  std::copy(e->rng_g0.begin(), e->rng_g0.end(), flat.begin());
+  for (size_t r = 0; r < pw.size(); r++) std::copy(pw[r].begin(), pw[r].end(), flat.begin() + (r + 1) * ltmt::GW);
+  DevBuf d_g;
+  TRY(upload(e, d_g, flat.data(), flat.size() * 4));
   if (!e->rng_polys.p) TRY(dev_alloc(e, e->rng_polys, (size_t)RNG_MAX_POLYS * ltmt::GW * 4));
   e->rng_poly_slot.clear();
   e->rng_family_done = false;
@@ -562,15 +591,22 @@ int rng_init_device(lt_engine* e) {
   if (!e->rng_states.p) TRY(dev_alloc(e, e->rng_states, (size_t)P * 624 * 4));
   if (!e->rng_jobs) HIPCHK(e, hipHostMalloc((void**)&e->rng_jobs, sizeof(ltmt::BlockJob) * (size_t)RNG_JOB_SLOTS * P, hipHostMallocMapped));
   HIPCHK(e, hipMemcpyAsync(e->rng_states.p, e->mt, 624 * 4, hipMemcpyHostToDevice, e->stream));
-  for (int p = 1; p < P; p++) {
-    hipLaunchKernelGGL(ltmt::k_mt_jump, dim3(1), dim3(256), ltmt::LDS_BYTES, e->stream,
-                       (uint32_t*)e->rng_states.p, p - 1, p,
-                       (const uint32_t*)(p == 1 ? d_g0.p : d_gS.p));
+  if (P > 1)
+    hipLaunchKernelGGL(ltmt::k_mt_jump, dim3(1), dim3(256), ltmt::LDS_BYTES, e->stream, (uint32_t*)e->rng_states.p, 0, 1,
+                       (const uint32_t*)d_g.p);
+  {
+    int have = 1, r = 0;  // states 1 .. have are in place; the next round jumps over `have` blocks
+    while (have < P - 1) {
+      const int cnt = std::min(have, P - 1 - have);
+      hipLaunchKernelGGL(ltmt::k_mt_jump_fan, dim3((unsigned)cnt), dim3(256), ltmt::LDS_BYTES, e->stream,
+                         (uint32_t*)e->rng_states.p, 1, have + 1, (const uint32_t*)d_g.p + (size_t)(r + 1) * ltmt::GW);
+      have += cnt;
+      r += 1;
+    }
   }
   HIPCHK(e, hipGetLastError());
   HIPCHK(e, hipStreamSynchronize(e->stream));
-  (void)hipFree(d_g0.p);
-  (void)hipFree(d_gS.p);
+  (void)hipFree(d_g.p);
   e->rng_pos.assign(P, 0);
   for (int p = 0; p < P; p++) e->rng_pos[p] = p;
   e->rng_gen0_raw = true;
@@ -716,7 +752,15 @@ int rng_ensure(lt_engine* e, uint64_t first, uint64_t last, hipStream_t gen_stre
       HIPCHK(e, hipStreamSynchronize(gen_stream));
       launches = 0;
     }
-    ltmt::BlockJob* jobs = e->rng_jobs + (size_t)e->rng_job_slot * P;
+    // (a job slot is host memory the launch reads when it RUNS: before it is written again, the launch that
+    // last used it must have finished -- the host may be many steps ahead of the device)
+    if (e->rng_job_ev.empty()) {
+      e->rng_job_ev.assign(RNG_JOB_SLOTS, nullptr);
+      for (auto& ev : e->rng_job_ev) HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    const int job_slot = e->rng_job_slot;
+    HIPCHK(e, hipEventSynchronize(e->rng_job_ev[(size_t)job_slot]));
+    ltmt::BlockJob* jobs = e->rng_jobs + (size_t)job_slot * P;
     e->rng_job_slot = (e->rng_job_slot + 1) % RNG_JOB_SLOTS;
     // one launch: the next blocks as long as their owners differ (P consecutive blocks at most)
     int nj_total = 0;
@@ -751,6 +795,7 @@ int rng_ensure(lt_engine* e, uint64_t first, uint64_t last, hipStream_t gen_stre
       j0 += nj;
     }
     HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipEventRecord(e->rng_job_ev[(size_t)job_slot], gen_stream));
     launches++;
   }
   return LT_OK;
@@ -890,18 +935,20 @@ int lt_create(const lt_config* cfg, lt_engine** out) {
       hipEventCreateWithFlags(&e->compute_mark, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&e->pin_free[0], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&e->pin_free[1], hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&e->rng_done, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&e->rng_done, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e->step_done, hipEventDisableTiming) != hipSuccess) {
     delete e;
     return LT_ERR_DEVICE;
   }
   e->device = dev;
-  if (hipMalloc(&e->counters.p, CNT_COUNT * sizeof(unsigned long long)) != hipSuccess ||
-      hipHostMalloc((void**)&e->h_counters, CNT_COUNT * sizeof(unsigned long long)) != hipSuccess ||
+  if (hipMalloc(&e->counters.p, CNT_ALLOC * sizeof(unsigned long long)) != hipSuccess ||
+      hipHostMalloc((void**)&e->h_counters, CNT_ALLOC * sizeof(unsigned long long)) != hipSuccess ||
       hipMalloc(&e->flags.p, 16) != hipSuccess) {
     lt_destroy(e);
     return LT_ERR_DEVICE;
   }
-  e->counters.bytes = CNT_COUNT * sizeof(unsigned long long);
+  e->counters.bytes = CNT_ALLOC * sizeof(unsigned long long);
+  (void)hipMemsetAsync(e->counters.p, 0, e->counters.bytes, e->stream);
   e->flags.bytes = 16;
   (void)hipMemsetAsync(e->flags.p, 0, 16, e->stream);
   const char* envs = getenv("LT_NO_SORT");
@@ -926,6 +973,8 @@ int lt_destroy(lt_engine* e) {
   if (!e) return LT_ERR_ARG;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
+  if (e->comm_stream) (void)hipStreamSynchronize(e->comm_stream);
+  if (e->rng_stream) (void)hipStreamSynchronize(e->rng_stream);
   DevBuf* bufs[] = {&e->rnode, &e->unode, &e->vnode, &e->RE, &e->UE, &e->VE, &e->rAdj, &e->uAdj,
                     &e->vAdj, &e->lev, &e->fsR, &e->fsU, &e->fsV, &e->fsVU, &e->U, &e->V, &e->W, &e->Kh, &e->zeta, &e->staging, &e->stage_rom, &e->rmask, &e->umask, &e->vmask,
                     &e->flags, &e->bnd, &e->land, &e->bx, &e->by, &e->hx, &e->hy, &e->hid,
@@ -954,6 +1003,12 @@ int lt_destroy(lt_engine* e) {
   if (e->compute_mark) (void)hipEventDestroy(e->compute_mark);
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
   if (e->rng_done) (void)hipEventDestroy(e->rng_done);
+  if (e->step_done) (void)hipEventDestroy(e->step_done);
+  for (hipEvent_t ev : e->resort_ev) if (ev) (void)hipEventDestroy(ev);
+  if (e->comm_packed) (void)hipEventDestroy(e->comm_packed);
+  if (e->comm_done) (void)hipEventDestroy(e->comm_done);
+  if (e->comm_stream) (void)hipStreamDestroy(e->comm_stream);
+  for (hipEvent_t ev : e->rng_job_ev) if (ev) (void)hipEventDestroy(ev);
   if (e->rng_jobs) (void)hipHostFree(e->rng_jobs);
   if (e->rng_stream) (void)hipStreamDestroy(e->rng_stream);
   if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -1554,10 +1609,12 @@ int lt_set_particles(lt_engine* e, const lt_particles* p) {
   return LT_OK;
 }
 
+static int fetch_counters(lt_engine* e);
 int lt_get_particles(lt_engine* e, lt_particles* out) {
   if (!e || !out) return LT_ERR_ARG;
   if (!e->have_particles) return fail(e, LT_ERR_STATE, "no particles uploaded");
   HIPCHK(e, hipSetDevice(e->device));
+  if (e->rng_static) TRY(fetch_counters(e));  // (reports a static stream window that did not hold)
   TRY(sync_perm(e));
   TRY(get_field<double>(e, e->par, out->par, 13));
   TRY(get_field<int32_t>(e, e->pr, out->P_r_element, 1));
@@ -2165,6 +2222,7 @@ int lt_set_rng_window(lt_engine* e, int64_t active_before, int64_t active_total)
   e->rng_before = active_before * D;
   e->rng_total = active_total * D;
   e->rng_static = false;
+  e->rng_static_own = -1;
   return LT_OK;
 }
 
@@ -2174,6 +2232,8 @@ int lt_set_rng_window_static(lt_engine* e, int64_t active_before, int64_t active
   e->rng_static = active_total > 0;
   e->rng_static_before = e->rng_before;
   e->rng_static_total = e->rng_total;
+  e->rng_static_own = -1;
+  HIPCHK(e, hipMemsetAsync((unsigned long long*)e->counters.p + CNT_STATIC_MISS, 0, sizeof(unsigned long long), e->stream));
   return LT_OK;
 }
 
@@ -2273,10 +2333,22 @@ static int step_prepare(lt_engine* e, const double* ex3, const double* ix3, int3
       HIPCHK(e, hipMemsetAsync((int*)e->flag.p + n, 0, 4, e->stream));
       size_t tb = e->scan_tmp_bytes;
       HIPCHK(e, hipcub::DeviceScan::ExclusiveSum(e->scan_tmp.p, tb, (int*)e->flag.p, (int*)e->rank.p, n + 1, e->stream));
-      int own = 0;  // rank[n] = draws of this shard
-      HIPCHK(e, hipMemcpyAsync(&own, (int*)e->rank.p + n, 4, hipMemcpyDeviceToHost, e->stream));
-      HIPCHK(e, hipStreamSynchronize(e->stream));
-      e->pre_own = own;
+      // rank[n] = draws of this shard.  Under a static window (lt_set_rng_window_static: no particle can stop
+      // drawing) it is read back once; afterwards the host knows it, the step is enqueued without waiting for the
+      // device, and k_post compares the scan's total with it (a mismatch is reported by lt_get_stats /
+      // lt_get_particles: LT_ERR_STATE).
+      if (e->rng_static && e->rng_static_own >= 0) {
+        e->pre_own = e->rng_static_own;
+        P.expect_own = (long long)e->rng_static_own;
+        e->pre_synced = false;
+      } else {
+        int own = 0;
+        HIPCHK(e, hipMemcpyAsync(&own, (int*)e->rank.p + n, 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        e->pre_own = own;
+        e->pre_synced = true;
+        if (e->rng_static) e->rng_static_own = own;
+      }
     }
   }
   HIPCHK(e, hipGetLastError());
@@ -2328,8 +2400,10 @@ int lt_step(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32
       if (!e->rng_ready) TRY(rng_init_device(e));
       const uint64_t base = e->rng_cur + (uint64_t)before;
       if (own > 0) {
-        // everything earlier on e->stream has completed (step_prepare synchronised), so the
-        // generators may overwrite old ring blocks while k_rk runs on the main stream
+        // the generators may overwrite old ring blocks while k_rk runs on the main stream: everything earlier on
+        // e->stream has completed (step_prepare synchronised), or -- static window, nobody waited -- the
+        // generator stream waits for the end of the step before
+        if (!e->pre_synced && e->step_done_valid) HIPCHK(e, hipStreamWaitEvent(e->rng_stream, e->step_done, 0));
         TRY(rng_ensure(e, base, base + (uint64_t)own, e->rng_stream));
         HIPCHK(e, hipEventRecord(e->rng_done, e->rng_stream));
         e->rng_pending = true;
@@ -2364,6 +2438,8 @@ int lt_step(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32
     wait_rng(e);
     hipLaunchKernelGGL(k_post, dim3(blocks), dim3(256), 0, e->stream, P);
     HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipEventRecord(e->step_done, e->stream));
+    e->step_done_valid = true;
     TRY(phase_mark(e, 4));
   } else if (e->phase_on) {
     for (int k = 2; k <= 4; k++) TRY(phase_mark(e, k));
@@ -2375,10 +2451,14 @@ int lt_step(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32
 
 static int fetch_counters(lt_engine* e) {
   if (e->counters_fetched) return LT_OK;
-  HIPCHK(e, hipMemcpyAsync(e->h_counters, e->counters.p, CNT_COUNT * sizeof(unsigned long long),
+  HIPCHK(e, hipMemcpyAsync(e->h_counters, e->counters.p, CNT_ALLOC * sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
   e->counters_fetched = true;
+  if (e->h_counters[CNT_STATIC_MISS])
+    return fail(e, LT_ERR_STATE, "static random-stream window: the shard's draws changed (%llu step(s)); a particle "
+                                 "stopped or started drawing -- set the window before each step instead",
+                e->h_counters[CNT_STATIC_MISS]);
   return LT_OK;
 }
 
@@ -2418,6 +2498,11 @@ int lt_get_counters(lt_engine* e, uint64_t* out8) {
   TRY(lt_sync(e));
   TRY(fetch_counters(e));
   for (int i = 0; i < CNT_COUNT; i++) out8[i] = e->h_counters[i];
+  {  // [7]: re-sorts of the particle order so far << 32 | GPU microseconds of the last one
+    float ms = 0.f;
+    if (e->resorts && hipEventElapsedTime(&ms, e->resort_ev[0], e->resort_ev[1]) != hipSuccess) ms = 0.f;
+    out8[7] = ((uint64_t)e->resorts << 32) | (uint64_t)(unsigned)(ms * 1000.0f + 0.5f);
+  }
   return LT_OK;
 }
 
@@ -2553,11 +2638,18 @@ int lt_comm_init(lt_engine* e, const void* id128, int32_t nranks, int32_t rank) 
   return LT_OK;
 }
 
+// The id file is good for ONE communicator: rank 0 removes whatever lies at `path` before it writes, and removes
+// its own file once ncclCommInitRank has returned (every rank has joined by then, so every rank has read it);
+// the other ranks ignore a file last written before (their own start - timeout_s) -- what a crashed run left
+// behind -- and keep waiting for rank 0's.  (Ranks are expected to start within timeout_s of each other; a path
+// that is unique per run needs none of this and is what INTEGRATION.md recommends.)
+static const time_t g_lib_loaded = time(nullptr);
 int lt_comm_init_file(lt_engine* e, const char* path, int32_t nranks, int32_t rank, int32_t timeout_s) {
   if (!e || !path || nranks < 1 || rank < 0 || rank >= nranks) return LT_ERR_ARG;
   unsigned char id[128];
   if (rank == 0) {
     TRY(lt_comm_unique_id(id));
+    (void)unlink(path);
     const std::string tmp = std::string(path) + ".tmp";
     FILE* f = fopen(tmp.c_str(), "wb");
     if (!f || fwrite(id, 1, 128, f) != 128) { if (f) fclose(f); return fail(e, LT_ERR_ARG, "lt_comm_init_file: cannot write %s", tmp.c_str()); }
@@ -2565,14 +2657,20 @@ int lt_comm_init_file(lt_engine* e, const char* path, int32_t nranks, int32_t ra
     if (rename(tmp.c_str(), path) != 0) return fail(e, LT_ERR_ARG, "lt_comm_init_file: cannot rename to %s", path);
   } else {
     bool ok = false;
+    const time_t oldest = g_lib_loaded - (time_t)(timeout_s > 0 ? timeout_s : 0) - 2;
     for (int waited_ms = 0; waited_ms <= timeout_s * 1000 && !ok; waited_ms += 50) {
-      FILE* f = fopen(path, "rb");
-      if (f) { ok = fread(id, 1, 128, f) == 128; fclose(f); }
+      struct stat sb;
+      if (stat(path, &sb) == 0 && sb.st_size == 128 && sb.st_mtime >= oldest) {
+        FILE* f = fopen(path, "rb");
+        if (f) { ok = fread(id, 1, 128, f) == 128; fclose(f); }
+      }
       if (!ok) usleep(50 * 1000);
     }
-    if (!ok) return fail(e, LT_ERR_STATE, "lt_comm_init_file: %s did not appear within %d s", path, (int)timeout_s);
+    if (!ok) return fail(e, LT_ERR_STATE, "lt_comm_init_file: %s did not appear within %d s (a file left by an earlier run is ignored)", path, (int)timeout_s);
   }
-  return lt_comm_init(e, id, nranks, rank);
+  const int rc = lt_comm_init(e, id, nranks, rank);
+  if (rank == 0) (void)unlink(path);
+  return rc;
 }
 
 int lt_comm_destroy(lt_engine* e) {
@@ -2580,12 +2678,76 @@ int lt_comm_destroy(lt_engine* e) {
   if (e->comm) {
     RcclApi* R = rccl();
     (void)hipSetDevice(e->device);
+    if (e->comm_stream) (void)hipStreamSynchronize(e->comm_stream);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (R) (void)R->CommDestroy(e->comm);
     e->comm = nullptr;
   }
   return LT_OK;
 }
+
+namespace {
+// The all-gather in three parts, so that the test build can stand in for the collective on one GPU:
+//   ag_pack     sizes, buffers, this shard packed as [3][nmax] into the send buffer (engine's stream), and the
+//               hand-over to the communication stream
+//   (collective: ncclAllGather of the padded shards into [rank][3][nmax] on the communication stream)
+//   ag_finish   the padded blocks assembled as xyz(sum(counts),3) in global particle order, the copy to the host
+// The collective runs on its OWN stream, ordered by events: it waits for the pack; the engine's stream does not
+// wait for it, so the next lt_step runs beside the transfer, and only the next pack (which overwrites the send
+// buffer) waits for the previous collective.
+struct AgPlan { int G = 0; long long nmax = 0, total = 0; double* out = nullptr; };
+int ag_pack(lt_engine* e, int G, int rank, const int32_t* counts, void* xyz_device, AgPlan& A) {
+  if (counts[rank] != e->cfg.numpar) return fail(e, LT_ERR_ARG, "lt_allgather_positions: counts(rank+1) /= numpar of this engine");
+  A.G = G;
+  std::vector<long long> offs(G + 1, 0);
+  for (int r = 0; r < G; r++) {
+    if (counts[r] < 0) return LT_ERR_ARG;
+    A.nmax = std::max<long long>(A.nmax, counts[r]);
+    offs[r + 1] = offs[r] + counts[r];
+  }
+  A.total = offs[G];
+  if (A.total == 0) return LT_OK;
+  if (!e->comm_stream) {
+    HIPCHK(e, hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
+    HIPCHK(e, hipEventCreateWithFlags(&e->comm_packed, hipEventDisableTiming));
+    HIPCHK(e, hipEventCreateWithFlags(&e->comm_done, hipEventDisableTiming));
+  }
+  // the buffers of the collective before this one are free once it has finished (also before they are re-allocated)
+  if (e->comm_busy) HIPCHK(e, hipStreamWaitEvent(e->stream, e->comm_done, 0));
+  const size_t blk = (size_t)3 * (size_t)A.nmax * 8;
+  if (e->comm_send.bytes < blk || e->comm_recv.bytes < blk * G || e->comm_counts.bytes < (size_t)(G + 1) * 8 ||
+      (!xyz_device && e->comm_out.bytes < (size_t)3 * A.total * 8)) {
+    if (e->comm_busy) HIPCHK(e, hipEventSynchronize(e->comm_done));
+    if (e->comm_send.bytes < blk) TRY(dev_alloc(e, e->comm_send, blk));
+    if (e->comm_recv.bytes < blk * G) TRY(dev_alloc(e, e->comm_recv, blk * G));
+    if (e->comm_counts.bytes < (size_t)(G + 1) * 8) TRY(dev_alloc(e, e->comm_counts, (size_t)(G + 1) * 8));
+    if (!xyz_device && e->comm_out.bytes < (size_t)3 * A.total * 8) TRY(dev_alloc(e, e->comm_out, (size_t)3 * A.total * 8));
+  }
+  A.out = xyz_device ? (double*)xyz_device : (double*)e->comm_out.p;
+  HIPCHK(e, hipMemcpyAsync(e->comm_counts.p, offs.data(), (size_t)(G + 1) * 8, hipMemcpyHostToDevice, e->stream));
+  const int n = e->cfg.numpar;
+  if (n) {
+    // this shard as [3][nmax]: xyz(numpar,3) column-major with the columns nmax apart
+    const unsigned blocks = (unsigned)(((size_t)n + 255) / 256);
+    hipLaunchKernelGGL(k_pack_positions, dim3(blocks), dim3(256), 0, e->stream, (const double*)e->par.p,
+                       (const int*)e->orig.p, (double*)e->comm_send.p, n, (size_t)A.nmax);
+    HIPCHK(e, hipGetLastError());
+  }
+  HIPCHK(e, hipEventRecord(e->comm_packed, e->stream));
+  HIPCHK(e, hipStreamWaitEvent(e->comm_stream, e->comm_packed, 0));
+  return LT_OK;
+}
+int ag_finish(lt_engine* e, const AgPlan& A, double* xyz_host) {
+  hipLaunchKernelGGL(k_unpad_positions, dim3((unsigned)((A.total + 255) / 256)), dim3(256), 0, e->comm_stream,
+                     (const double*)e->comm_recv.p, (const long long*)e->comm_counts.p, A.G, A.nmax, A.total, A.out);
+  HIPCHK(e, hipGetLastError());
+  if (xyz_host) HIPCHK(e, hipMemcpyAsync(xyz_host, A.out, (size_t)3 * A.total * 8, hipMemcpyDeviceToHost, e->comm_stream));
+  HIPCHK(e, hipEventRecord(e->comm_done, e->comm_stream));
+  e->comm_busy = true;
+  if (xyz_host) HIPCHK(e, hipStreamSynchronize(e->comm_stream));
+  return LT_OK;
+}
+}  // namespace
 
 int lt_allgather_positions(lt_engine* e, const int32_t* counts, double* xyz_host, void* xyz_device) {
   if (!e || !counts || (!xyz_host && !xyz_device)) return LT_ERR_ARG;
@@ -2594,50 +2756,56 @@ int lt_allgather_positions(lt_engine* e, const int32_t* counts, double* xyz_host
   RcclApi* R = rccl();
   if (!R) return LT_ERR_UNSUPPORTED;
   HIPCHK(e, hipSetDevice(e->device));
-  const int G = e->comm_nranks;
-  if (counts[e->comm_rank] != e->cfg.numpar) return fail(e, LT_ERR_ARG, "lt_allgather_positions: counts(rank+1) /= numpar of this engine");
-  long long nmax = 0, total = 0;
-  std::vector<long long> offs(G + 1, 0);
-  for (int r = 0; r < G; r++) {
-    if (counts[r] < 0) return LT_ERR_ARG;
-    nmax = std::max<long long>(nmax, counts[r]);
-    offs[r + 1] = offs[r] + counts[r];
-  }
-  total = offs[G];
-  if (total == 0) return LT_OK;
-  const size_t blk = (size_t)3 * (size_t)nmax * 8;
-  if (e->comm_send.bytes < blk) TRY(dev_alloc(e, e->comm_send, blk));
-  if (e->comm_recv.bytes < blk * G) TRY(dev_alloc(e, e->comm_recv, blk * G));
-  if (e->comm_counts.bytes < (size_t)(G + 1) * 8) TRY(dev_alloc(e, e->comm_counts, (size_t)(G + 1) * 8));
-  double* out = (double*)xyz_device;
-  if (!out) {
-    if (e->comm_out.bytes < (size_t)3 * total * 8) TRY(dev_alloc(e, e->comm_out, (size_t)3 * total * 8));
-    out = (double*)e->comm_out.p;
-  }
-  HIPCHK(e, hipMemcpyAsync(e->comm_counts.p, offs.data(), (size_t)(G + 1) * 8, hipMemcpyHostToDevice, e->stream));
-  // pack this shard as [3][nmax] (column-major xyz(numpar,3) with the columns nmax apart)
-  const int n = e->cfg.numpar;
-  if (n) {
-    unsigned blocks = (unsigned)(((size_t)n + 255) / 256);
-    // k_pack_positions writes dst[o], dst[N + o], dst[2N + o] with N = numpar: pack densely, then spread the columns
-    double* dense = (double*)e->comm_recv.p;  // scratch: the receive buffer is free until the collective
-    hipLaunchKernelGGL(k_pack_positions, dim3(blocks), dim3(256), 0, e->stream, (const double*)e->par.p,
-                       (const int*)e->orig.p, dense, n);
-    for (int c = 0; c < 3; c++)
-      HIPCHK(e, hipMemcpyAsync((double*)e->comm_send.p + (size_t)c * nmax, dense + (size_t)c * n, (size_t)n * 8,
-                               hipMemcpyDeviceToDevice, e->stream));
-  }
-  const ncclResult_t rc = R->AllGather(e->comm_send.p, e->comm_recv.p, (size_t)3 * (size_t)nmax, ncclDouble, e->comm, e->stream);
+  AgPlan A;
+  TRY(ag_pack(e, e->comm_nranks, e->comm_rank, counts, xyz_device, A));
+  if (A.total == 0) return LT_OK;
+  const ncclResult_t rc = R->AllGather(e->comm_send.p, e->comm_recv.p, (size_t)3 * (size_t)A.nmax, ncclDouble, e->comm, e->comm_stream);
   if (rc != ncclSuccess) return fail(e, LT_ERR_DEVICE, "ncclAllGather: %s", R->GetErrorString ? R->GetErrorString(rc) : "error");
-  hipLaunchKernelGGL(k_unpad_positions, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream,
-                     (const double*)e->comm_recv.p, (const long long*)e->comm_counts.p, G, nmax, total, out);
-  HIPCHK(e, hipGetLastError());
-  if (xyz_host) {
-    HIPCHK(e, hipMemcpyAsync(xyz_host, out, (size_t)3 * total * 8, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+  return ag_finish(e, A, xyz_host);
+}
+
+int lt_allgather_wait(lt_engine* e) {
+  if (!e) return LT_ERR_ARG;
+  if (e->comm_busy) {
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipEventSynchronize(e->comm_done));
   }
   return LT_OK;
 }
+
+#ifdef LT_TEST_HOOKS
+/* Test aid (libltrans_hip_test.so only): the N-rank form of lt_allgather_positions on ONE GPU.  This engine is
+ * rank `rank` of `nranks`; the collective is replaced by what it would deliver: the receive buffer
+ * [rank][3][nmax] holds this engine's own padded block (copied from its send buffer, as ncclAllGather does) and,
+ * for every other rank r, counts[r] rows of others(sum of the other counts, 3) -- column-major, the other ranks'
+ * particles in rank order -- padded to nmax; the padding is filled with NaN so that a row taken from it shows. */
+int lt_test_allgather_layout(lt_engine* e, int32_t nranks, int32_t rank, const int32_t* counts, const double* others,
+                             double* xyz_host) {
+  if (!e || !counts || !xyz_host || nranks < 1 || rank < 0 || rank >= nranks) return LT_ERR_ARG;
+  if (!e->have_particles) return fail(e, LT_ERR_STATE, "no particles uploaded");
+  HIPCHK(e, hipSetDevice(e->device));
+  AgPlan A;
+  TRY(ag_pack(e, nranks, rank, counts, nullptr, A));
+  if (A.total == 0) return LT_OK;
+  long long n_others = 0;
+  for (int r = 0; r < nranks; r++) if (r != rank) n_others += counts[r];
+  std::vector<double> recv((size_t)nranks * 3 * (size_t)A.nmax, std::nan(""));
+  long long o = 0;
+  for (int r = 0; r < nranks; r++) {
+    if (r == rank) continue;
+    for (int c = 0; c < 3; c++)
+      for (long long j = 0; j < counts[r]; j++)
+        recv[((size_t)r * 3 + c) * (size_t)A.nmax + j] = others[(size_t)c * n_others + o + j];
+    o += counts[r];
+  }
+  HIPCHK(e, hipMemcpyAsync(e->comm_recv.p, recv.data(), recv.size() * 8, hipMemcpyHostToDevice, e->comm_stream));
+  HIPCHK(e, hipMemcpyAsync((double*)e->comm_recv.p + (size_t)rank * 3 * (size_t)A.nmax, e->comm_send.p,
+                           (size_t)3 * (size_t)A.nmax * 8, hipMemcpyDeviceToDevice, e->comm_stream));
+  const int rc = ag_finish(e, A, xyz_host);
+  HIPCHK(e, hipStreamSynchronize(e->comm_stream));   // (recv is a local)
+  return rc;
+}
+#endif
 
 
 /* createBounds (boundary_module.f90:82-1215) on the host side of the library: lt_bounds_host.h does the walk,
@@ -2705,7 +2873,7 @@ int lt_pack_positions(lt_engine* e, void* dst_device) {
   if (blocks)
     hipLaunchKernelGGL(k_pack_positions, dim3(blocks), dim3(256), 0, e->stream,
                        (const double*)e->par.p, (const int*)e->orig.p, (double*)dst_device,
-                       e->cfg.numpar);
+                       e->cfg.numpar, (size_t)e->cfg.numpar);
   HIPCHK(e, hipGetLastError());
   return LT_OK;
 }

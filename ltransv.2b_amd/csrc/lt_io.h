@@ -58,15 +58,16 @@ __global__ void k_rom_scatter(const HostT* __restrict__ src, SlabT* __restrict__
 }
 
 // xyz(numpar,3) column-major in the REFERENCE particle order <- par(:,1:3)
+// (ld = distance between the columns of dst: numpar, or the padded shard length of the all-gather)
 __global__ void k_pack_positions(const double* __restrict__ par, const int* __restrict__ orig,
-                                 double* __restrict__ dst, int numpar) {
+                                 double* __restrict__ dst, int numpar, size_t ld) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= numpar) return;
   const size_t N = (size_t)numpar;
   const int o = orig[i];
   dst[o] = par[i];
-  dst[N + o] = par[N + i];
-  dst[2 * N + o] = par[2 * N + i];
+  dst[ld + o] = par[N + i];
+  dst[2 * ld + o] = par[2 * N + i];
 }
 
 // act flag of every particle in REFERENCE order (input of the rank scan)

@@ -337,6 +337,20 @@ __global__ __launch_bounds__(256) void k_mt_jump(uint32_t* __restrict__ states, 
   for (int i = tid; i < N; i += blockDim.x) states[(size_t)dst * N + i] = lds[i];
 }
 
+// states[dst0 + b] = g(F) states[src0 + b], b = blockIdx.x: one round of the start-up positioning by doubling (the
+// states 1 .. 2^r sit at the starts of blocks 1 .. 2^r; the jump over 2^r blocks places 2^r more of them)
+__global__ __launch_bounds__(256) void k_mt_jump_fan(uint32_t* __restrict__ states, int src0, int dst0,
+                                                     const uint32_t* __restrict__ g) {
+  extern __shared__ uint32_t lds[];
+  const int tid = threadIdx.x;
+  const uint32_t* src = states + (size_t)(src0 + (int)blockIdx.x) * N;
+  uint32_t* dst = states + (size_t)(dst0 + (int)blockIdx.x) * N;
+  for (int i = tid; i < N; i += blockDim.x) lds[i] = src[i];
+  __syncthreads();
+  jump_in_lds(lds, g, tid, true);
+  for (int i = tid; i < N; i += blockDim.x) dst[i] = lds[i];
+}
+
 // states[b] = g(F) states[b] for every state b = blockIdx.x (a shard moves its whole pool to its part of the stream)
 __global__ __launch_bounds__(256) void k_mt_jump_each(uint32_t* __restrict__ states, const uint32_t* __restrict__ g) {
   extern __shared__ uint32_t lds[];

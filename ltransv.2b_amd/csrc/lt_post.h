@@ -262,7 +262,10 @@ __global__ __launch_bounds__(256) void k_post(const StepParams P) {
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if ((threadIdx.x & 63) == 0) atomicAdd(&tot, s);
     __syncthreads();
-    if (threadIdx.x == 0) P.counters[CNT_ACTIVE] = tot;
+    if (threadIdx.x == 0) {
+      P.counters[CNT_ACTIVE] = tot;
+      if (P.expect_own >= 0 && (long long)P.rank[P.numpar] != P.expect_own) P.counters[CNT_STATIC_MISS] += 1ull;
+    }
   }
   __syncthreads();
   unsigned vals[3] = {c_err, c_brute, c_pipslow};

@@ -460,6 +460,18 @@ class Engine:
         self._check(f(self._h, _ip(counts), _dp(out), None), "allgather_positions")
         return out
 
+    def allgather_positions_device(self, counts, dst_device_ptr):
+        """the same into device memory, asynchronously (allgather_wait() says when it is complete)"""
+        counts = _i4(counts)
+        f = self.lib.lt_allgather_positions
+        f.restype = C.c_int
+        self._check(f(self._h, _ip(counts), None, C.c_void_p(int(dst_device_ptr))), "allgather_positions")
+
+    def allgather_wait(self):
+        f = self.lib.lt_allgather_wait
+        f.restype = C.c_int
+        self._check(f(self._h), "allgather_wait")
+
     def comm_destroy(self):
         f = self.lib.lt_comm_destroy
         f.restype = C.c_int
@@ -484,7 +496,8 @@ class Engine:
         a = np.zeros(8, dtype=np.uint64)
         self._check(f(self._h, a.ctypes.data_as(C.c_void_p)), "get_counters")
         return {"active": int(a[0]), "errors": int(a[1]), "sigerr": int(a[2]),
-                "brute_bounds": int(a[3]), "pip_full": int(a[4]), "vt_queued": int(a[5]), "vt_rounds": int(a[6])}
+                "brute_bounds": int(a[3]), "pip_full": int(a[4]), "vt_queued": int(a[5]), "vt_rounds": int(a[6]),
+                "resorts": int(a[7]) >> 32, "last_resort_ms": (int(a[7]) & 0xFFFFFFFF) * 1e-3}
 
     def stream(self):
         f = self.lib.lt_stream

@@ -17,6 +17,19 @@
 ! Like the reference it appends every particle error to ErrorLog.txt (LTRANS.f90:858-877 etc., formats
 ! :761-775) and, with WriteModelTiming = .TRUE., writes Timing.csv (:471-476, :1669-1689) -- both in the
 ! current directory.
+!
+! Several GPUs (SURVEY 8e): one process per GPU, started by whatever starts processes (a shell loop, srun, mpirun)
+! with the environment
+!     LT_NRANKS = number of processes, LT_RANK = 0 .. LT_NRANKS-1, LT_COMM_FILE = a path all of them can reach
+!     (unique per run), LT_DEVICE = the GPU of this process (default: LT_RANK)
+! Rank g keeps particles [g*N/G, (g+1)*N/G) of the case file (contiguous blocks, so that a shard's place in the
+! serial random stream is one offset), the fields are replicated, and the only exchange is the all-gather of the
+! new (x,y,z) that the reference needs as one array at print steps (LTRANS.f90:604-612): lt_comm_init_file /
+! lt_allgather_positions, RCCL inside the library.  With turbulence the shards take static windows of the stream
+! (lt_set_rng_window_static), which holds while no particle can stop drawing; a run with settlement, mortality or
+! an open boundary needs the shards' counts exchanged before every step (lt_count_active + the host's own
+! collective), which this harness does not carry.  Every rank writes <out.bin>.rank<g> (its shard, then the
+! gathered xyz(N,3)); ErrorLog.txt / Timing.csv get the same suffix on ranks > 0.
 program ltrans_hip_driver
   use iso_c_binding
   use ltrans_hip
@@ -94,6 +107,13 @@ program ltrans_hip_driver
   double precision :: t_hydro, t_elapsed, tc(7)
   integer(8) :: clk0, clk1, clk_rate, clk_print
   integer :: printdt
+  ! ---- sharding (one process per GPU)
+  integer :: nranks, myrank, mydev, n0, n1, numpar_global, g_r, envlen, envstat
+  character(len=512) :: commfile, sfx, errlog, timingcsv
+  integer(c_int32_t), allocatable :: counts(:)
+  real(c_double), allocatable, target :: xyz_all(:,:)
+  real(c_double), allocatable :: par_g(:,:)
+  integer(c_int32_t), allocatable :: er_g(:), eu_g(:), ev_g(:)
 
   nargs = command_argument_count()
   if (nargs < 3) then
@@ -114,6 +134,30 @@ program ltrans_hip_driver
   endif
   if (nargs >= 5) then
     call get_command_argument(5, arg); read(arg, *) max_internal
+  endif
+  nranks = 1; myrank = 0; mydev = -1; commfile = ' '; sfx = ' '
+  call get_environment_variable('LT_NRANKS', arg, envlen, envstat)
+  if (envstat == 0 .and. envlen > 0) read(arg, *) nranks
+  call get_environment_variable('LT_RANK', arg, envlen, envstat)
+  if (envstat == 0 .and. envlen > 0) read(arg, *) myrank
+  call get_environment_variable('LT_DEVICE', arg, envlen, envstat)
+  if (envstat == 0 .and. envlen > 0) then
+    read(arg, *) mydev
+  else if (nranks > 1) then
+    mydev = myrank
+  endif
+  call get_environment_variable('LT_COMM_FILE', commfile, envlen, envstat)
+  if (envstat /= 0 .or. envlen == 0) commfile = ' '
+  if (nranks < 1 .or. myrank < 0 .or. myrank >= nranks) stop 'LT_RANK / LT_NRANKS out of range'
+  if (len_trim(commfile) > 0) then
+    write(sfx, '(a,i0)') '.rank', myrank
+    outfile = trim(outfile)//trim(sfx)
+  else if (nranks > 1) then
+    stop 'LT_NRANKS > 1 needs LT_COMM_FILE'
+  endif
+  errlog = 'ErrorLog.txt'; timingcsv = 'Timing.csv'
+  if (myrank > 0) then
+    errlog = trim(errlog)//trim(sfx); timingcsv = trim(timingcsv)//trim(sfx)
   endif
 
   ! ---- getParams: same groups, same order as the reference's reader
@@ -162,6 +206,23 @@ program ltrans_hip_driver
   if (maxisland > 0) read(2) hx(1:maxisland), hy(1:maxisland), hid(1:maxisland)
   read(2) par, P_r_element, P_u_element, P_v_element
   allocate(zeta(rho_nodes), Uvel(u_nodes,us), Vvel(v_nodes,us), Wvel(rho_nodes,ws), Kh(rho_nodes,ws))
+  ! ---- this rank's contiguous block of the particles (everything below sees numpar = the shard)
+  numpar_global = numpar
+  allocate(counts(nranks))
+  do g_r = 0, nranks - 1
+    counts(g_r + 1) = int((int(g_r + 1, 8) * numpar_global) / nranks - (int(g_r, 8) * numpar_global) / nranks, c_int32_t)
+  enddo
+  n0 = int((int(myrank, 8) * numpar_global) / nranks)
+  n1 = int((int(myrank + 1, 8) * numpar_global) / nranks)
+  if (nranks > 1) then
+    call move_alloc(par, par_g); call move_alloc(P_r_element, er_g)
+    call move_alloc(P_u_element, eu_g); call move_alloc(P_v_element, ev_g)
+    numpar = n1 - n0
+    allocate(par(numpar,13), P_r_element(numpar), P_u_element(numpar), P_v_element(numpar))
+    par = par_g(n0+1:n1, :)
+    P_r_element = er_g(n0+1:n1); P_u_element = eu_g(n0+1:n1); P_v_element = ev_g(n0+1:n1)
+    deallocate(par_g, er_g, eu_g, ev_g)
+  endif
 
   ! ---- initBehave (behavior_module.f90:94-160) / initSettlement state
   allocate(P_behave(numpar), dead(numpar), oob(numpar), settle(numpar), endpoly(numpar))
@@ -197,8 +258,20 @@ program ltrans_hip_driver
   cfg%lonmin = lonmin; cfg%latmin = latmin
   cfg%SaltTempOn = merge(1, 0, SaltTempOn); cfg%TrackCollisions = merge(1, 0, TrackCollisions)
   cfg%FreeSlip = merge(1, 0, FreeSlip)
+  cfg%device = mydev
   eng = c_null_ptr
   call lt_check(lt_create(cfg, eng), eng, 'lt_create')
+  if (len_trim(commfile) > 0) then
+    call lt_check(lt_comm_init_file(eng, trim(commfile)//c_null_char, int(nranks, c_int32_t), &
+                                    int(myrank, c_int32_t), 120_c_int32_t), eng, 'lt_comm_init_file')
+  endif
+  if (nranks > 1 .and. (HTurbOn .or. VTurbOn)) then
+    if (settlementon .or. mortality .or. OpenOceanBoundary .or. (Behavior >= 1 .and. Behavior <= 5)) &
+      stop 'sharded run: the shards'' draw counts can change; exchange them before each step (lt_count_active)'
+    ! the shard's window of the serial stream: the tracked particles of the lower ranks come first
+    call lt_check(lt_set_rng_window_static(eng, int(n0, c_int64_t), int(numpar_global, c_int64_t)), eng, &
+                  'lt_set_rng_window_static')
+  endif
 
   g%rho_nodes = rho_nodes; g%u_nodes = u_nodes; g%v_nodes = v_nodes
   g%rho_elements = rho_elements; g%u_elements = u_elements; g%v_elements = v_elements
@@ -253,7 +326,7 @@ program ltrans_hip_driver
   call lt_check(lt_set_time_slots(eng, t_b, t_c, t_f), eng, 'lt_set_time_slots')
 
   ! ErrorLog.txt is opened fresh by ini_LTRANS (LTRANS.f90:337-354); only err_code comes back for it
-  open(210, file='ErrorLog.txt', status='replace'); close(210)
+  open(210, file=trim(errlog), status='replace'); close(210)
   perr%par = c_null_ptr
   perr%P_r_element = c_null_ptr; perr%P_u_element = c_null_ptr; perr%P_v_element = c_null_ptr
   perr%P_behave = c_null_ptr; perr%dead = c_null_ptr; perr%oob = c_null_ptr
@@ -264,7 +337,7 @@ program ltrans_hip_driver
   perr%P_Salt = c_null_ptr; perr%P_Temp = c_null_ptr
   perr%err_code = c_loc(err_code)
   if (WriteModelTiming) then        ! LTRANS.f90:471-476
-    open(300, file='Timing.csv', status='replace')
+    open(300, file=trim(timingcsv), status='replace')
     write(300,'(A)') 'Daytime,Elapsed,Hydro,Hydro %,Set Up,Set Up %,'// &
                      'Advection,Advection %,HTurb,HTurb %,VTurb,VTurb %,Behavior,'// &
                      'Behavior %,Update,Update %'
@@ -325,7 +398,7 @@ program ltrans_hip_driver
         ! the reference appends one line per event to ErrorLog.txt as it happens; here the step's
         ! per-particle codes come back once and are written in particle order (formats LTRANS.f90:761-775)
         call lt_check(lt_get_particles(eng, perr), eng, 'lt_get_particles(err_code)')
-        open(210, file='ErrorLog.txt', position='append')
+        open(210, file=trim(errlog), position='append')
         do n = 1, numpar
           select case (err_code(n))
             case (4);  write(210,21) n, int(ix(3))
@@ -359,7 +432,7 @@ program ltrans_hip_driver
           tc(1) = t_hydro; tc(2) = ms4(1) * 1.0d-3; tc(3) = ms4(2) * 1.0d-3
           tc(5) = ms4(3) * 1.0d-3; tc(7) = ms4(4) * 1.0d-3      ! HTurb, Behavior: inside the update kernel
           t_hydro = 0.0d0
-          open(300, file='Timing.csv', position='append')
+          open(300, file=trim(timingcsv), position='append')
           write(300,"(15(F14.4,','),F14.4)") ix(3)/86400.0d0, t_elapsed, &
             tc(1), tc(1)/t_elapsed*100.0d0, tc(2), tc(2)/t_elapsed*100.0d0, tc(3), tc(3)/t_elapsed*100.0d0, &
             tc(4), tc(4)/t_elapsed*100.0d0, tc(5), tc(5)/t_elapsed*100.0d0, tc(6), tc(6)/t_elapsed*100.0d0, &
@@ -383,6 +456,14 @@ program ltrans_hip_driver
   outp%hitBottom = c_null_ptr; outp%hitLand = c_null_ptr
   call lt_check(lt_get_output(eng, outp, 0_c_int32_t), eng, 'lt_get_output')
   write(3) o_lon, o_lat, o_z, o_age, o_status
+  if (len_trim(commfile) > 0) then
+    ! the print step's one array of all particles (LTRANS.f90:604-612): every rank receives xyz(N,3)
+    allocate(xyz_all(numpar_global,3))
+    call lt_check(lt_allgather_positions(eng, counts, xyz_all, c_null_ptr), eng, 'lt_allgather_positions')
+    write(3) int(numpar_global, c_int32_t)
+    write(3) xyz_all
+    call lt_check(lt_comm_destroy(eng), eng, 'lt_comm_destroy')
+  endif
   close(3)
   write(*,'(A,I0,A,I0,A,I0)') 'ltrans_hip_driver: ', numpar, ' particles, ', stepT*stepIT, &
         ' internal steps, particle errors: ', total_errors

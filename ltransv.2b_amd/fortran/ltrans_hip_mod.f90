@@ -260,6 +260,11 @@ module ltrans_hip
       type(c_ptr), value :: xyz_device
       integer(c_int) :: rc
     end function
+    function lt_allgather_wait(engine) bind(C, name="lt_allgather_wait") result(rc)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: engine
+      integer(c_int) :: rc
+    end function
     function lt_comm_destroy(engine) bind(C, name="lt_comm_destroy") result(rc)
       import :: c_ptr, c_int
       type(c_ptr), value :: engine

@@ -246,7 +246,7 @@ def create_bounds(g):
 # --------------------------------------------------------------------------
 # fields
 # --------------------------------------------------------------------------
-def make_record(g, geo, r, dt=3600.0, with_kh=True, drift=(0.0, 0.0), raw=None):
+def make_record(g, geo, r, dt=3600.0, with_kh=True, drift=(0.0, 0.0), raw=None, with_st=True):
     """History record r (time r*dt) as ROMS stores it (float32), then masked and
     node-numbered as updateHydro does (hydrodynamic_module.f90:1371-1403).
     ``drift`` adds a uniform (u, v) to push particles into the coast (reflection tests).
@@ -255,7 +255,9 @@ def make_record(g, geo, r, dt=3600.0, with_kh=True, drift=(0.0, 0.0), raw=None):
     ``raw`` = np.float32 / np.float64: instead return the record as NF90_GET_VAR delivers
     it, BEFORE the mask multiply: dict romZ (vi,uj), romU (ui,uj,us), romV (vi,vj,us),
     romW, romKH (vi,uj,ws) of that type, Fortran order (land points hold ocean-like
-    values, as a ROMS file's fill-free fields may)."""
+    values, as a ROMS file's fill-free fields may).  with_st=False leaves salinity and temperature
+    out (None): two transcendental fields over the whole grid that only the salinity / temperature
+    behaviours read."""
     vi, uj, us, ws = g["vi"], g["uj"], g["us"], g["ws"]
     Lx, Ly = (vi - 1) * g["dx"], (uj - 1) * g["dy"]
     t = r * dt
@@ -284,21 +286,24 @@ def make_record(g, geo, r, dt=3600.0, with_kh=True, drift=(0.0, 0.0), raw=None):
             (0.55 + 0.45 * np.sin(2 * np.pi * (xr + 0.25 * t / 44714.0)) * np.cos(2 * np.pi * yr))[:, :, None]
     # salinity with a halocline near -6 m that moves with the tide (up to ~2 psu/m: above the
     # Sgradient cue of behaviours 4/5 in places, below it elsewhere); temperature
-    zr = (g["h"][:, :, None] * sr)                       # approximate depth of the rho levels
-    hal = -6.0 + 2.0 * np.sin(2 * np.pi * (xr + t / 44714.0))[:, :, None]
-    S = 30.0 + 4.0 * np.tanh((hal - zr) / 2.0) + 1.5 * (np.sin(2 * np.pi * xr) * np.cos(np.pi * yr))[:, :, None]
-    T = 12.0 + 8.0 * np.exp(zr / 15.0) + 0.5 * np.cos(2 * np.pi * (yr - t / 44714.0))[:, :, None]
+    S = T = None
+    if with_st:
+        zr = (g["h"][:, :, None] * sr)                       # approximate depth of the rho levels
+        hal = -6.0 + 2.0 * np.sin(2 * np.pi * (xr + t / 44714.0))[:, :, None]
+        S = 30.0 + 4.0 * np.tanh((hal - zr) / 2.0) + 1.5 * (np.sin(2 * np.pi * xr) * np.cos(np.pi * yr))[:, :, None]
+        T = 12.0 + 8.0 * np.exp(zr / 15.0) + 0.5 * np.cos(2 * np.pi * (yr - t / 44714.0))[:, :, None]
     if raw is not None:
         conv = lambda a: np.asfortranarray(a.astype(np.float32).astype(raw))  # noqa: E731
         return dict(romZ=conv(zeta), romU=conv(U + 0.0 * sr), romV=conv(V + 0.0 * sr), romW=conv(W),
-                    romKH=conv(K) if with_kh else None, romS=conv(S), romT=conv(T))
+                    romKH=conv(K) if with_kh else None, romS=conv(S) if with_st else None,
+                    romT=conv(T) if with_st else None)
     out = dict(
         zeta=F(f32(zeta) * geo["m_r"]),
         Uvel=F(f32(U) * geo["m_u"][:, :, None]),
         Vvel=F(f32(V) * geo["m_v"][:, :, None]),
         Wvel=F(f32(W) * geo["m_r"][:, :, None]),
-        salt=F(f32(S) * geo["m_r"][:, :, None]),
-        temp=F(f32(T) * geo["m_r"][:, :, None]),
+        salt=F(f32(S) * geo["m_r"][:, :, None]) if with_st else None,
+        temp=F(f32(T) * geo["m_r"][:, :, None]) if with_st else None,
     )
     if with_kh:
         out["Kh"] = F(f32(K) * geo["m_r"][:, :, None])

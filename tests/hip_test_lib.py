@@ -27,3 +27,16 @@ class HipTestEngine(ltrans_amd.Engine):
 
     def __init__(self, cfg):
         self._open(cfg, load(), "lt_")
+
+    def allgather_layout(self, nranks, rank, counts, others):
+        """lt_test_allgather_layout: this engine as rank `rank` of `nranks`; `others` = xyz(sum of the other
+        counts, 3) of the other ranks in rank order -> xyz(sum(counts), 3) as lt_allgather_positions assembles it"""
+        import numpy as np
+        counts = np.ascontiguousarray(counts, dtype=np.int32)
+        others = np.asfortranarray(others, dtype=np.float64)
+        out = np.full((int(counts.sum()), 3), -7.0, order="F")
+        f = self.lib.lt_test_allgather_layout
+        f.restype = C.c_int
+        self._check(f(self._h, int(nranks), int(rank), counts.ctypes.data_as(C.c_void_p),
+                      others.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)), "test_allgather_layout")
+        return out

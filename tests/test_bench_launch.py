@@ -53,7 +53,8 @@ def test_two_rank_rehearsal_of_the_benchmark():
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 3
     assert d["config"]["particles_total"] == 40000 and d["config"]["particles_this_rank"] == 20000
-    assert d["config"]["baseline_config"] == "config4" and d["config"]["rng_window"] == "static"
+    assert d["config"]["baseline_config"] == "config4" and d["config"]["rng_window"].startswith("static")
+    assert d["config"]["collective_backend"] == "gloo" and "gloo" in d["config"]["workload"]
     assert d["config"]["errors_last_step"] == 0 and d["value"] > 0
     assert d["config"]["single_gpu_same_workload"]["value"] > 0
     assert d["cpu_baseline"] is None
@@ -68,6 +69,11 @@ def test_single_gpu_line_carries_config3_and_hash():
     assert d["n_gpus"] == 1 and d["config"]["baseline_config"] == "config2"
     t = d["config"]["turbulence"]
     assert t["value"] > 0 and t["roofline"]["kernel"] == "k_vt_table+k_vt_sigs+k_vt_walk_fast+k_vt_walk"
+    # bytes and time of a figure cover the same kernels: the VTurb group against A_turb - A_adv, the step against A_turb
+    assert t["roofline"]["algorithmic_bytes_per_particle_step"] == 48 * 21 + 992
+    assert t["roofline"]["whole_step"]["algorithmic_bytes_per_particle_step"] == 976 + 48 * 21 + 992
+    assert t["rng_window"].startswith("static") and t["create_to_first_step_s"] > 0
+    assert d["config"]["resorts_in_timed_region"] == 0 and d["config"]["total_s"] > d["config"]["setup_s"] > 0
     assert len(d["config"]["kernel_source_hash"]) == 16
     assert d["roofline"]["traffic"] is None          # not the profiled shape
 

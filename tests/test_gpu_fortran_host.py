@@ -45,6 +45,28 @@ def test_fortran_driver_matches_python_driver(tmp_path, name, pipeline):
         assert np.array_equal(f[k], o[k]), k
 
 
+def test_fortran_driver_rank_mode(tmp_path):
+    """the harness as one process per GPU (LT_NRANKS / LT_RANK / LT_COMM_FILE), here with one rank: the shard is the
+    whole case, the static stream window is the whole stream, and the array the all-gather returns is par(:,1:3)."""
+    if not os.path.exists(DRIVER):
+        pytest.skip("Fortran harness not built (flang absent at build time)")
+    case = cases.build_case("tiny_turb")
+    n_ext, n_int = 2, 5
+    casefile.write_ltrans_data(tmp_path / "LTRANS.data", case["cfg"], days=1.0)
+    casefile.write_case(tmp_path / "case.bin", case["g"], case["geo"], case["bounds"], case["parts"],
+                        [case["record"](r) for r in range(n_ext + 1)], case["cfg"].numpar)
+    env = dict(os.environ, LT_NRANKS="1", LT_RANK="0", LT_COMM_FILE=str(tmp_path / "comm_id"), LT_DEVICE="0")
+    r = subprocess.run([DRIVER, str(tmp_path / "LTRANS.data"), str(tmp_path / "case.bin"),
+                        str(tmp_path / "out.bin"), str(n_ext), str(n_int), "0"], capture_output=True, text=True,
+                       cwd=tmp_path, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    f = casefile.read_result(tmp_path / "out.bin.rank0")
+    p = cases.run_case(case, ltrans_amd.Engine, {}, n_external=n_ext, max_internal=n_int)
+    assert np.array_equal(f["par"], p["par"])
+    assert np.array_equal(f["xyz_all"], p["par"][:, :3])
+    assert not (tmp_path / "comm_id").exists()
+
+
 def test_fortran_driver_writes_errorlog_and_timing(tmp_path):
     """the harness's ErrorLog.txt (one line per particle error in the reference's formats, LTRANS.f90:761-775,
     858-877) and, with WriteModelTiming, Timing.csv (header :471-476, one row per print interval :1669-1689)."""

@@ -118,8 +118,59 @@ def test_abi_allgather_single_rank(tmp_path):
     run = LtransRun(e, case["cfg"].dt, case["cfg"].idt, case["record"])
     run.init_hydro()
     run.run(1, max_internal=3)
-    e.comm_init_file(tmp_path / "lt_comm_id", 1, 0)
+    idfile = tmp_path / "lt_comm_id"
+    e.comm_init_file(idfile, 1, 0)
+    assert not idfile.exists()          # rank 0 removes the id file once the communicator exists
     xyz = e.allgather_positions([case["cfg"].numpar])
     assert np.array_equal(xyz, e.get_particles(fields=("par",))["par"][:, :3])
+    # the asynchronous form: the next step is enqueued behind the call and runs beside the collective
+    import torch
+    dst = torch.empty(3 * case["cfg"].numpar, dtype=torch.float64, device="cuda")
+    before = e.get_particles(fields=("par",))["par"][:, :3].copy()
+    e.allgather_positions_device([case["cfg"].numpar], dst.data_ptr())
+    run.run_external_timestep(2, max_internal=1)
+    e.allgather_wait()
+    torch.cuda.synchronize()
+    assert np.array_equal(dst.cpu().numpy().reshape(3, -1).T, before)
     e.comm_destroy()
     e.close()
+
+
+def test_comm_id_file_of_an_earlier_run_is_ignored(tmp_path):
+    """a rank > 0 does not take the id file a crashed run left behind (older than its own start - timeout)"""
+    import os
+    import time
+    case = cases.build_case("tiny_adv")
+    e = cases.make_engine(case, ltrans_amd.Engine, {})
+    stale = tmp_path / "lt_comm_id"
+    stale.write_bytes(b"\0" * 128)
+    old = time.time() - 3600
+    os.utime(stale, (old, old))
+    with pytest.raises(RuntimeError, match="did not appear"):
+        e.comm_init_file(stale, 2, 1, timeout_s=1)
+    e.close()
+
+
+def test_allgather_layout_three_ragged_shards():
+    """The N-rank form of lt_allgather_positions on one GPU (test build: the collective is replaced by what it
+    delivers): padded blocks [rank][3][nmax] of three shards of unequal size -- one of them empty -- assembled in
+    global particle order, for this engine as the first, the middle and the last rank."""
+    import hip_test_lib
+    case = cases.build_case("tiny_adv")
+    n = case["cfg"].numpar
+    rng = np.random.default_rng(5)
+    for rank, counts in ((0, [n, 0, 3 * n + 7]), (1, [5, n, 2 * n + 1]), (2, [n + 9, 1, n]), (1, [0, n, 0])):
+        e = cases.make_engine(case, hip_test_lib.HipTestEngine, {})
+        own = e.get_particles(fields=("par",))["par"][:, :3]
+        n_others = sum(c for r, c in enumerate(counts) if r != rank)
+        others = np.asfortranarray(rng.standard_normal((n_others, 3)))
+        got = e.allgather_layout(3, rank, counts, others)
+        parts, o = [], 0
+        for r, c in enumerate(counts):
+            if r == rank:
+                parts.append(own)
+            else:
+                parts.append(others[o:o + c])
+                o += c
+        assert np.array_equal(got, np.concatenate(parts, axis=0)), (rank, counts)
+        e.close()

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "GRBM_GUI_ACTIVE TA_TA_BUSY TA_FLAT_READ_WAVEFRONTS" "TA_ADDR_STALLED_BY_TC_CYCLES TA_DATA_STALLED_BY_TC_CYCLES" "TCP_TOTAL_CACHE_ACCESSES TCP_TCC_READ_REQ TCP_PENDING_STALL_CYCLES TCP_TCP_TA_DATA_STALL_CYCLES" "TCP_TA_TCP_STATE_READ TCP_GATE_EN1 TCP_GATE_EN2 TCP_TOTAL_ACCESSES"; do
   i=$((i+1))
-  timeout -k 5 150 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/p$i -o r -- python3 $repo/bench.py --no-cpu-baseline --no-hydro-timing --steps 4 --warmup 2 > $out/p$i.log 2>&1 || echo "pass $i failed: $set"
+  timeout -k 5 150 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/p$i -o r -- python3 $repo/bench.py --no-cpu-baseline --no-hydro-timing --no-turbulence-line --steps 4 --warmup 2 > $out/p$i.log 2>&1 || echo "pass $i failed: $set"
   echo "pass $i done"
 done
 cd $repo
