@@ -16,6 +16,8 @@ CASES = {
                       numpar=608, near_land=0.2, cfg=dict(Behavior=0)),
     "mid_adv": dict(grid=(128, 64, 30), islands=[], numpar=20000, near_land=0.1,
                     cfg=dict(Behavior=0)),
+    "mid_turb": dict(grid=(128, 64, 30), islands=[], numpar=20000, near_land=0.1,
+                     cfg=dict(Behavior=0, HTurbOn=1, VTurbOn=1)),
     "tiny_vt2": dict(grid=(24, 16, 8), islands=[(10, 12, 6, 8)], numpar=512, near_land=0.3,
                      cfg=dict(Behavior=0, Vtransform=2, hc=5.0)),
     "tiny_vt3": dict(grid=(24, 16, 8), islands=[(10, 12, 6, 8)], numpar=512, near_land=0.3,
@@ -165,6 +167,8 @@ def run_case(case, engine_cls, engine_kw, n_external=2, max_internal=None, trace
     run.run(n_external, max_internal=max_internal, on_step=on_step if trace is not None else None)
     out = e.get_particles()
     out["stats"] = e.stats()
+    if hasattr(e, "counters") and getattr(e, "prefix", "") == "lt_":
+        out["counters"] = e.counters()
     e.close()
     return out
 

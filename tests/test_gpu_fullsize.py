@@ -118,3 +118,33 @@ def test_sample_of_the_full_run_against_the_oracle(world):
     orc[0][0].close()
     rel = np.max(np.abs(rh[:, :3] - ro[:, :3]) / np.maximum(np.abs(ro[:, :3]), 1.0))
     assert rel <= 1e-6, rel      # BASELINE.json's tolerance; typically 1e-15
+
+
+INT_FIELDS = ("P_r_element", "P_u_element", "P_v_element", "err_code", "hitBottom", "hitLand", "dead", "oob")
+
+
+def test_sample_of_the_full_run_with_turbulence_against_the_oracle(world):
+    """BASELINE configs[2]'s own shape -- 512x256x30, ws = 31 (the 124-knot VTurb profile), HTurb + VTurb -- against
+    the oracle: a 20k-particle sample of the 1M, 5 internal steps; integers identical, (x,y,z) within 1e-6."""
+    lo, hi = 400_000, 420_000
+    kw = dict(HTurbOn=1, VTurbOn=1, ConstantHTurb=1.0, TrackCollisions=1)
+
+    def run(engine_kw):
+        e, r = _engine(world, lo, hi, kw=engine_kw, **kw)
+        ex = r.external_times(2)
+        for it in range(1, 6):
+            e.update_particles(ex, r.internal_times(ex, it), 2, it)
+        out = e.get_particles(fields=("par",) + INT_FIELDS)
+        out["active"] = e.stats()["active"]
+        e.close()
+        return out
+
+    rh = run(None)
+    ro = run(dict(lib=oracle_lib.load_oracle(), prefix="lto_"))
+    rel = np.max(np.abs(rh["par"][:, :3] - ro["par"][:, :3]) / np.maximum(np.abs(ro["par"][:, :3]), 1.0))
+    print(f"configs[2] sample: max rel err {rel:.3e}")
+    assert rel <= 1e-6, rel
+    for k in INT_FIELDS:
+        assert np.array_equal(rh[k], ro[k]), k
+    assert rh["active"] == ro["active"] == hi - lo
+    assert np.abs(ro["par"][:, 2] - ro["par"][:, 8]).max() > 0.0

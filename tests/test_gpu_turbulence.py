@@ -156,3 +156,19 @@ def test_long_horizon_is_bit_identical(oracle, name):
         err = cases.rel_error(hip["par"], ora["par"])
         assert err <= 1e-3
         pytest.xfail(f"not bit-identical (max rel err {err:.2e}): the host libm is not the one lt_libm.h restates")
+
+
+def test_mid_size_run_across_a_resort_is_bit_identical(oracle):
+    """20k particles on 128x64x30 with HTurb + VTurb through 46 internal steps (two external steps): the device-side
+    re-sort of the particle order (every 32 steps by default) falls inside a run that is compared with the oracle."""
+    case = cases.build_case("mid_turb")
+    hip = cases.run_case(case, ltrans_amd.Engine, {}, n_external=2, max_internal=23)
+    assert hip["counters"]["resorts"] >= 1
+    ora = cases.run_case(cases.build_case("mid_turb"), ltrans_amd.Engine, dict(lib=oracle, prefix="lto_"), n_external=2,
+                         max_internal=23)
+    for k in ("P_r_element", "P_u_element", "P_v_element", "err_code", "hitBottom", "hitLand", "dead", "oob"):
+        assert np.array_equal(hip[k], ora[k]), k
+    err = cases.rel_error(hip["par"], ora["par"])
+    assert err <= 1e-6, err
+    if not np.array_equal(hip["par"][:, :9], ora["par"][:, :9]):
+        pytest.xfail(f"within 1e-6 but not bit-identical (max rel err {err:.2e}): the host libm is not the one lt_libm.h restates")
