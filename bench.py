@@ -216,7 +216,7 @@ def algorithmic_bytes(slab, turb, ws):
     return A
 
 
-VT_KERNELS = ["k_vt_table", "k_vt_sigs", "k_vt_walk_fast", "k_vt_walk"]
+VT_KERNELS = ["k_vt_table", "k_vt_sigs", "k_vt_norm", "k_vt_walk_fast", "k_vt_walk"]
 
 
 def roofline_block(slab, turb, ws, n, k_avg_s, step_s, traffic, traffic_src, valu):

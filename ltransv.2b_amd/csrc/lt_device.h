@@ -149,6 +149,7 @@ struct StepParams {
                                   // sum, in reference order, of the draws of the tracked particles
   const int* orig;                // [numpar] reference index of internal slot i
   long long expect_own;           // >= 0: the shard's draw total the host assumed (static window); k_post checks rank[numpar]
+  double* vt_dev;   // the walk's normal deviates [group of 64 particles][idt/2 sub-steps][lane] (k_vt_norm)
   double4* vt_tab;  // VTurb spline table [wave][4*ws][lane] of {x, y, yp, sigma}
   VtQueue vt_q;     // per-wave task lists of the SIGS iterations (lt_vturb.h)
   // the walks that met an interval with a tension factor and are finished by k_vt_walk (lt_vturb.h):

@@ -129,7 +129,7 @@ struct lt_engine {
   ltmt::BlockJob* rng_jobs = nullptr;  // pinned, mapped: RNG_JOB_SLOTS launches of up to P jobs
   int rng_job_slot = 0;
   std::vector<long long> rng_ring_blk;  // the stream block each ring slot holds (-1: none)
-  DevBuf flag, rank, scan_tmp, vt_tab, vt_qS, vt_qS1, vt_qS2, vt_qwl, vt_qcount, vt_wl;
+  DevBuf flag, rank, scan_tmp, vt_tab, vt_qS, vt_qS1, vt_qS2, vt_qwl, vt_qcount, vt_wl, vt_dev;
   int vt_qcap = 0;
   size_t scan_tmp_bytes = 0;
   // counters
@@ -311,6 +311,7 @@ void fill_params(lt_engine* e, StepParams& P) {
   P.rank = (const int*)e->rank.p; P.orig = (const int*)e->orig.p;
   P.expect_own = -1;
   P.vt_tab = (double4*)e->vt_tab.p;
+  P.vt_dev = (double*)e->vt_dev.p;
   P.vt_q.S = (double*)e->vt_qS.p; P.vt_q.S1 = (double*)e->vt_qS1.p; P.vt_q.S2 = (double*)e->vt_qS2.p;
   P.vt_q.wl = (unsigned short*)e->vt_qwl.p; P.vt_q.count = (int*)e->vt_qcount.p; P.vt_q.cap = e->vt_qcap;
   P.vt_wl_count = (int*)e->vt_wl.p;
@@ -834,6 +835,7 @@ void launch_vturb_t(lt_engine* e, const StepParams& P, unsigned blocks) {
 #undef LT_LAUNCH_VT_TABLE
   hipLaunchKernelGGL(k_vt_sigs, dim3(blocks), dim3(256), 0, e->stream, P);
   wait_rng(e);
+  hipLaunchKernelGGL(k_vt_norm, dim3(blocks), dim3(256), 0, e->stream, P);
   // the walks on zero-tension intervals; then, for the ones that met a tension factor, the rest of the walk
   // (as many workgroups as could be needed: the ones beyond the list's end leave at once)
   hipLaunchKernelGGL(k_vt_walk_fast, dim3(blocks), dim3(256), 0, e->stream, P);
@@ -984,7 +986,7 @@ int lt_destroy(lt_engine* e) {
                     &e->pv, &e->P_behave, &e->dead, &e->oob, &e->settle, &e->endpoly,
                     &e->hitBottom, &e->hitLand, &e->err_code, &e->P_swim, &e->P_pediage,
                     &e->P_deadage, &e->settletime, &e->timer, &e->P_Sprev, &e->P_zprev, &e->bottom, &e->P_Salt, &e->P_Temp, &e->S, &e->T, &e->counters, &e->ws_d, &e->ws_i, &e->orig, &e->ele_ok, &e->block_active, &e->count_slots, &e->out_cols, &e->out_hits, &e->rng_states, &e->rng_ring, &e->rng_polys, &e->flag, &e->rank, &e->scan_tmp,
-                    &e->vt_tab, &e->vt_qS, &e->vt_qS1, &e->vt_qS2, &e->vt_qwl, &e->vt_qcount, &e->vt_wl, &e->sort_keys, &e->sort_keys_in, &e->tile_key, &e->sort_idx_in, &e->sort_idx_out,
+                    &e->vt_tab, &e->vt_qS, &e->vt_qS1, &e->vt_qS2, &e->vt_qwl, &e->vt_qcount, &e->vt_wl, &e->vt_dev, &e->sort_keys, &e->sort_keys_in, &e->tile_key, &e->sort_idx_in, &e->sort_idx_out,
                     &e->sort_tmp, &e->permute_tmp};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
@@ -1566,6 +1568,7 @@ int lt_set_particles(lt_engine* e, const lt_particles* p) {
       TRY(dev_alloc(e, e->vt_qS2, waves * e->vt_qcap * 8)); TRY(dev_alloc(e, e->vt_qwl, waves * e->vt_qcap * 2));
       TRY(dev_alloc(e, e->vt_qcount, waves * 4 + 4));
       TRY(dev_alloc(e, e->vt_wl, (2 * n + 4) * 4));
+      TRY(dev_alloc(e, e->vt_dev, waves * 64 * (size_t)std::max(e->cfg.idt / 2, 1) * 8));
     }
   }
   TRY(sync_perm(e));

@@ -529,6 +529,54 @@ __global__ __launch_bounds__(256) void k_vt_sigs(const StepParams P) {
   if (lane == 0 && rounds) atomicAdd(&P.counters[CNT_VT_ROUNDS], (unsigned long long)rounds);
 }
 
+struct __attribute__((packed, aligned(4))) RawWords4 { uint32_t a, b, c, d; };
+// ---- the normal deviates of the walk
+// norm() (norm_module.f90:25-39) of a sub-step is a function of the particle's two words of the stream alone, not
+// of where the walk has got to: the idt/2 deviates of every tracked particle are formed here, ahead of the walk and
+// out of its chain of dependent operations (a sub-step of the walk is a serial chain HPVAL -> HVAL -> displacement;
+// log, cos and sqrt -- the host-libm-exact forms, 240 of its 386 instructions -- sat in that chain although they
+// depend on nothing in it).  One lane per particle, a line of raw words (8 sub-steps) at a time as the walk took
+// them; the deviates go to vt_dev[group of 64 particles][sub-step][lane], so that a wave of the walk reads one
+// 512-byte row per sub-step.  Same functions, same operands, same product: the walk's sums are unchanged.
+__global__ __launch_bounds__(256) void k_vt_norm(const StepParams P) {
+  __shared__ uint2 rbuf[8][256];
+  libm_tables_load<LM_LOG | LM_SINCOS>();
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= P.numpar) return;
+  if (!(P.ws_i[n] & FL_ACT)) return;
+  const int loop = P.idt / 2;
+  unsigned long long di = P.rng_base + (unsigned long long)(unsigned)P.rank[P.orig[n]] +
+                          (P.HTurbOn ? 4ull : 0ull);
+  double* out = P.vt_dev + (size_t)(n >> 6) * (size_t)loop * 64 + (size_t)(n & 63);
+#pragma unroll 1
+  for (int i0 = 0; i0 < loop; i0 += 8) {
+    const unsigned long long o = di & P.rng_mask;
+    if (o + 16 <= P.rng_mask + 1ull) {
+      const RawWords4* src = (const RawWords4*)(P.rng_ring + o);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const RawWords4 w = src[j];
+        rbuf[2 * j][threadIdx.x] = make_uint2(w.a, w.b);
+        rbuf[2 * j + 1][threadIdx.x] = make_uint2(w.c, w.d);
+      }
+    } else {  // the window wraps around the end of the ring
+#pragma unroll 1
+      for (int j = 0; j < 8; j++)
+        rbuf[j][threadIdx.x] = make_uint2(P.rng_ring[(di + 2 * j) & P.rng_mask],
+                                          P.rng_ring[(di + 2 * j + 1) & P.rng_mask]);
+    }
+    di += 16;
+    const int m = (loop - i0 < 8) ? (loop - i0) : 8;
+#pragma unroll 2
+    for (int j = 0; j < m; j++) {
+      const uint2 rw = rbuf[j][threadIdx.x];
+      const double dev1 = ((double)ltmt_temper(rw.x) + 0.5) / 4294967296.0;
+      const double dev2 = ((double)ltmt_temper(rw.y) + 0.5) / 4294967296.0;
+      out[(size_t)(i0 + j) * 64] = sqrt(-2.0 * lt_log(dev1)) * lt_cos(2.0 * P.PI * dev2);
+    }
+  }
+}
+
 // ---- the walk, in two kernels
 // 80 % of the walks never leave the zero-tension intervals (~9 % of the intervals carry a tension factor and
 // a walk stays within a knot or two of its start), but a wave of 64 walks meets a tension factor at nearly
@@ -537,7 +585,6 @@ __global__ __launch_bounds__(256) void k_vt_sigs(const StepParams P) {
 // only: a walk that enters an interval with a tension factor (or whose table is not a proper spline: SigErr,
 // YPC1's failure) stops at the beginning of that sub-step and is listed; k_vt_walk takes the listed walks,
 // one lane each, from the sub-step they stopped at, with every form.  Same operations per walk either way.
-struct __attribute__((packed, aligned(4))) RawWords4 { uint32_t a, b, c, d; };
 struct VtLite {          // the cached interval without the tension-dependent parts
   int I;
   double X1, X2, Y1, Y2, P1, P2, SG, SGhi;
@@ -581,8 +628,7 @@ LT_DEV void vt_seek_lite(VtLite& c, double T, int n, const double4* tab) {
   }
 }
 __global__ __launch_bounds__(256) void k_vt_walk_fast(const StepParams P) {
-  __shared__ uint2 rbuf[8][256];
-  libm_tables_load<LM_EXP | LM_LOG | LM_POW | LM_SINCOS>();  // (pow takes the exp table too)
+  libm_tables_load<LM_EXP | LM_POW>();  // (pow takes the exp table too)
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= P.numpar) return;
   const int fl = P.ws_i[n];
@@ -596,8 +642,7 @@ __global__ __launch_bounds__(256) void k_vt_walk_fast(const StepParams P) {
   const double P_zetac = wsd[(size_t)WS_ZETA1 * N];
   const double background = (double)1.0E-6f, deltat = 2.0;
   const int loop = P.idt / (int)deltat;
-  unsigned long long di = P.rng_base + (unsigned long long)(unsigned)P.rank[P.orig[n]] +
-                          (P.HTurbOn ? 4ull : 0ull);
+  const double* dev = P.vt_dev + (size_t)(n >> 6) * (size_t)loop * 64 + (size_t)(n & 63);
   double ParZc = P_zc;
   VtLite ci;
   ci.I = 0; ci.X1 = ci.X2 = ci.Y1 = ci.Y2 = ci.P1 = ci.P2 = ci.SG = ci.SGhi = 0.0;
@@ -608,27 +653,7 @@ __global__ __launch_bounds__(256) void k_vt_walk_fast(const StepParams P) {
 #pragma unroll 1
   for (int i = 1; i <= loop; i++) {
     if (stopped) break;
-    const int sub = (i - 1) & 7;
-    if (sub == 0) {
-      const unsigned long long o = di & P.rng_mask;
-      if (o + 16 <= P.rng_mask + 1ull) {
-        const RawWords4* src = (const RawWords4*)(P.rng_ring + o);
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const RawWords4 w = src[j];
-          rbuf[2 * j][threadIdx.x] = make_uint2(w.a, w.b);
-          rbuf[2 * j + 1][threadIdx.x] = make_uint2(w.c, w.d);
-        }
-      } else {  // the window wraps around the end of the ring
-#pragma unroll 1
-        for (int j = 0; j < 8; j++)
-          rbuf[j][threadIdx.x] = make_uint2(P.rng_ring[(di + 2 * j) & P.rng_mask],
-                                            P.rng_ring[(di + 2 * j + 1) & P.rng_mask]);
-      }
-    }
-    const uint2 rw = rbuf[sub][threadIdx.x];
-    const uint32_t raw1 = rw.x, raw2 = rw.y;
-    di += 2;
+    const double DEV = dev[(size_t)(i - 1) * 64];   // norm() of this sub-step (k_vt_norm)
     double Kprimec = 0.0;
     bool tens = false;
     if (!(ParZc < P_depth || ParZc > P_zetac)) {
@@ -653,10 +678,6 @@ __global__ __launch_bounds__(256) void k_vt_walk_fast(const StepParams P) {
       stop_i = i;
       break;
     }
-    // norm(), norm_module.f90:25-39
-    const double dev1 = ((double)ltmt_temper(raw1) + 0.5) / 4294967296.0;
-    const double dev2 = ((double)ltmt_temper(raw2) + 0.5) / 4294967296.0;
-    const double DEV = sqrt(-2.0 * lt_log(dev1)) * lt_cos(2.0 * P.PI * dev2);
     // (2/r * KH3rd * deltat)**0.5 with r = 1
     ParZc = ParZc + KprimeZc + DEV * lt_pow_half(2.0 / 1.0 * KH3rdc * deltat);
   }
@@ -679,10 +700,9 @@ __global__ __launch_bounds__(256) void k_vt_walk_fast(const StepParams P) {
 
 // :282-335 random displacement model, idt/2 sub-steps of 2 s: the listed walks, every form of HVAL / HPVAL
 __global__ __launch_bounds__(256) void k_vt_walk(const StepParams P) {
-  __shared__ uint2 rbuf[8][256];
   const int nlisted = *P.vt_wl_count;
   if ((int)(blockIdx.x * blockDim.x) >= nlisted) return;   // (the whole workgroup: launched for the worst case)
-  libm_tables_load<LM_EXP | LM_LOG | LM_POW | LM_SINCOS>();
+  libm_tables_load<LM_EXP | LM_POW>();
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nlisted) return;
   const int n = P.vt_wl_list[t];
@@ -699,9 +719,7 @@ __global__ __launch_bounds__(256) void k_vt_walk(const StepParams P) {
   // :282-335 random displacement model, idt/2 sub-steps of 2 s
   const double background = (double)1.0E-6f, deltat = 2.0;
   const int loop = P.idt / (int)deltat;
-  // this particle's window of the serial stream: HTurb's 4 draws come first (:1087,1098); two words per sub-step
-  const unsigned long long di0 = P.rng_base + (unsigned long long)(unsigned)P.rank[P.orig[n]] +
-                                 (P.HTurbOn ? 4ull : 0ull);
+  const double* dev = P.vt_dev + (size_t)(n >> 6) * (size_t)loop * 64 + (size_t)(n & 63);   // norm() per sub-step
   double ParZc = wsd[(size_t)WS_TURBV * N];   // left there by k_vt_walk_fast
   int il = 1;
   VtInterval ci;
@@ -710,30 +728,7 @@ __global__ __launch_bounds__(256) void k_vt_walk(const StepParams P) {
   const bool cached = (sigerr == 0) && !ypc_fail;
 #pragma unroll 1
   for (int i = i0; i <= loop; i++) {
-    // The particle's raw words are consecutive in the ring: 16 of them (8 sub-steps,
-    // one 64-B line) are fetched at a time with four 16-byte loads and parked in this
-    // thread's LDS column; word-by-word loads re-fetched the line for every sub-step.
-    const int sub = (i - 1) & 7;
-    if (sub == 0 || i == i0) {
-      const unsigned long long di = di0 + 2ull * (unsigned long long)((i - 1) & ~7);   // the group of 8 sub-steps i is in
-      const unsigned long long o = di & P.rng_mask;
-      if (o + 16 <= P.rng_mask + 1ull) {
-        const RawWords4* src = (const RawWords4*)(P.rng_ring + o);
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const RawWords4 w = src[j];
-          rbuf[2 * j][threadIdx.x] = make_uint2(w.a, w.b);
-          rbuf[2 * j + 1][threadIdx.x] = make_uint2(w.c, w.d);
-        }
-      } else {  // the window wraps around the end of the ring
-#pragma unroll 1
-        for (int j = 0; j < 8; j++)
-          rbuf[j][threadIdx.x] = make_uint2(P.rng_ring[(di + 2 * j) & P.rng_mask],
-                                            P.rng_ring[(di + 2 * j + 1) & P.rng_mask]);
-      }
-    }
-    const uint2 rw = rbuf[sub][threadIdx.x];
-    const uint32_t raw1 = rw.x, raw2 = rw.y;
+    const double DEV = dev[(size_t)(i - 1) * 64];
     double Kprimec = 0.0;
     if (!(ParZc < P_depth || ParZc > P_zetac)) {
       if (cached) {
@@ -757,10 +752,6 @@ __global__ __launch_bounds__(256) void k_vt_walk(const StepParams P) {
       } else { double mm; linint_n(&tab[0].x, &tab[0].y, p2, 4 * VT_TS, Z3rdc, KH3rdc, mm); }
       if (KH3rdc < background) KH3rdc = background;
     }
-    // norm(), norm_module.f90:25-39
-    const double dev1 = ((double)ltmt_temper(raw1) + 0.5) / 4294967296.0;
-    const double dev2 = ((double)ltmt_temper(raw2) + 0.5) / 4294967296.0;
-    const double DEV = sqrt(-2.0 * lt_log(dev1)) * lt_cos(2.0 * P.PI * dev2);
     // (2/r * KH3rd * deltat)**0.5 with r = 1
     ParZc = ParZc + KprimeZc + DEV * lt_pow_half(2.0 / 1.0 * KH3rdc * deltat);
   }

@@ -68,7 +68,7 @@ def test_single_gpu_line_carries_config3_and_hash():
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 1 and d["config"]["baseline_config"] == "config2"
     t = d["config"]["turbulence"]
-    assert t["value"] > 0 and t["roofline"]["kernel"] == "k_vt_table+k_vt_sigs+k_vt_walk_fast+k_vt_walk"
+    assert t["value"] > 0 and t["roofline"]["kernel"] == "k_vt_table+k_vt_sigs+k_vt_norm+k_vt_walk_fast+k_vt_walk"
     # bytes and time of a figure cover the same kernels: the VTurb group against A_turb - A_adv, the step against A_turb
     assert t["roofline"]["algorithmic_bytes_per_particle_step"] == 48 * 21 + 992
     assert t["roofline"]["whole_step"]["algorithmic_bytes_per_particle_step"] == 976 + 48 * 21 + 992
