@@ -28,6 +28,7 @@ enum Counter : int {
   CNT_PIP_SLOW = 4,   // point-in-polygon queries that used the full algorithm
   CNT_VT_QUEUED = 5,  // VTurb spline intervals whose tension factor needed the batched SIGS iteration
   CNT_VT_ROUNDS = 6,  // rounds (of up to 64 intervals) of that iteration, summed over the waves
+  CNT_SLOW = 7,       // particle-steps k_rk listed for k_rk_slow (the list's length)
   CNT_COUNT = 8,
   // (not a per-step counter -- k_pre does not clear it: steps whose draw total differed from the one the host
   // assumed under a static stream window, lt_set_rng_window_static)
@@ -163,6 +164,7 @@ struct StepParams {
   // ---- counters
   unsigned long long* counters;
   unsigned int* block_active;  // [blocks] tracked particles per k_pre block
+  int* slow_list;              // [numpar] the particle slots k_rk hands to k_rk_slow (counters[CNT_SLOW] of them)
 };
 
 }  // namespace ltd

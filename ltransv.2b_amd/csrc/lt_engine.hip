@@ -129,7 +129,7 @@ struct lt_engine {
   ltmt::BlockJob* rng_jobs = nullptr;  // pinned, mapped: RNG_JOB_SLOTS launches of up to P jobs
   int rng_job_slot = 0;
   std::vector<long long> rng_ring_blk;  // the stream block each ring slot holds (-1: none)
-  DevBuf flag, rank, scan_tmp, vt_tab, vt_qS, vt_qS1, vt_qS2, vt_qwl, vt_qcount, vt_wl, vt_dev;
+  DevBuf flag, rank, scan_tmp, vt_tab, vt_qS, vt_qS1, vt_qS2, vt_qwl, vt_qcount, vt_wl, vt_dev, slow_list;
   int vt_qcap = 0;
   size_t scan_tmp_bytes = 0;
   // counters
@@ -312,6 +312,7 @@ void fill_params(lt_engine* e, StepParams& P) {
   P.expect_own = -1;
   P.vt_tab = (double4*)e->vt_tab.p;
   P.vt_dev = (double*)e->vt_dev.p;
+  P.slow_list = (int*)e->slow_list.p;
   P.vt_q.S = (double*)e->vt_qS.p; P.vt_q.S1 = (double*)e->vt_qS1.p; P.vt_q.S2 = (double*)e->vt_qS2.p;
   P.vt_q.wl = (unsigned short*)e->vt_qwl.p; P.vt_q.count = (int*)e->vt_qcount.p; P.vt_q.cap = e->vt_qcap;
   P.vt_wl_count = (int*)e->vt_wl.p;
@@ -986,7 +987,7 @@ int lt_destroy(lt_engine* e) {
                     &e->pv, &e->P_behave, &e->dead, &e->oob, &e->settle, &e->endpoly,
                     &e->hitBottom, &e->hitLand, &e->err_code, &e->P_swim, &e->P_pediage,
                     &e->P_deadage, &e->settletime, &e->timer, &e->P_Sprev, &e->P_zprev, &e->bottom, &e->P_Salt, &e->P_Temp, &e->S, &e->T, &e->counters, &e->ws_d, &e->ws_i, &e->orig, &e->ele_ok, &e->block_active, &e->count_slots, &e->out_cols, &e->out_hits, &e->rng_states, &e->rng_ring, &e->rng_polys, &e->flag, &e->rank, &e->scan_tmp,
-                    &e->vt_tab, &e->vt_qS, &e->vt_qS1, &e->vt_qS2, &e->vt_qwl, &e->vt_qcount, &e->vt_wl, &e->vt_dev, &e->sort_keys, &e->sort_keys_in, &e->tile_key, &e->sort_idx_in, &e->sort_idx_out,
+                    &e->vt_tab, &e->vt_qS, &e->vt_qS1, &e->vt_qS2, &e->vt_qwl, &e->vt_qcount, &e->vt_wl, &e->vt_dev, &e->slow_list, &e->sort_keys, &e->sort_keys_in, &e->tile_key, &e->sort_idx_in, &e->sort_idx_out,
                     &e->sort_tmp, &e->permute_tmp};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
@@ -1554,6 +1555,7 @@ int lt_set_particles(lt_engine* e, const lt_particles* p) {
     TRY(upload(e, e->orig, e->perm.data(), n * 4));
     TRY(dev_alloc(e, e->ws_d, (size_t)WS_NDOUBLE * n * 8));
     TRY(dev_alloc(e, e->ws_i, n * 4));
+    TRY(dev_alloc(e, e->slow_list, (size_t)n * 4));
     if (e->cfg.HTurbOn || e->cfg.VTurbOn || (e->cfg.Behavior >= 1 && e->cfg.Behavior <= 5)) {
       TRY(dev_alloc(e, e->flag, (n + 1) * 4));
       TRY(dev_alloc(e, e->rank, (n + 1) * 4));
@@ -2428,8 +2430,9 @@ int lt_step(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32
       HIPCHK(e, hipEventRecord(e->prof_ev[e->prof_used + 1], e->stream));
       e->prof_used += 2;
     }
-    if (f32) hipLaunchKernelGGL((k_rk_slow<float>), dim3(blocks), dim3(256), 0, e->stream, P);
-    else hipLaunchKernelGGL((k_rk_slow<double>), dim3(blocks), dim3(256), 0, e->stream, P);
+    const unsigned slow_blocks = blocks < 256u ? blocks : 256u;
+    if (f32) hipLaunchKernelGGL((k_rk_slow<float>), dim3(slow_blocks), dim3(256), 0, e->stream, P);
+    else hipLaunchKernelGGL((k_rk_slow<double>), dim3(slow_blocks), dim3(256), 0, e->stream, P);
     TRY(phase_mark(e, 2));
     if (prof_vt) HIPCHK(e, hipEventRecord(e->prof_ev[e->prof_used], e->stream));
     if (e->cfg.VTurbOn) launch_vturb(e, P, blocks);

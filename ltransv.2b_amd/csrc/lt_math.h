@@ -766,7 +766,13 @@ LT_DEV void sigs_newton_k(const double (&T)[K], const bool (&need)[K], double (&
       const double FP = T1 + s * (div_prep(small ? s : N2, ds) - T1 * T1 + 1.0);
       const double F = s * T1 - TP1[j];
       const bool capped = NIT > 10000;
+#ifdef LT_NEWTON_TRUE_DIV
       const double DSIG = -F / FP;
+#else
+      // (FP is of order one where the step is used -- FP <= 0 stops the iteration -- and F is a rounded
+      // difference of such numbers or zero: the prepared-divisor quotient is the value of -F / FP, lt_math.h above)
+      const double DSIG = div_prep(-F, prep_div(FP));
+#endif
       const bool stop = (FP <= 0.0) | (fabs(DSIG) <= RTOL * s) | ((F >= 0.0) & (F <= FTOL)) | (fabs(F) <= RTOL);
       const bool adv = live[j] & !capped & !stop;
       const double nx = s + DSIG;

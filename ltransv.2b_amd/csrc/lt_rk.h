@@ -276,6 +276,7 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
   int nchk = 0, nev = 0;  // wave-uniform task counts of this stage
   double zt = 0.0, pz = 0.0;
   SlabT raw[16];
+  LevCoef lc[4];   // (kept from the U fit to the V fit: the same four rho levels)
 #pragma unroll 1
   for (int var = 0; var < 3; var++) {
     const int4 nd = nd_next;
@@ -331,9 +332,13 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
     { const unsigned long long m3 = __ballot(spl && w.regime >= 3); if (lane == 0) ws.tim[7] += __popcll(m3) + ((m3 != 0) ? (1ull << 32) : 0ull); }
 #endif
     TICK(1);
-    LevCoef lc[4];
+#ifndef LT_RK_NO_LC_SHARE
+    if (var != 1)
+#endif
+    {
 #pragma unroll
-    for (int l = 0; l < 4; l++) lc[l] = level_coef_d(tab, k0 + l, h, P.hc, VT, dv);
+      for (int l = 0; l < 4; l++) lc[l] = level_coef_d(tab, k0 + l, h, P.hc, VT, dv);
+    }
 #pragma unroll 1
     for (int s = 0; s < 3; s++) {
       const int slot9 = var * 3 + s;
@@ -903,7 +908,17 @@ void k_rk(const StepParams P) {
     wso[(size_t)WS_SUMU * N] = sumU;
     wso[(size_t)WS_SUMV * N] = sumV;
     wso[(size_t)WS_SUMW * N] = sumW;
-    if (slow) P.ws_i[n] |= FL_SLOW;
+  }
+  {  // the particle-steps k_rk_slow redoes: listed (one atomic per wave that has any), so that the kernel behind
+     // this one is a few workgroups over the list instead of a pass over every particle's flag word
+    const unsigned long long ms = __ballot(act && slow);
+    if (ms) {
+      const int lane = threadIdx.x & 63, leader = __ffsll((long long)ms) - 1;
+      unsigned long long base = 0;
+      if (lane == leader) base = atomicAdd(&P.counters[CNT_SLOW], (unsigned long long)__popcll(ms));
+      base = __shfl(base, leader, 64);
+      if (act && slow) P.slow_list[base + __popcll(ms & ((1ull << lane) - 1ull))] = n;
+    }
   }
   unsigned v = (unsigned)sigerr_count;
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -982,14 +997,16 @@ LT_DEV void find_currents_ref(const StepParams& P, const double* lev, const Colu
 template <typename SlabT>
 __global__ __launch_bounds__(256) void k_rk_slow(const StepParams P) {
   __shared__ double lev[6 * LT_LEV_STRIDE];
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  // almost every block has nothing to redo: decide that before staging the tables
-  const bool mine = (n < P.numpar) && ((P.ws_i[n] & FL_SLOW) != 0);
-  if (!__syncthreads_or(mine ? 1 : 0)) return;
+  // k_rk's list of the particle-steps to redo; a fixed, small grid strides over it (usually a few hundred
+  // entries or none: the workgroups beyond the list leave before staging the tables)
+  const long long nslow = (long long)P.counters[CNT_SLOW];
+  if ((long long)blockIdx.x * blockDim.x >= nslow) return;
   for (int i = threadIdx.x; i < 6 * LT_LEV_STRIDE; i += blockDim.x) lev[i] = P.lev[i];
   exp_table_load();
-  if (!mine) return;
   const size_t N = (size_t)P.numpar;
+#pragma unroll 1
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < nslow; t += (long long)gridDim.x * blockDim.x) {
+  const int n = P.slow_list[t];
   double* wsd = P.ws_d + n;
   const double X = P.par[(size_t)pX * N + n], Y = P.par[(size_t)pY * N + n];
   const double Zpar = wsd[(size_t)WS_ZPAR * N];
@@ -1047,4 +1064,5 @@ __global__ __launch_bounds__(256) void k_rk_slow(const StepParams P) {
   wsd[(size_t)WS_SUMU * N] = sumU;
   wsd[(size_t)WS_SUMV * N] = sumV;
   wsd[(size_t)WS_SUMW * N] = sumW;
+  }
 }
