@@ -10,11 +10,14 @@ particles a rank holds: one internal time step of LTRANS.
           advection only (the configuration the metric is quoted on).  The same line carries,
           under config.turbulence, configs[2] (the same + HTurb + VTurb with the device
           MT19937 stream) timed for the same number of steps.
-  N > 1   BASELINE.json configs[3]: 10M particles in total on a 1024x512x50 grid, RK4 + HTurb
-          + VTurb, sharded by contiguous index block over the N ranks (fields replicated,
-          SURVEY.md section 8e): STRONG scaling.  After every step the ranks all-gather the
-          new (x,y,z) over RCCL.  --weak keeps --numpar particles per rank instead;
-          --workload picks any configuration explicitly.
+  N > 1   the same configuration PER GPU (1M particles each, fields replicated, particles sharded
+          by contiguous index block): WEAK scaling, so that the per-N
+          values form one series with the N = 1 line.  After every step the ranks all-gather the
+          new (x,y,z) over RCCL, on a stream of its own beside the next step.  The same line
+          carries, under config.configs3_strong, BASELINE.json configs[3] -- 10M particles in
+          total on a 1024x512x50 grid, RK4 + HTurb + VTurb, STRONG-scaled over the same ranks --
+          with rank 0's run of all its particles on one GPU (the one-GPU point of that workload).
+          --workload picks one configuration explicitly (strong scaling unless --weak).
 
 When started without a launcher (`python bench.py --gpus N`, N > 1) this process only starts
 N children (one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), relays rank 0's
@@ -61,8 +64,13 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=["auto"] + sorted(WORKLOADS), default="auto",
-                    help="auto = config2 on one GPU, config4 (10M particles in total, strong scaling) on several")
-    ap.add_argument("--weak", action="store_true", help="N > 1: --numpar particles PER RANK on --grid (weak scaling)")
+                    help="auto = config2 (the configuration the metric is quoted on) per GPU: on several GPUs weak scaling, "
+                         "with configs[3] strong-scaled timed beside it (config.configs3_strong)")
+    ap.add_argument("--weak", action="store_true", help="N > 1, explicit --workload: --numpar particles PER RANK (weak scaling)")
+    ap.add_argument("--no-configs3-line", action="store_true",
+                    help="N > 1, --workload auto: skip the embedded configs[3] (10M particles, 1024x512x50, strong scaling) measurement")
+    ap.add_argument("--configs3-grid", type=str, default=None, help="grid of the embedded configs[3] line (rehearsals)")
+    ap.add_argument("--configs3-numpar", type=int, default=None, help="total particles of the embedded configs[3] line")
     ap.add_argument("--numpar", type=int, default=None, help="particles (per GPU with --weak, else in total)")
     ap.add_argument("--grid", type=str, default=None)
     ap.add_argument("--slab", choices=["f32", "f64"], default="f32")
@@ -408,23 +416,29 @@ def cpu_baseline(ltrans_amd, args, spec, g, geo, bounds, records):
                       f"{spec['grid']} grid, {dt:.1f} s wall, {os.cpu_count()} host cores present"}
 
 
-def resolve_workload(args, world):
-    name = args.workload
+def resolve_workload(args, world, name=None):
+    """--workload auto: the configuration the metric is quoted on (configs[1]; configs[2] with --turb) PER GPU, i.e.
+    weak scaling over the ranks.  An explicit --workload is taken whole (strong scaling unless --weak).
+    name="config4": the embedded configs[3] line of an auto run (its own --configs3-grid / --configs3-numpar)."""
+    embedded = name is not None
+    auto = not embedded and args.workload == "auto"
+    if name is None:
+        name = args.workload
     if name == "auto":
-        name = "config3" if (args.turb and world == 1) else ("config2" if world == 1 else "config4")
+        name = "config3" if args.turb else "config2"
     grid, total, turb, reflect = WORKLOADS[name]
-    if args.turb:
+    if args.turb and not embedded:
         turb = True
-    grid = args.grid or grid
+    grid = (args.configs3_grid if embedded else args.grid) or grid
     vi, uj, us = (int(v) for v in grid.split("x"))
-    behavior = args.behavior if args.behavior is not None else (6 if reflect else 0)
-    settle = bool(args.settle or reflect)
-    weak = bool(args.weak and world > 1)
+    behavior = args.behavior if (args.behavior is not None and not embedded) else (6 if reflect else 0)
+    settle = bool((args.settle and not embedded) or reflect)
+    weak = bool(world > 1 and not embedded and (args.weak or auto))
     if weak:
         per_rank = args.numpar or 1_000_000
         total = per_rank * world
     else:
-        total = args.numpar or total
+        total = (args.configs3_numpar if embedded else args.numpar) or total
     return dict(name=name, grid=grid, vi=vi, uj=uj, us=us, turb=turb, reflect=reflect, behavior=behavior,
                 settle=settle, total=total, weak=weak)
 
@@ -484,290 +498,314 @@ def main():
     dev = torch.device("cuda", dev_index)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
-    spec = resolve_workload(args, world)
-    vi, uj, us = spec["vi"], spec["uj"], spec["us"]
-    # (--emulate-rank: the shard and the stream window of rank R of W, computed by this one process)
-    em_rank, em_world = (int(x) for x in args.emulate_rank.split(":")) if args.emulate_rank else (rank, world)
-    if args.emulate_rank and (world != 1 or not 0 <= em_rank < em_world):
-        sys.stderr.write("bench.py: --emulate-rank R:W needs --gpus 1 and 0 <= R < W\n")
-        return 2
-    lo, hi = sharding.shard_range(spec["total"], em_world, em_rank)
-    n = hi - lo
-    g, geo, bounds = build_world(vi, uj, us, spec["reflect"])
-    drift = (-0.2, -0.15) if spec["reflect"] else (0.0, 0.0)
-    # every rank's shard is its own draw (seed + rank): the shards of a strong-scaling run are the
-    # blocks of the global particle list that rank 0 re-assembles for the single-GPU reference
-    parts = make_parts(g, geo, bounds, n, 12345 + em_rank, spec["reflect"])
-    rec_cache = {}
-    needs_st = spec["behavior"] not in (0, 6)     # salinity / temperature only for the behaviours that read them
+    def measure(spec, main_line):
+        """One workload on all ranks -> (rc, the JSON object of the line as rank 0 sees it).  main_line: with the
+        one-GPU extras (configs[2] timed beside, updateHydro / print-step / init-geometry costs, the CPU baseline)."""
+        t_begin = time.perf_counter()
+        vi, uj, us = spec["vi"], spec["uj"], spec["us"]
+        # (--emulate-rank: the shard and the stream window of rank R of W, computed by this one process)
+        em_rank, em_world = (int(x) for x in args.emulate_rank.split(":")) if args.emulate_rank else (rank, world)
+        if args.emulate_rank and (world != 1 or not 0 <= em_rank < em_world):
+            sys.stderr.write("bench.py: --emulate-rank R:W needs --gpus 1 and 0 <= R < W\n")
+            return 2, None
+        lo, hi = sharding.shard_range(spec["total"], em_world, em_rank)
+        n = hi - lo
+        g, geo, bounds = build_world(vi, uj, us, spec["reflect"])
+        drift = (-0.2, -0.15) if spec["reflect"] else (0.0, 0.0)
+        # every rank's shard is its own draw (seed + rank): the shards of a strong-scaling run are the
+        # blocks of the global particle list that rank 0 re-assembles for the single-GPU reference
+        parts = make_parts(g, geo, bounds, n, 12345 + em_rank, spec["reflect"])
+        rec_cache = {}
+        needs_st = spec["behavior"] not in (0, 6)     # salinity / temperature only for the behaviours that read them
 
-    def records(r, with_kh=None):
-        k = (r, bool(spec["turb"] if with_kh is None else with_kh))
-        if k not in rec_cache:
-            rec_cache[k] = rs.make_record(g, geo, r, with_kh=k[1], drift=drift, with_st=needs_st)
-        return rec_cache[k]
+        def records(r, with_kh=None):
+            k = (r, bool(spec["turb"] if with_kh is None else with_kh))
+            if k not in rec_cache:
+                rec_cache[k] = rs.make_record(g, geo, r, with_kh=k[1], drift=drift, with_st=needs_st)
+            return rec_cache[k]
 
-    def config_for(numpar, turb):
-        t = 1 if turb else 0
-        return ltrans_amd.LtConfig(numpar=numpar, us=us, ws=us + 1, dt=3600, idt=120, ErrorFlag=1, device=dev.index,
-                                   HTurbOn=t, VTurbOn=t, ConstantHTurb=1.0, **behaviour_cfg(spec["behavior"], spec["settle"]),
-                                   slab_storage=(ltrans_amd.abi.LT_SLAB_F32 if args.slab == "f32"
-                                                 else ltrans_amd.abi.LT_SLAB_F64))
+        def config_for(numpar, turb):
+            t = 1 if turb else 0
+            return ltrans_amd.LtConfig(numpar=numpar, us=us, ws=us + 1, dt=3600, idt=120, ErrorFlag=1, device=dev.index,
+                                       HTurbOn=t, VTurbOn=t, ConstantHTurb=1.0, **behaviour_cfg(spec["behavior"], spec["settle"]),
+                                       slab_storage=(ltrans_amd.abi.LT_SLAB_F32 if args.slab == "f32"
+                                                     else ltrans_amd.abi.LT_SLAB_F64))
 
-    cfg = config_for(n, spec["turb"])
-    e, run = make_engine(ltrans_amd, cfg, g, geo, bounds, parts, records)
-    st = Stepper(e, run, cfg)
-    lib_hash = e.source_hash()
+        cfg = config_for(n, spec["turb"])
+        e, run = make_engine(ltrans_amd, cfg, g, geo, bounds, parts, records)
+        st = Stepper(e, run, cfg)
+        lib_hash = e.source_hash()
 
-    # N > 1: the end-of-step all-gather of (x,y,z) runs on its own stream and overlaps the next
-    # step's kernels.  It is ordered behind the step on the DEVICE (an event on the engine's stream;
-    # no host synchronisation per step); the packed positions are double-buffered and the engine's
-    # stream waits for the all-gather that last read a buffer before packing into it again.
-    nmax = max(sharding.shard_sizes(spec["total"], world)) if world > 1 else n
-    send = recv = gather_stream = eng_stream = None
-    send_done = [None, None]
-    nstep = [0]
-    if world > 1:
-        send = [torch.zeros(3 * nmax, dtype=torch.float64, device=dev) for _ in range(2)]
-        recv = torch.empty(3 * nmax * world, dtype=torch.float64, device=dev)
-        gather_stream = torch.cuda.Stream(device=dev)
-        eng_stream = torch.cuda.ExternalStream(e.stream(), device=dev)
-
-    draws = spec["turb"] or 1 <= spec["behavior"] <= 5
-    # A shard's window of the single serial random stream is static while no particle can stop drawing:
-    # nothing is unreleased (DOB <= 0), settles, dies or leaves through an open boundary.  Otherwise the
-    # ranks exchange their counts before every step (one all-gather of one int64 each, one host read).
-    # The choice is the JOB's, not the rank's (a rank that exchanged counts while another did not would wait for
-    # ever): the minimum over the ranks of the local predicate.  The engine checks it on the device in every step
-    # (lt_set_rng_window_static: a step whose draw total differs makes e.counters() fail below).
-    static_window = (draws and not (1 <= spec["behavior"] <= 5) and not spec["settle"]
-                     and float(parts["par"][:, 10].max()) <= 0.0)
-    if world > 1:
-        sw = torch.tensor([1 if static_window else 0], dtype=torch.int64, device=coll_dev)
-        dist.all_reduce(sw, op=dist.ReduceOp.MIN)
-        static_window = bool(int(sw.item()))
-    if static_window:
-        # (one engine alone: its window is the whole stream -- set once, no step waits for the device)
-        sizes = sharding.shard_sizes(spec["total"], em_world)
-        e.set_rng_window(int(sum(sizes[:em_rank])), int(sum(sizes)), persistent=True)
-    elif em_world > world and draws:
-        sys.stderr.write("bench.py: --emulate-rank needs a workload with a static stream window\n")
-        return 2
-
-    def one_step():
-        ix = st.next_times()
-        if world > 1 and draws and not static_window:
-            if 1 <= spec["behavior"] <= 5:   # data-dependent number of deviates: count draws
-                mine = e.count_draws(st.ex, ix, st.p, st.it)
-                before, total = sharding.rng_window(dist, torch, mine, world, rank, device=coll_dev)
-                e.set_rng_window_draws(before, total)
-            else:
-                before, total = sharding.rng_window(dist, torch, e.count_active(ix), world, rank, device=coll_dev)
-                e.set_rng_window(before, total)
-        e.update_particles(st.ex, ix, st.p, st.it)
+        # N > 1: the end-of-step all-gather of (x,y,z) runs on its own stream and overlaps the next
+        # step's kernels.  It is ordered behind the step on the DEVICE (an event on the engine's stream;
+        # no host synchronisation per step); the packed positions are double-buffered and the engine's
+        # stream waits for the all-gather that last read a buffer before packing into it again.
+        nmax = max(sharding.shard_sizes(spec["total"], world)) if world > 1 else n
+        send = recv = gather_stream = eng_stream = None
+        send_done = [None, None]
+        nstep = [0]
         if world > 1:
-            b = nstep[0] & 1
-            nstep[0] += 1
-            if send_done[b] is not None:
-                eng_stream.wait_event(send_done[b])   # the all-gather that last read this buffer
-            e.pack_positions(send[b].data_ptr())
-            packed = torch.cuda.Event()
-            packed.record(eng_stream)
-            gather_stream.wait_event(packed)
-            with torch.cuda.stream(gather_stream):
-                if backend == "nccl":
-                    dist.all_gather_into_tensor(recv, send[b])
-                else:                                   # rehearsal: the same ordering, the collective through host memory
-                    parts_ = [torch.empty(3 * nmax, dtype=torch.float64) for _ in range(world)]
-                    dist.all_gather(parts_, send[b].cpu())      # (.cpu() on the gather stream: behind `packed`)
-                    recv.copy_(torch.cat(parts_), non_blocking=True)
-                send_done[b] = torch.cuda.Event()
-                send_done[b].record(gather_stream)
+            send = [torch.zeros(3 * nmax, dtype=torch.float64, device=dev) for _ in range(2)]
+            recv = torch.empty(3 * nmax * world, dtype=torch.float64, device=dev)
+            gather_stream = torch.cuda.Stream(device=dev)
+            eng_stream = torch.cuda.ExternalStream(e.stream(), device=dev)
 
-    def fence():
-        e.sync()
-        torch.cuda.synchronize()
+        draws = spec["turb"] or 1 <= spec["behavior"] <= 5
+        # A shard's window of the single serial random stream is static while no particle can stop drawing:
+        # nothing is unreleased (DOB <= 0), settles, dies or leaves through an open boundary.  Otherwise the
+        # ranks exchange their counts before every step (one all-gather of one int64 each, one host read).
+        # The choice is the JOB's, not the rank's (a rank that exchanged counts while another did not would wait for
+        # ever): the minimum over the ranks of the local predicate.  The engine checks it on the device in every step
+        # (lt_set_rng_window_static: a step whose draw total differs makes e.counters() fail below).
+        static_window = (draws and not (1 <= spec["behavior"] <= 5) and not spec["settle"]
+                         and float(parts["par"][:, 10].max()) <= 0.0)
         if world > 1:
-            dist.barrier()
+            sw = torch.tensor([1 if static_window else 0], dtype=torch.int64, device=coll_dev)
+            dist.all_reduce(sw, op=dist.ReduceOp.MIN)
+            static_window = bool(int(sw.item()))
+        if static_window:
+            # (one engine alone: its window is the whole stream -- set once, no step waits for the device)
+            sizes = sharding.shard_sizes(spec["total"], em_world)
+            e.set_rng_window(int(sum(sizes[:em_rank])), int(sum(sizes)), persistent=True)
+        elif em_world > world and draws:
+            sys.stderr.write("bench.py: --emulate-rank needs a workload with a static stream window\n")
+            return 2, None
+
+        def one_step():
+            ix = st.next_times()
+            if world > 1 and draws and not static_window:
+                if 1 <= spec["behavior"] <= 5:   # data-dependent number of deviates: count draws
+                    mine = e.count_draws(st.ex, ix, st.p, st.it)
+                    before, total = sharding.rng_window(dist, torch, mine, world, rank, device=coll_dev)
+                    e.set_rng_window_draws(before, total)
+                else:
+                    before, total = sharding.rng_window(dist, torch, e.count_active(ix), world, rank, device=coll_dev)
+                    e.set_rng_window(before, total)
+            e.update_particles(st.ex, ix, st.p, st.it)
+            if world > 1:
+                b = nstep[0] & 1
+                nstep[0] += 1
+                if send_done[b] is not None:
+                    eng_stream.wait_event(send_done[b])   # the all-gather that last read this buffer
+                e.pack_positions(send[b].data_ptr())
+                packed = torch.cuda.Event()
+                packed.record(eng_stream)
+                gather_stream.wait_event(packed)
+                with torch.cuda.stream(gather_stream):
+                    if backend == "nccl":
+                        dist.all_gather_into_tensor(recv, send[b])
+                    else:                                   # rehearsal: the same ordering, the collective through host memory
+                        parts_ = [torch.empty(3 * nmax, dtype=torch.float64) for _ in range(world)]
+                        dist.all_gather(parts_, send[b].cpu())      # (.cpu() on the gather stream: behind `packed`)
+                        recv.copy_(torch.cat(parts_), non_blocking=True)
+                    send_done[b] = torch.cuda.Event()
+                    send_done[b].record(gather_stream)
+
+        def fence():
+            e.sync()
             torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+                torch.cuda.synchronize()
 
-    setup_s = time.perf_counter() - t_start
-    for _ in range(args.warmup):
-        if st.needs_rotation():
-            st.rotate()
-        one_step()
-    fence()
-    resorts0 = e.counters()["resorts"]
-    e.profile_begin(args.steps)
-    wall, upload_s = timed_steps(st, args.steps, one_step, fence)
-    k_ms, k_n = e.profile_end()
-    stats = e.counters()      # (fails if a static stream window did not hold)
-    if static_window and stats["active"] != n:
-        sys.stderr.write(f"bench.py: static stream window, but {stats['active']} of {n} particles were tracked\n")
-        return 3
-
-    wall_t = torch.tensor([wall], dtype=torch.float64, device=coll_dev)
-    if world > 1:
-        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
-    wall = float(wall_t.item())
-
-    # (an emulated rank reports its own shard's particle-steps: one GPU's share of the job)
-    total_particle_steps = float(n if args.emulate_rank else spec["total"]) * args.steps
-    value = total_particle_steps / wall
-    k_avg_s = (k_ms / max(k_n, 1)) * 1e-3
-    kernels = VT_KERNELS if spec["turb"] else ["k_rk"]
-    default_shape = (n == 1_000_000 and spec["grid"] == "512x256x30" and args.slab == "f32" and not spec["reflect"])
-    traffic = traffic_src = valu = None
-    if default_shape:
-        traffic, traffic_src, valu = pmc_traffic(PROFILE_TURB if spec["turb"] else PROFILE_ADV, kernels, lib_hash)
-
-    out = {
-        "metric": "particle-steps/s", "value": value, "unit": "particle-steps/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak" if (spec["weak"] or world == 1) else "strong",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": workload_text(spec, world, n, backend) + (f"; THIS LINE: rank {em_rank} of {em_world} emulated by one "
-                   "process (its shard, its window of the random stream, no all-gather)" if args.emulate_rank else ""),
-                   "baseline_config": spec["name"],
-                   "particles_total": spec["total"], "particles_this_rank": n, "grid": spec["grid"],
-                   "slab_storage": args.slab, "kernel_source_hash": lib_hash,
-                   "active_last_step": stats["active"], "errors_last_step": stats["errors"],
-                   "sigerr_last_step": stats["sigerr"], "slab_rotation_s_excluded": upload_s,
-                   # the device-side re-sort of the particle order (every `resort_every` = 32 steps inside lt_step):
-                   # how many fell into the timed region -- they are part of `value` -- and what one costs
-                   "resorts_in_timed_region": stats["resorts"] - resorts0, "resort_every_steps": 32,
-                   "resort_ms_each": stats["last_resort_ms"] if stats["resorts"] else None,
-                   "rng_window": (("static (validated on the device every step)" if static_window
-                                   else "exchanged per step") if draws else None),
-                   "collective_backend": (backend if world > 1 else None), "device_index": dev_index,
-                   "setup_s": setup_s},
-        "roofline": roofline_block(args.slab, spec["turb"], us + 1, n, k_avg_s, wall / args.steps, traffic, traffic_src,
-                                   valu),
-    }
-
-    if world == 1 and spec["name"] == "config2" and not args.no_turbulence_line:
-        # BASELINE configs[2] in the same line: the same particles with HTurb + VTurb, same number of steps
-        cfg_t = config_for(n, True)
-        t_create = time.perf_counter()
-        e_t, run_t = make_engine(ltrans_amd, cfg_t, g, geo, bounds, parts, lambda r: records(r, True))
-        st_t = Stepper(e_t, run_t, cfg_t)
-        static_t = float(parts["par"][:, 10].max()) <= 0.0 and not spec["settle"]
-        if static_t:
-            e_t.set_rng_window(0, n, persistent=True)
-
-        def step_t():
-            e_t.update_particles(st_t.ex, st_t.next_times(), st_t.p, st_t.it)
-
-        def fence_t():
-            e_t.sync()
-            torch.cuda.synchronize()
-
-        step_t()                  # the first step carries the start-up of the random stream (generator states, ring)
-        fence_t()
-        first_step_s = time.perf_counter() - t_create
-        for _ in range(max(args.warmup - 1, 0)):
-            if st_t.needs_rotation():
-                st_t.rotate()
-            step_t()
-        fence_t()
-        rs0 = e_t.counters()["resorts"]
-        e_t.profile_begin(args.steps)
-        wall_tb, _ = timed_steps(st_t, args.steps, step_t, fence_t)
-        kt_ms, kt_n = e_t.profile_end()
-        kt_avg = (kt_ms / max(kt_n, 1)) * 1e-3
-        tr_t, src_t, valu_t = pmc_traffic(PROFILE_TURB, VT_KERNELS, lib_hash) if default_shape else (None, None, None)
-        cnt_t = e_t.counters()
-        out["config"]["turbulence"] = {
-            "workload": "BASELINE configs[2]: the same + HTurb + VTurb (MT19937 stream on device)",
-            "value": n * args.steps / wall_tb, "unit": "particle-steps/s", "ms_per_step": wall_tb / args.steps * 1e3,
-            "steps": args.steps, "sigerr_last_step": cnt_t["sigerr"],
-            "rng_window": "static (validated on the device every step)" if static_t else "the engine's own draws, read back per step",
-            "resorts_in_timed_region": cnt_t["resorts"] - rs0,
-            "create_to_first_step_s": first_step_s,
-            "roofline": roofline_block(args.slab, True, us + 1, n, kt_avg, wall_tb / args.steps, tr_t, src_t, valu_t)}
-        e_t.close()
-
-    if world == 1 and not args.no_hydro_timing:
-        out["config"]["hydro_update"] = hydro_update_costs(e, run, rs, g, geo, spec["turb"], st, one_step, fence)
-        # the print step: lon/lat/status on the device + download of the
-        # writers' columns, against downloading the whole particle state
+        setup_s = time.perf_counter() - t_begin
+        for _ in range(args.warmup):
+            if st.needs_rotation():
+                st.rotate()
+            one_step()
         fence()
-        e.get_output()
-        t0 = time.perf_counter(); e.get_output(); t_out = time.perf_counter() - t0
-        t0 = time.perf_counter(); e.get_particles(); t_all = time.perf_counter() - t0
-        out["config"]["print_step"] = {"lt_get_output_ms": t_out * 1e3, "lt_get_particles_ms": t_all * 1e3}
-        # init-time geometry: setEle_all for this shard's particles and the three
-        # adjacency tables on the device, checked against the host-side construction of the inputs
-        px, py = parts["par"][:, 0].copy(), parts["par"][:, 1].copy()
-        e.locate_particles(px[:1024], py[:1024])
-        t0 = time.perf_counter(); er, eu, ev, lerr, _ = e.locate_particles(px, py); t_loc = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        adj = [e.build_adjacency(geo[k], row) for k, row in (("RE", g["vi"]), ("UE", g["ui"]), ("VE", g["vi"]))]
-        t_adj = time.perf_counter() - t0
-        same = (lerr == 0 and np.array_equal(er, parts["P_r_element"]) and np.array_equal(eu, parts["P_u_element"])
-                and np.array_equal(ev, parts["P_v_element"]) and np.array_equal(adj[0], geo["r_Adjacent"])
-                and np.array_equal(adj[1], geo["u_Adjacent"]) and np.array_equal(adj[2], geo["v_Adjacent"]))
-        out["config"]["init_geometry"] = {"lt_locate_particles_ms": t_loc * 1e3, "lt_build_adjacency_ms": t_adj * 1e3,
-                                          "matches_host_construction": bool(same)}
-    e.close()
+        resorts0 = e.counters()["resorts"]
+        e.profile_begin(args.steps)
+        wall, upload_s = timed_steps(st, args.steps, one_step, fence)
+        k_ms, k_n = e.profile_end()
+        stats = e.counters()      # (fails if a static stream window did not hold)
+        if static_window and stats["active"] != n:
+            sys.stderr.write(f"bench.py: static stream window, but {stats['active']} of {n} particles were tracked\n")
+            return 3, None
 
-    if world > 1 and not spec["weak"] and not args.no_single_ref:
-        # strong scaling needs its one-GPU point on the SAME workload: rank 0 alone runs all the
-        # particles (the concatenation of the ranks' shards) for a few steps; reported raw, beside `value`.
-        # It costs rank 0 the generation of every shard's particles and a whole-workload engine: skipped (and
-        # said so) when the run has already used more than --single-ref-budget seconds; --no-single-ref skips it.
-        # (the other ranks hand their shards over through files in the node's temporary directory: generating
-        # them again on rank 0 took longer than everything else together)
-        import tempfile
-        shard_dir = os.path.join(tempfile.gettempdir(), "ltbench_%s" % os.environ.get("MASTER_PORT", "0"))
-        if rank > 0:
-            os.makedirs(shard_dir, exist_ok=True)
-            np.savez(os.path.join(shard_dir, f"rank{rank}.npz"), **parts)
-        torch.cuda.synchronize()
-        dist.barrier()
-        elapsed = time.perf_counter() - t_start
-        if rank == 0 and elapsed > args.single_ref_budget:
-            out["config"]["single_gpu_same_workload"] = {"skipped": f"{elapsed:.0f} s used, budget {args.single_ref_budget} s"}
+        wall_t = torch.tensor([wall], dtype=torch.float64, device=coll_dev)
+        if world > 1:
+            dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
+        wall = float(wall_t.item())
+
+        # (an emulated rank reports its own shard's particle-steps: one GPU's share of the job)
+        total_particle_steps = float(n if args.emulate_rank else spec["total"]) * args.steps
+        value = total_particle_steps / wall
+        k_avg_s = (k_ms / max(k_n, 1)) * 1e-3
+        kernels = VT_KERNELS if spec["turb"] else ["k_rk"]
+        default_shape = (n == 1_000_000 and spec["grid"] == "512x256x30" and args.slab == "f32" and not spec["reflect"])
+        traffic = traffic_src = valu = None
+        if default_shape:
+            traffic, traffic_src, valu = pmc_traffic(PROFILE_TURB if spec["turb"] else PROFILE_ADV, kernels, lib_hash)
+
+        out = {
+            "metric": "particle-steps/s", "value": value, "unit": "particle-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak" if (spec["weak"] or world == 1) else "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload_text(spec, world, n, backend) + (f"; THIS LINE: rank {em_rank} of {em_world} emulated by one "
+                       "process (its shard, its window of the random stream, no all-gather)" if args.emulate_rank else ""),
+                       "baseline_config": spec["name"],
+                       "particles_total": spec["total"], "particles_this_rank": n, "grid": spec["grid"],
+                       "slab_storage": args.slab, "kernel_source_hash": lib_hash,
+                       "active_last_step": stats["active"], "errors_last_step": stats["errors"],
+                       "sigerr_last_step": stats["sigerr"], "slab_rotation_s_excluded": upload_s,
+                       # the device-side re-sort of the particle order (every `resort_every` = 32 steps inside lt_step):
+                       # how many fell into the timed region -- they are part of `value` -- and what one costs
+                       "resorts_in_timed_region": stats["resorts"] - resorts0, "resort_every_steps": 32,
+                       "resort_ms_each": stats["last_resort_ms"] if stats["resorts"] else None,
+                       "rng_window": (("static (validated on the device every step)" if static_window
+                                       else "exchanged per step") if draws else None),
+                       "collective_backend": (backend if world > 1 else None), "device_index": dev_index,
+                       "setup_s": setup_s},
+            "roofline": roofline_block(args.slab, spec["turb"], us + 1, n, k_avg_s, wall / args.steps, traffic, traffic_src,
+                                       valu),
+        }
+
+        if main_line and world == 1 and spec["name"] == "config2" and not args.no_turbulence_line:
+            # BASELINE configs[2] in the same line: the same particles with HTurb + VTurb, same number of steps
+            cfg_t = config_for(n, True)
+            t_create = time.perf_counter()
+            e_t, run_t = make_engine(ltrans_amd, cfg_t, g, geo, bounds, parts, lambda r: records(r, True))
+            st_t = Stepper(e_t, run_t, cfg_t)
+            static_t = float(parts["par"][:, 10].max()) <= 0.0 and not spec["settle"]
+            if static_t:
+                e_t.set_rng_window(0, n, persistent=True)
+
+            def step_t():
+                e_t.update_particles(st_t.ex, st_t.next_times(), st_t.p, st_t.it)
+
+            def fence_t():
+                e_t.sync()
+                torch.cuda.synchronize()
+
+            step_t()                  # the first step carries the start-up of the random stream (generator states, ring)
+            fence_t()
+            first_step_s = time.perf_counter() - t_create
+            for _ in range(max(args.warmup - 1, 0)):
+                if st_t.needs_rotation():
+                    st_t.rotate()
+                step_t()
+            fence_t()
+            rs0 = e_t.counters()["resorts"]
+            e_t.profile_begin(args.steps)
+            wall_tb, _ = timed_steps(st_t, args.steps, step_t, fence_t)
+            kt_ms, kt_n = e_t.profile_end()
+            kt_avg = (kt_ms / max(kt_n, 1)) * 1e-3
+            tr_t, src_t, valu_t = pmc_traffic(PROFILE_TURB, VT_KERNELS, lib_hash) if default_shape else (None, None, None)
+            cnt_t = e_t.counters()
+            out["config"]["turbulence"] = {
+                "workload": "BASELINE configs[2]: the same + HTurb + VTurb (MT19937 stream on device)",
+                "value": n * args.steps / wall_tb, "unit": "particle-steps/s", "ms_per_step": wall_tb / args.steps * 1e3,
+                "steps": args.steps, "sigerr_last_step": cnt_t["sigerr"],
+                "rng_window": "static (validated on the device every step)" if static_t else "the engine's own draws, read back per step",
+                "resorts_in_timed_region": cnt_t["resorts"] - rs0,
+                "create_to_first_step_s": first_step_s,
+                "roofline": roofline_block(args.slab, True, us + 1, n, kt_avg, wall_tb / args.steps, tr_t, src_t, valu_t)}
+            e_t.close()
+
+        if main_line and world == 1 and not args.no_hydro_timing:
+            out["config"]["hydro_update"] = hydro_update_costs(e, run, rs, g, geo, spec["turb"], st, one_step, fence)
+            # the print step (SURVEY.md 8f row 3): lon/lat/status on the device + download of the
+            # writers' columns, against downloading the whole particle state
+            fence()
+            e.get_output()
+            t0 = time.perf_counter(); e.get_output(); t_out = time.perf_counter() - t0
+            t0 = time.perf_counter(); e.get_particles(); t_all = time.perf_counter() - t0
+            out["config"]["print_step"] = {"lt_get_output_ms": t_out * 1e3, "lt_get_particles_ms": t_all * 1e3}
+            # init-time geometry (SURVEY.md 8f row 4): setEle_all for this shard's particles and the three
+            # adjacency tables on the device, checked against the host-side construction of the inputs
+            px, py = parts["par"][:, 0].copy(), parts["par"][:, 1].copy()
+            e.locate_particles(px[:1024], py[:1024])
+            t0 = time.perf_counter(); er, eu, ev, lerr, _ = e.locate_particles(px, py); t_loc = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            adj = [e.build_adjacency(geo[k], row) for k, row in (("RE", g["vi"]), ("UE", g["ui"]), ("VE", g["vi"]))]
+            t_adj = time.perf_counter() - t0
+            same = (lerr == 0 and np.array_equal(er, parts["P_r_element"]) and np.array_equal(eu, parts["P_u_element"])
+                    and np.array_equal(ev, parts["P_v_element"]) and np.array_equal(adj[0], geo["r_Adjacent"])
+                    and np.array_equal(adj[1], geo["u_Adjacent"]) and np.array_equal(adj[2], geo["v_Adjacent"]))
+            out["config"]["init_geometry"] = {"lt_locate_particles_ms": t_loc * 1e3, "lt_build_adjacency_ms": t_adj * 1e3,
+                                              "matches_host_construction": bool(same)}
+        e.close()
+
+        if world > 1 and not spec["weak"] and not args.no_single_ref:
+            # strong scaling needs its one-GPU point on the SAME workload: rank 0 alone runs all the
+            # particles (the concatenation of the ranks' shards) for a few steps; reported raw, beside `value`.
+            # It costs rank 0 the generation of every shard's particles and a whole-workload engine: skipped (and
+            # said so) when the run has already used more than --single-ref-budget seconds; --no-single-ref skips it.
+            # (the other ranks hand their shards over through files in the node's temporary directory: generating
+            # them again on rank 0 took longer than everything else together)
+            import tempfile
+            shard_dir = os.path.join(tempfile.gettempdir(), "ltbench_%s" % os.environ.get("MASTER_PORT", "0"))
+            if rank > 0:
+                os.makedirs(shard_dir, exist_ok=True)
+                np.savez(os.path.join(shard_dir, f"rank{rank}.npz"), **parts)
+            torch.cuda.synchronize()
+            dist.barrier()
+            elapsed = time.perf_counter() - t_start
+            if rank == 0 and elapsed > args.single_ref_budget:
+                out["config"]["single_gpu_same_workload"] = {"skipped": f"{elapsed:.0f} s used, budget {args.single_ref_budget} s"}
+            elif rank == 0:
+                t_ref = time.perf_counter()
+                shards = [parts]
+                for r in range(1, world):
+                    with np.load(os.path.join(shard_dir, f"rank{r}.npz")) as z:
+                        shards.append({k: z[k] for k in parts})
+                allp = {k: np.concatenate([s[k] for s in shards]) if shards[0][k].ndim == 1
+                        else np.asfortranarray(np.vstack([s[k] for s in shards])) for k in parts}
+                del shards
+                cfg1 = config_for(spec["total"], spec["turb"])
+                e1, run1 = make_engine(ltrans_amd, cfg1, g, geo, bounds, allp, records)
+                st1 = Stepper(e1, run1, cfg1)
+                k1 = max(2, min(args.steps, 5))
+
+                def step1():
+                    e1.update_particles(st1.ex, st1.next_times(), st1.p, st1.it)
+
+                def fence1():
+                    e1.sync()
+
+                step1(); step1(); fence1()
+                w1, _ = timed_steps(st1, k1, step1, fence1)
+                out["config"]["single_gpu_same_workload"] = {
+                    "value": spec["total"] * k1 / w1, "unit": "particle-steps/s", "ms_per_step": w1 / k1 * 1e3, "steps": k1,
+                    "note": "all the particles on rank 0's GPU alone, no all-gather",
+                    "wall_s_incl_setup": time.perf_counter() - t_ref}
+                e1.close()
+            dist.barrier()
+            if rank > 0:
+                try:
+                    os.remove(os.path.join(shard_dir, f"rank{rank}.npz"))
+                    os.rmdir(shard_dir)
+                except OSError:
+                    pass
+
+        if main_line and rank == 0 and world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ltrans_amd, args, spec, g, geo, bounds, records)
         elif rank == 0:
-            t_ref = time.perf_counter()
-            shards = [parts]
-            for r in range(1, world):
-                with np.load(os.path.join(shard_dir, f"rank{r}.npz")) as z:
-                    shards.append({k: z[k] for k in parts})
-            allp = {k: np.concatenate([s[k] for s in shards]) if shards[0][k].ndim == 1
-                    else np.asfortranarray(np.vstack([s[k] for s in shards])) for k in parts}
-            del shards
-            cfg1 = config_for(spec["total"], spec["turb"])
-            e1, run1 = make_engine(ltrans_amd, cfg1, g, geo, bounds, allp, records)
-            st1 = Stepper(e1, run1, cfg1)
-            k1 = max(2, min(args.steps, 5))
+            out["cpu_baseline"] = None
+        return 0, out
 
-            def step1():
-                e1.update_particles(st1.ex, st1.next_times(), st1.p, st1.it)
-
-            def fence1():
-                e1.sync()
-
-            step1(); step1(); fence1()
-            w1, _ = timed_steps(st1, k1, step1, fence1)
-            out["config"]["single_gpu_same_workload"] = {
-                "value": spec["total"] * k1 / w1, "unit": "particle-steps/s", "ms_per_step": w1 / k1 * 1e3, "steps": k1,
-                "note": "all the particles on rank 0's GPU alone, no all-gather",
-                "wall_s_incl_setup": time.perf_counter() - t_ref}
-            e1.close()
-        dist.barrier()
-        if rank > 0:
-            try:
-                os.remove(os.path.join(shard_dir, f"rank{rank}.npz"))
-                os.rmdir(shard_dir)
-            except OSError:
-                pass
-
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(ltrans_amd, args, spec, g, geo, bounds, records)
-    elif rank == 0:
-        out["cpu_baseline"] = None
+    spec = resolve_workload(args, world)
+    rc, out = measure(spec, True)
+    if rc:
+        return rc
+    if world > 1 and args.workload == "auto" and not args.weak and not args.no_configs3_line:
+        # BASELINE configs[3] -- the 8-GPU configuration by name: 10M particles in total, 1024x512x50, HTurb + VTurb --
+        # strong-scaled over the same ranks, with its one-GPU point; reported raw under config.configs3_strong
+        rc, o4 = measure(resolve_workload(args, world, name="config4"), False)
+        if rc:
+            return rc
+        if rank == 0:
+            c4 = o4["config"]
+            out["config"]["configs3_strong"] = {
+                "workload": c4["workload"], "value": o4["value"], "unit": o4["unit"], "ms_per_step": o4["ms_per_step"],
+                "steps": o4["steps"], "scaling": o4["scaling"], "particles_total": c4["particles_total"],
+                "particles_this_rank": c4["particles_this_rank"], "grid": c4["grid"], "rng_window": c4["rng_window"],
+                "errors_last_step": c4["errors_last_step"], "sigerr_last_step": c4["sigerr_last_step"],
+                "setup_s": c4["setup_s"], "roofline": o4["roofline"],
+                "single_gpu_same_workload": c4.get("single_gpu_same_workload")}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -761,7 +761,8 @@ int rng_ensure(lt_engine* e, uint64_t first, uint64_t last, hipStream_t gen_stre
       for (auto& ev : e->rng_job_ev) HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
     const int job_slot = e->rng_job_slot;
-    HIPCHK(e, hipEventSynchronize(e->rng_job_ev[(size_t)job_slot]));
+    if (hipEventQuery(e->rng_job_ev[(size_t)job_slot]) != hipSuccess)   // (32 launches back: done, unless the host runs far ahead)
+      HIPCHK(e, hipEventSynchronize(e->rng_job_ev[(size_t)job_slot]));
     ltmt::BlockJob* jobs = e->rng_jobs + (size_t)job_slot * P;
     e->rng_job_slot = (e->rng_job_slot + 1) % RNG_JOB_SLOTS;
     // one launch: the next blocks as long as their owners differ (P consecutive blocks at most)

@@ -2,7 +2,11 @@
 // Part of lt_kernels.h (included inside namespace ltd); see the notes there.
 #pragma once
 
+#ifdef LT_POST_WAVES
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LT_POST_WAVES, LT_POST_WAVES))) void k_post(const StepParams P) {
+#else
 __global__ __launch_bounds__(256) void k_post(const StepParams P) {
+#endif
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned c_err = 0, c_brute = 0, c_pipslow = 0;
   __shared__ EleScratch esc[4];

@@ -517,7 +517,11 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
 // RK4 part does not carry the state of the element search and boundary code (lt_kernels.h).
 
 template <typename SlabT>
+#ifdef LT_PRE_WAVES
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LT_PRE_WAVES, LT_PRE_WAVES))) void k_pre(const StepParams P) {
+#else
 __global__ __launch_bounds__(256) void k_pre(const StepParams P) {
+#endif
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   // the step's diagnostic counters (SigErr, errors, ...): later kernels of the step add to them
   if (blockIdx.x == 0 && threadIdx.x < CNT_COUNT) P.counters[threadIdx.x] = 0ull;

@@ -61,6 +61,24 @@ def test_two_rank_rehearsal_of_the_benchmark():
 
 
 @pytest.mark.gpu
+def test_two_rank_default_line_is_the_headline_workload_weak_scaled():
+    """`bench.py --gpus N` as the driver runs it: the configuration of the N = 1 line per GPU (weak scaling, one series
+    with N = 1), and BASELINE configs[3] strong-scaled with its one-GPU point under config.configs3_strong."""
+    r = _run(["--gpus", "2", "--grid", "128x64x20", "--numpar", "20000", "--configs3-grid", "128x64x20",
+              "--configs3-numpar", "40000", "--steps", "3", "--warmup", "1"], {"LT_BENCH_BACKEND": "gloo"}, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["baseline_config"] == "config2"
+    assert d["config"]["particles_total"] == 40000 and d["config"]["particles_this_rank"] == 20000
+    assert d["roofline"]["kernel"] == "k_rk" and d["config"]["rng_window"] is None and d["value"] > 0
+    c3 = d["config"]["configs3_strong"]
+    assert c3["scaling"] == "strong" and c3["particles_total"] == 40000 and c3["particles_this_rank"] == 20000
+    assert c3["rng_window"].startswith("static") and c3["errors_last_step"] == 0 and c3["value"] > 0
+    assert c3["single_gpu_same_workload"]["value"] > 0
+    assert d["config"]["total_s"] > 0 and d["cpu_baseline"] is None
+
+
+@pytest.mark.gpu
 def test_single_gpu_line_carries_config3_and_hash():
     r = _run(["--steps", "3", "--warmup", "1", "--numpar", "20000", "--grid", "128x64x20", "--no-cpu-baseline",
               "--no-hydro-timing"], timeout=900)
