@@ -594,13 +594,13 @@ int rng_init_device(lt_engine* e) {
   if (!e->rng_jobs) HIPCHK(e, hipHostMalloc((void**)&e->rng_jobs, sizeof(ltmt::BlockJob) * (size_t)RNG_JOB_SLOTS * P, hipHostMallocMapped));
   HIPCHK(e, hipMemcpyAsync(e->rng_states.p, e->mt, 624 * 4, hipMemcpyHostToDevice, e->stream));
   if (P > 1)
-    hipLaunchKernelGGL(ltmt::k_mt_jump, dim3(1), dim3(256), ltmt::LDS_BYTES, e->stream, (uint32_t*)e->rng_states.p, 0, 1,
-                       (const uint32_t*)d_g.p);
+    hipLaunchKernelGGL(ltmt::k_mt_jump_fan, dim3(1), dim3(ltmt::JUMP_WIDE), ltmt::LDS_BYTES, e->stream,
+                       (uint32_t*)e->rng_states.p, 0, 1, (const uint32_t*)d_g.p);
   {
     int have = 1, r = 0;  // states 1 .. have are in place; the next round jumps over `have` blocks
     while (have < P - 1) {
       const int cnt = std::min(have, P - 1 - have);
-      hipLaunchKernelGGL(ltmt::k_mt_jump_fan, dim3((unsigned)cnt), dim3(256), ltmt::LDS_BYTES, e->stream,
+      hipLaunchKernelGGL(ltmt::k_mt_jump_fan, dim3((unsigned)cnt), dim3(ltmt::JUMP_WIDE), ltmt::LDS_BYTES, e->stream,
                          (uint32_t*)e->rng_states.p, 1, have + 1, (const uint32_t*)d_g.p + (size_t)(r + 1) * ltmt::GW);
       have += cnt;
       r += 1;

@@ -337,18 +337,53 @@ __global__ __launch_bounds__(256) void k_mt_jump(uint32_t* __restrict__ states, 
   for (int i = tid; i < N; i += blockDim.x) states[(size_t)dst * N + i] = lds[i];
 }
 
+// jump_in_lds for a workgroup of JUMP_WIDE threads that drives ONE generator: thread t accumulates the single word
+// j = t of the new window (t < N) instead of three, so the pass over the ~10^4 set bits of g reads a third as much
+// per thread; the generation rounds use the first N - M threads as before.  Same result as jump_in_lds.
+constexpr int JUMP_WIDE = 1024;
+__device__ inline void jump_in_lds_wide(uint32_t* lds, const uint32_t* __restrict__ g, int t) {
+  uint32_t acc = 0;
+  for (int c = 0; c < DEG; c += JUMP_CHUNK) {
+    const int todo = (DEG - c < JUMP_CHUNK) ? (DEG - c) : JUMP_CHUNK;
+    for (int base = 0; base < todo; base += (N - M)) {
+      const int i = base + t;
+      if (t < (N - M) && i < todo) lds[N + i] = lds[M + i] ^ twist(lds[i], lds[i + 1]);
+      __syncthreads();
+    }
+    if (t < N) {
+      const int w1 = (c + todo + 31) >> 5;
+      for (int w = c >> 5; w < w1; w++) {
+        uint32_t bits = g[w];
+        const int i0 = w * 32 - c;
+        while (bits) {
+          const int b = __ffs(bits) - 1;
+          bits &= bits - 1;
+          acc ^= lds[i0 + b + t];
+        }
+      }
+    }
+    __syncthreads();
+    const uint32_t keep = (t < N) ? lds[todo + t] : 0u;   // slide the window by todo words
+    __syncthreads();
+    if (t < N) lds[t] = keep;
+    __syncthreads();
+  }
+  if (t < N) lds[t] = acc;
+  __syncthreads();
+}
+
 // states[dst0 + b] = g(F) states[src0 + b], b = blockIdx.x: one round of the start-up positioning by doubling (the
 // states 1 .. 2^r sit at the starts of blocks 1 .. 2^r; the jump over 2^r blocks places 2^r more of them)
-__global__ __launch_bounds__(256) void k_mt_jump_fan(uint32_t* __restrict__ states, int src0, int dst0,
-                                                     const uint32_t* __restrict__ g) {
+__global__ __launch_bounds__(JUMP_WIDE) void k_mt_jump_fan(uint32_t* __restrict__ states, int src0, int dst0,
+                                                          const uint32_t* __restrict__ g) {
   extern __shared__ uint32_t lds[];
   const int tid = threadIdx.x;
   const uint32_t* src = states + (size_t)(src0 + (int)blockIdx.x) * N;
   uint32_t* dst = states + (size_t)(dst0 + (int)blockIdx.x) * N;
-  for (int i = tid; i < N; i += blockDim.x) lds[i] = src[i];
+  if (tid < N) lds[tid] = src[tid];
   __syncthreads();
-  jump_in_lds(lds, g, tid, true);
-  for (int i = tid; i < N; i += blockDim.x) dst[i] = lds[i];
+  jump_in_lds_wide(lds, g, tid);
+  if (tid < N) dst[tid] = lds[tid];
 }
 
 // states[b] = g(F) states[b] for every state b = blockIdx.x (a shard moves its whole pool to its part of the stream)
