@@ -278,37 +278,64 @@ def make_record(g, geo, r, dt=3600.0, with_kh=True, drift=(0.0, 0.0), raw=None, 
     u2 = -0.5 * tide * np.sin(2 * np.pi * xu) * np.cos(np.pi * yu) + 0.05 * math.sin(2 * math.pi * t / 44714.0)
     v2 = 0.5 * tide * np.cos(2 * np.pi * xv) * np.sin(np.pi * yv) * (Ly / Lx) * 2.0
     v2 = np.clip(v2, -0.5, 0.5)
-    U = (u2[:, :, None] + drift[0]) * shear
-    V = (v2[:, :, None] + drift[1]) * shear
-    W = 1.0e-3 * np.sin(np.pi * sw) * (np.sin(2 * np.pi * xr) * np.cos(np.pi * yr))[:, :, None] * tide
+    # The 3-D fields level by level from their 2-D factors (each element through the same operations, in the same
+    # order, as the whole-array expressions kept in the comments: the values are those of the earlier rounds bit for bit)
+    u2d, v2d = u2 + drift[0], v2 + drift[1]
+    shear_l = shear[0, 0, :]
+    A2 = np.sin(2 * np.pi * xr) * np.cos(np.pi * yr)
+    cw_l = 1.0e-3 * np.sin(np.pi * g["SCW"])
+    U_l = lambda l: u2d * shear_l[l]            # noqa: E731  U = (u2[:, :, None] + drift[0]) * shear
+    V_l = lambda l: v2d * shear_l[l]            # noqa: E731  V = (v2[:, :, None] + drift[1]) * shear
+    W_l = lambda l: cw_l[l] * A2 * tide         # noqa: E731  W = 1.0e-3 * sin(pi * sw) * A2[:, :, None] * tide
+    levels = {"U": (U_l, us), "V": (V_l, us), "W": (W_l, ws)}
     if with_kh:
-        K = 1.0e-5 + 1.0e-2 * 4.0 * (-sw) * (1.0 + sw) * \
-            (0.55 + 0.45 * np.sin(2 * np.pi * (xr + 0.25 * t / 44714.0)) * np.cos(2 * np.pi * yr))[:, :, None]
+        B2 = 0.55 + 0.45 * np.sin(2 * np.pi * (xr + 0.25 * t / 44714.0)) * np.cos(2 * np.pi * yr)
+        ck_l = 1.0e-2 * 4.0 * (-g["SCW"]) * (1.0 + g["SCW"])
+        levels["K"] = (lambda l: 1.0e-5 + ck_l[l] * B2, ws)   # K = 1.0e-5 + 1.0e-2 * 4.0 * (-sw) * (1.0 + sw) * B2[:, :, None]
     # salinity with a halocline near -6 m that moves with the tide (up to ~2 psu/m: above the
     # Sgradient cue of behaviours 4/5 in places, below it elsewhere); temperature
-    S = T = None
     if with_st:
-        zr = (g["h"][:, :, None] * sr)                       # approximate depth of the rho levels
-        hal = -6.0 + 2.0 * np.sin(2 * np.pi * (xr + t / 44714.0))[:, :, None]
-        S = 30.0 + 4.0 * np.tanh((hal - zr) / 2.0) + 1.5 * (np.sin(2 * np.pi * xr) * np.cos(np.pi * yr))[:, :, None]
-        T = 12.0 + 8.0 * np.exp(zr / 15.0) + 0.5 * np.cos(2 * np.pi * (yr - t / 44714.0))[:, :, None]
+        hal2 = -6.0 + 2.0 * np.sin(2 * np.pi * (xr + t / 44714.0))
+        C2 = 1.5 * (np.sin(2 * np.pi * xr) * np.cos(np.pi * yr))
+        D2 = 0.5 * np.cos(2 * np.pi * (yr - t / 44714.0))
+        zr_l = lambda l: g["h"] * g["SC"][l]    # noqa: E731  approximate depth of the rho levels
+        # S = 30.0 + 4.0 * tanh((hal - zr) / 2.0) + 1.5 * (...)[:, :, None];  T = 12.0 + 8.0 * exp(zr / 15.0) + 0.5 * cos(...)[:, :, None]
+        levels["S"] = (lambda l: 30.0 + 4.0 * np.tanh((hal2 - zr_l(l)) / 2.0) + C2, us)
+        levels["T"] = (lambda l: 12.0 + 8.0 * np.exp(zr_l(l) / 15.0) + D2, us)
+
+    def whole(name):
+        fn, nl = levels[name]
+        return np.stack([fn(l) for l in range(nl)], axis=2)
+
     if raw is not None:
         conv = lambda a: np.asfortranarray(a.astype(np.float32).astype(raw))  # noqa: E731
-        return dict(romZ=conv(zeta), romU=conv(U + 0.0 * sr), romV=conv(V + 0.0 * sr), romW=conv(W),
-                    romKH=conv(K) if with_kh else None, romS=conv(S) if with_st else None,
-                    romT=conv(T) if with_st else None)
+        return dict(romZ=conv(zeta), romU=conv(whole("U") + 0.0 * sr), romV=conv(whole("V") + 0.0 * sr), romW=conv(whole("W")),
+                    romKH=conv(whole("K")) if with_kh else None, romS=conv(whole("S")) if with_st else None,
+                    romT=conv(whole("T")) if with_st else None)
+
+    def node_numbered(name, m2):
+        """f32(field) * mask as (nodes, levels), Fortran order, node = i + j * ni: formed level by level into the
+        level-major buffer whose transposed view that is (no 3-D temporaries, no transposing copy); the product
+        with the 0 / 1 mask is exact in either type, so it is taken on the float32 values."""
+        fn, nl = levels[name]
+        ni, nj = m2.shape
+        buf = np.empty((nl, nj, ni), dtype=np.float64)
+        m32 = np.ascontiguousarray(m2.T, dtype=np.float32)
+        for l in range(nl):
+            lev = np.ascontiguousarray(fn(l).T, dtype=np.float32)
+            lev *= m32
+            buf[l] = lev
+        return buf.reshape(nl, nj * ni).T
+
     out = dict(
         zeta=F(f32(zeta) * geo["m_r"]),
-        Uvel=F(f32(U) * geo["m_u"][:, :, None]),
-        Vvel=F(f32(V) * geo["m_v"][:, :, None]),
-        Wvel=F(f32(W) * geo["m_r"][:, :, None]),
-        salt=F(f32(S) * geo["m_r"][:, :, None]) if with_st else None,
-        temp=F(f32(T) * geo["m_r"][:, :, None]) if with_st else None,
+        Uvel=node_numbered("U", geo["m_u"]),
+        Vvel=node_numbered("V", geo["m_v"]),
+        Wvel=node_numbered("W", geo["m_r"]),
+        salt=node_numbered("S", geo["m_r"]) if with_st else None,
+        temp=node_numbered("T", geo["m_r"]) if with_st else None,
+        Kh=node_numbered("K", geo["m_r"]) if with_kh else None,
     )
-    if with_kh:
-        out["Kh"] = F(f32(K) * geo["m_r"][:, :, None])
-    else:
-        out["Kh"] = None
     assert out["Uvel"].shape == (geo["u_nodes"], us) and out["Wvel"].shape == (geo["rho_nodes"], ws)
     return out
 
@@ -339,16 +366,19 @@ def locate_elements(g, geo, x, y, kind):
     gi = np.clip(np.floor((x - x0) / g["dx"]).astype(np.int64), 0, ni - 1)
     gj = np.clip(np.floor((y - y0) / g["dy"]).astype(np.int64), 0, nj - 1)
     ele = np.zeros(x.shape, dtype=np.int32)
-    done = np.zeros(x.shape, dtype=bool)
+    todo = np.arange(x.size)          # the points not located yet: the first cell that holds a point wins
     for dj in (0, -1, 1, -2, 2):
         for di in (0, -1, 1, -2, 2):
-            ci = np.clip(gi + di, 0, ni - 1)
-            cj = np.clip(gj + dj, 0, nj - 1)
+            if todo.size == 0:
+                return ele
+            ci = np.clip(gi[todo] + di, 0, ni - 1)
+            cj = np.clip(gj[todo] + dj, 0, nj - 1)
             qx = [X[ci, cj], X[ci + 1, cj], X[ci + 1, cj + 1], X[ci, cj + 1]]
             qy = [Y[ci, cj], Y[ci + 1, cj], Y[ci + 1, cj + 1], Y[ci, cj + 1]]
-            hit = _in_quad(x, y, qx, qy) & ~done & (cmap[ci, cj] > 0)
-            ele[hit] = cmap[ci, cj][hit]
-            done |= hit
+            cm = cmap[ci, cj]
+            hit = _in_quad(x[todo], y[todo], qx, qy) & (cm > 0)
+            ele[todo[hit]] = cm[hit]
+            todo = todo[~hit]
     return ele
 
 
