@@ -170,12 +170,12 @@ LT_DEV double hpval_prepared(double T, const VtInterval& c) {
 // the old interval is kept)
 LT_DEV void vt_seek(VtInterval& c, double T, int n, const double4* tab) {
   bool moved = false;
-  if (c.I == 0) {  // first use: bisection
-    int lo = 1, hi = n;
-    while (hi > lo + 1) {
-      const int kk = (lo + hi) >> 1;
-      if (T < tab[(size_t)(kk - 1) * VT_TS].x) hi = kk; else lo = kk;
-    }
+  if (c.I == 0) {  // first use: the start of vt_seek_lite (the table is strictly increasing wherever this is called)
+    const double xa = tab[0].x, xb = tab[(size_t)(n - 1) * VT_TS].x;
+    const double f = (T - xa) / (xb - xa) * (double)(n - 1);
+    int lo = (f >= 0.0 && f < (double)(n - 1)) ? (int)f + 1 : ((f >= 0.0) ? n - 1 : 1);
+    if (lo < 1) lo = 1;
+    if (lo > n - 1) lo = n - 1;
     c.I = lo;
     const double4 ra = tab[(size_t)(lo - 1) * VT_TS], rb = tab[(size_t)lo * VT_TS];
     c.X1 = ra.x; c.Y1 = ra.y; c.P1 = ra.z; c.SG = ra.w;
@@ -593,12 +593,16 @@ struct VtLite {          // the cached interval without the tension-dependent pa
 };
 LT_DEV void vt_seek_lite(VtLite& c, double T, int n, const double4* tab) {
   bool moved = false;
-  if (c.I == 0) {  // first use: bisection
-    int lo = 1, hi = n;
-    while (hi > lo + 1) {
-      const int kk = (lo + hi) >> 1;
-      if (T < tab[(size_t)(kk - 1) * VT_TS].x) hi = kk; else lo = kk;
-    }
+  if (c.I == 0) {
+    // first use.  The table is strictly increasing here (k_vt_walk_fast does not take a table YPC1 rejected), so
+    // the interval INTRVL's bisection finds is the unique one with X(I) <= T < X(I+1) (clamped to 1 .. N-1), and
+    // the stepping below reaches it from any start: start where T lies between the end knots in proportion --
+    // the knots are nearly evenly spaced -- two or three loads instead of a chain of seven.
+    const double xa = tab[0].x, xb = tab[(size_t)(n - 1) * VT_TS].x;
+    const double f = (T - xa) / (xb - xa) * (double)(n - 1);
+    int lo = (f >= 0.0 && f < (double)(n - 1)) ? (int)f + 1 : ((f >= 0.0) ? n - 1 : 1);   // (NaN: 1)
+    if (lo < 1) lo = 1;
+    if (lo > n - 1) lo = n - 1;
     c.I = lo;
     const double4 ra = tab[(size_t)(lo - 1) * VT_TS], rb = tab[(size_t)lo * VT_TS];
     c.X1 = ra.x; c.Y1 = ra.y; c.P1 = ra.z; c.SG = ra.w;
