@@ -2229,6 +2229,10 @@ int lt_set_rng_window(lt_engine* e, int64_t active_before, int64_t active_total)
   e->rng_total = active_total * D;
   e->rng_static = false;
   e->rng_static_own = -1;
+  if (e->h_counters && e->h_counters[CNT_STATIC_MISS]) {   // a window set anew: the earlier report is spent
+    e->h_counters[CNT_STATIC_MISS] = 0;
+    HIPCHK(e, hipMemsetAsync((unsigned long long*)e->counters.p + CNT_STATIC_MISS, 0, sizeof(unsigned long long), e->stream));
+  }
   return LT_OK;
 }
 
@@ -2457,12 +2461,13 @@ int lt_step(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32
 }
 
 static int fetch_counters(lt_engine* e) {
-  if (e->counters_fetched) return LT_OK;
-  HIPCHK(e, hipMemcpyAsync(e->h_counters, e->counters.p, CNT_ALLOC * sizeof(unsigned long long),
-                           hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(e, hipStreamSynchronize(e->stream));
-  e->counters_fetched = true;
-  if (e->h_counters[CNT_STATIC_MISS])
+  if (!e->counters_fetched) {
+    HIPCHK(e, hipMemcpyAsync(e->h_counters, e->counters.p, CNT_ALLOC * sizeof(unsigned long long),
+                             hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    e->counters_fetched = true;
+  }
+  if (e->h_counters[CNT_STATIC_MISS])   // (reported by every call until a window is set again)
     return fail(e, LT_ERR_STATE, "static random-stream window: the shard's draws changed (%llu step(s)); a particle "
                                  "stopped or started drawing -- set the window before each step instead",
                 e->h_counters[CNT_STATIC_MISS]);

@@ -172,3 +172,38 @@ def test_mid_size_run_across_a_resort_is_bit_identical(oracle):
     assert err <= 1e-6, err
     if not np.array_equal(hip["par"][:, :9], ora["par"][:, :9]):
         pytest.xfail(f"within 1e-6 but not bit-identical (max rel err {err:.2e}): the host libm is not the one lt_libm.h restates")
+
+
+def test_static_window_that_does_not_hold_is_reported():
+    """lt_set_rng_window_static promises that no particle stops drawing.  The engine reads the shard's draws back once
+    and enqueues the later steps without waiting for the device; the device compares every step's total with that
+    figure.  With mortality the promise breaks after a few steps: the following lt_get_stats / lt_get_counters /
+    lt_get_particles fail (LT_ERR_STATE) instead of handing back a stream position that silently left the serial one."""
+    case = cases.build_case("tiny_turb", mortality=1, deadage=500.0)
+    n = case["cfg"].numpar
+    e = cases.make_engine(case, ltrans_amd.Engine, {})
+    from ltrans_amd.driver import LtransRun
+    run = LtransRun(e, case["cfg"].dt, case["cfg"].idt, case["record"])
+    run.init_hydro()
+    e.set_rng_window(0, n, persistent=True)
+    ex = run.external_times(1)
+    reported = None
+    for it in range(1, 13):
+        e.update_particles(ex, run.internal_times(ex, it), 1, it)
+        try:
+            st = e.stats()
+        except ltrans_amd.LtError as err:
+            reported = (it, str(err))
+            break
+        assert st["active"] == n          # as long as nothing is reported, every particle drew
+    assert reported is not None and "static random-stream window" in reported[1], reported
+    assert reported[0] >= 3               # the first steps (age below deadage) are fine
+    with pytest.raises(ltrans_amd.LtError):
+        e.get_particles(fields=("par",))
+    # a window set before the step (the exchange of counts) is how such a run goes on
+    it = reported[0] + 1
+    ix = run.internal_times(ex, it)
+    e.set_rng_window(0, e.count_active(ix))
+    e.update_particles(ex, ix, 1, it)
+    assert e.stats()["active"] < n
+    e.close()
