@@ -1536,6 +1536,7 @@ int lt_set_particles(lt_engine* e, const lt_particles* p) {
   if (!e->have_grid) return fail(e, LT_ERR_STATE, "lt_set_particles before lt_set_grid");
   if (!e->par.p && !p->par) return fail(e, LT_ERR_ARG, "lt_set_particles: par is required");
   HIPCHK(e, hipSetDevice(e->device));
+  e->rng_static_own = -1;   // (new particle state: a static stream window reads the shard's draws back again)
   const size_t n = (size_t)e->cfg.numpar;
   if (p->P_r_element) TRY(check_particle_elements(e, p->P_r_element, (int)n, e->rho_elements, "P_r_element"));
   if (p->P_u_element) TRY(check_particle_elements(e, p->P_u_element, (int)n, e->u_elements, "P_u_element"));
@@ -1571,7 +1572,7 @@ int lt_set_particles(lt_engine* e, const lt_particles* p) {
       TRY(dev_alloc(e, e->vt_qS2, waves * e->vt_qcap * 8)); TRY(dev_alloc(e, e->vt_qwl, waves * e->vt_qcap * 2));
       TRY(dev_alloc(e, e->vt_qcount, waves * 4 + 4));
       TRY(dev_alloc(e, e->vt_wl, (2 * n + 4) * 4));
-      TRY(dev_alloc(e, e->vt_dev, waves * 64 * (size_t)std::max(e->cfg.idt / 2, 1) * 8));
+      TRY(dev_alloc(e, e->vt_dev, waves * 64 * (size_t)(std::max(e->cfg.idt / 2, 1) + VT_DEV_HROWS) * 8));
     }
   }
   TRY(sync_perm(e));

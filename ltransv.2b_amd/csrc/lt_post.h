@@ -10,6 +10,11 @@ __global__ __launch_bounds__(256) void k_post(const StepParams P) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned c_err = 0, c_brute = 0, c_pipslow = 0;
   __shared__ EleScratch esc[4];
+  __shared__ double s_hamp;   // HTurb's amplitude (2/r*KM*idt)**0.5 -- the same for every particle: libm's pow once per workgroup
+  if (P.HTurbOn) {
+    if (threadIdx.x == 0) s_hamp = lt_pow_half_g(2.0 / 1.0 * P.ConstantHTurb * P.idt);
+    __syncthreads();
+  }
   // Part 1 (per lane): behaviour, new position, boundaries.  Part 2 (whole wave): setEle on
   // the new position.  Part 3 (per lane): settlement, error handling, commit.
   const bool inrange = n < P.numpar;
@@ -48,9 +53,15 @@ __global__ __launch_bounds__(256) void k_post(const StepParams P) {
       // HTurb, hor_turb_module.f90:29-50: X deviate before Y; VTurb's TurbV from k_vt_walk
       double TurbHx = 0.0, TurbHy = 0.0, TurbV = 0.0;
       if (P.HTurbOn) {
-        const unsigned long long di = P.rng_base + (unsigned long long)(unsigned)P.rank[P.orig[n]];
-        const double devX = draw_norm(P, di), devY = draw_norm(P, di + 2);
-        const double amp = lt_pow_half_g(2.0 / 1.0 * P.ConstantHTurb * P.idt);  // (2/r*KM*idt)**0.5: libm's pow
+        double devX, devY;
+        if (P.VTurbOn) {   // formed by k_vt_norm with the walk's deviates (the tables are in LDS there)
+          const double* hrow = VT_DEV_BASE(P, n, P.idt / 2);
+          devX = hrow[0]; devY = hrow[64];
+        } else {
+          const unsigned long long di = P.rng_base + (unsigned long long)(unsigned)P.rank[P.orig[n]];
+          devX = draw_norm(P, di); devY = draw_norm(P, di + 2);
+        }
+        const double amp = s_hamp;
         TurbHx = devX * amp;
         TurbHy = devY * amp;
       }

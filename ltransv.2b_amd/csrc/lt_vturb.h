@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
   if (lane == 0)
     for (int q = 0; q < 6; q++) atomicAdd(&g_tim[8 + q], vt_acc[q]);
 #endif
-  if (lane == 0) {
+  if (lane == 0 && (size_t)wave * 64 < (size_t)P.numpar) {   // (the last workgroup may hold waves beyond the particles)
     Q.count[wave] = (ntask < Q.cap) ? ntask : Q.cap;
     if (ntask) atomicAdd(&P.counters[CNT_VT_QUEUED], (unsigned long long)ntask);
   }
@@ -530,6 +530,10 @@ __global__ __launch_bounds__(256) void k_vt_sigs(const StepParams P) {
 }
 
 struct __attribute__((packed, aligned(4))) RawWords4 { uint32_t a, b, c, d; };
+// rows of deviates per group of 64 particles: two for HTurb's X and Y (hor_turb_module.f90:29-50; formed here when
+// both kinds of turbulence are on, read by k_post), then the idt/2 of the walk
+#define VT_DEV_HROWS 2
+#define VT_DEV_BASE(P, n, loop) ((P).vt_dev + (size_t)((n) >> 6) * (size_t)((loop) + VT_DEV_HROWS) * 64 + (size_t)((n) & 63))
 // ---- the normal deviates of the walk
 // norm() (norm_module.f90:25-39) of a sub-step is a function of the particle's two words of the stream alone, not
 // of where the walk has got to: the idt/2 deviates of every tracked particle are formed here, ahead of the walk and
@@ -545,9 +549,18 @@ __global__ __launch_bounds__(256) void k_vt_norm(const StepParams P) {
   if (n >= P.numpar) return;
   if (!(P.ws_i[n] & FL_ACT)) return;
   const int loop = P.idt / 2;
-  unsigned long long di = P.rng_base + (unsigned long long)(unsigned)P.rank[P.orig[n]] +
-                          (P.HTurbOn ? 4ull : 0ull);
-  double* out = P.vt_dev + (size_t)(n >> 6) * (size_t)loop * 64 + (size_t)(n & 63);
+  unsigned long long di = P.rng_base + (unsigned long long)(unsigned)P.rank[P.orig[n]];
+  double* out = VT_DEV_BASE(P, n, loop);
+  if (P.HTurbOn) {   // HTurb's two deviates (its four words come first, LTRANS.f90:1087,1098): norm() as below
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const double dev1 = ((double)ltmt_temper(P.rng_ring[(di + 2 * j) & P.rng_mask]) + 0.5) / 4294967296.0;
+      const double dev2 = ((double)ltmt_temper(P.rng_ring[(di + 2 * j + 1) & P.rng_mask]) + 0.5) / 4294967296.0;
+      out[(size_t)j * 64] = sqrt(-2.0 * lt_log(dev1)) * lt_cos(2.0 * P.PI * dev2);
+    }
+    di += 4ull;
+  }
+  out += (size_t)VT_DEV_HROWS * 64;
 #pragma unroll 1
   for (int i0 = 0; i0 < loop; i0 += 8) {
     const unsigned long long o = di & P.rng_mask;
@@ -646,7 +659,7 @@ __global__ __launch_bounds__(256) void k_vt_walk_fast(const StepParams P) {
   const double P_zetac = wsd[(size_t)WS_ZETA1 * N];
   const double background = (double)1.0E-6f, deltat = 2.0;
   const int loop = P.idt / (int)deltat;
-  const double* dev = P.vt_dev + (size_t)(n >> 6) * (size_t)loop * 64 + (size_t)(n & 63);
+  const double* dev = VT_DEV_BASE(P, n, loop) + (size_t)VT_DEV_HROWS * 64;
   double ParZc = P_zc;
   VtLite ci;
   ci.I = 0; ci.X1 = ci.X2 = ci.Y1 = ci.Y2 = ci.P1 = ci.P2 = ci.SG = ci.SGhi = 0.0;
@@ -723,7 +736,7 @@ __global__ __launch_bounds__(256) void k_vt_walk(const StepParams P) {
   // :282-335 random displacement model, idt/2 sub-steps of 2 s
   const double background = (double)1.0E-6f, deltat = 2.0;
   const int loop = P.idt / (int)deltat;
-  const double* dev = P.vt_dev + (size_t)(n >> 6) * (size_t)loop * 64 + (size_t)(n & 63);   // norm() per sub-step
+  const double* dev = VT_DEV_BASE(P, n, loop) + (size_t)VT_DEV_HROWS * 64;   // norm() per sub-step
   double ParZc = wsd[(size_t)WS_TURBV * N];   // left there by k_vt_walk_fast
   int il = 1;
   VtInterval ci;
