@@ -207,3 +207,47 @@ def test_static_window_that_does_not_hold_is_reported():
     e.update_particles(ex, ix, 1, it)
     assert e.stats()["active"] < n
     e.close()
+
+
+def test_long_run_without_host_waits_equals_the_run_with_windows_per_step():
+    """400 internal steps (14 external steps) of 20k particles with HTurb + VTurb, once under a static stream window --
+    the host enqueues every step without waiting for the device, hundreds of steps ahead: the generators' ring, their
+    job slots and the order against the step before are all kept by events on the device -- and once with the window
+    set before every step (a read-back per step): the same particles and the same stream position, bit for bit."""
+    outs = []
+    for static in (True, False):
+        case = cases.build_case("mid_turb")
+        n = case["cfg"].numpar
+        e = cases.make_engine(case, ltrans_amd.Engine, {})
+        from ltrans_amd.driver import LtransRun
+        run = LtransRun(e, case["cfg"].dt, case["cfg"].idt, case["record"])
+        run.init_hydro()
+        if static:
+            e.set_rng_window(0, n, persistent=True)
+
+        def on_step(p, it, ex, ix):
+            pass
+
+        left = [400]
+        for p in range(1, 15):
+            run.p = p
+            if p > 2:
+                run.update_hydro()
+            ex = run.external_times(p)
+            for it in range(1, case["cfg"].dt // case["cfg"].idt + 1):
+                if left[0] == 0:
+                    break
+                ix = run.internal_times(ex, it)
+                if not static:
+                    e.set_rng_window(0, e.count_active(ix))
+                e.update_particles(ex, ix, p, it)
+                left[0] -= 1
+        out = e.get_particles(fields=("par", "P_r_element", "err_code"))
+        out["rng"] = e.get_rng()
+        assert e.stats()["active"] == n
+        e.close()
+        outs.append(out)
+    a, b = outs
+    assert np.array_equal(a["par"], b["par"])
+    assert np.array_equal(a["P_r_element"], b["P_r_element"]) and np.array_equal(a["err_code"], b["err_code"])
+    assert np.array_equal(a["rng"][0], b["rng"][0]) and a["rng"][1] == b["rng"][1]
