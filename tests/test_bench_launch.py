@@ -45,6 +45,34 @@ def test_world_size_must_match_gpus():
     assert r.returncode == 2 and "WORLD_SIZE=3" in r.stderr
 
 
+def test_workload_resolution():
+    """what `bench.py --gpus N` measures: the N = 1 configuration per GPU (weak scaling, one series with N = 1) unless a
+    workload is named; BASELINE configs[3] strong-scaled as the embedded line of an auto run"""
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse([])
+    one = bench.resolve_workload(a, 1)
+    assert (one["name"], one["total"], one["weak"], one["turb"], one["grid"]) == ("config2", 1_000_000, False, False, "512x256x30")
+    eight = bench.resolve_workload(a, 8)
+    assert (eight["name"], eight["total"], eight["weak"], eight["grid"]) == ("config2", 8_000_000, True, "512x256x30")
+    emb = bench.resolve_workload(a, 8, name="config4")
+    assert (emb["name"], emb["total"], emb["weak"], emb["turb"], emb["grid"]) == ("config4", 10_000_000, False, True, "1024x512x50")
+    named = bench.resolve_workload(bench.parse(["--workload", "config4", "--gpus", "8"]), 8)
+    assert (named["name"], named["total"], named["weak"]) == ("config4", 10_000_000, False)
+    small = bench.parse(["--gpus", "2", "--grid", "128x64x20", "--numpar", "20000", "--configs3-grid", "64x32x10",
+                         "--configs3-numpar", "5000"])
+    assert bench.resolve_workload(small, 2)["total"] == 40000 and bench.resolve_workload(small, 2)["grid"] == "128x64x20"
+    e2 = bench.resolve_workload(small, 2, name="config4")
+    assert (e2["total"], e2["grid"], e2["weak"]) == (5000, "64x32x10", False)
+    turb = bench.resolve_workload(bench.parse(["--turb"]), 1)
+    assert turb["name"] == "config3" and turb["turb"]
+    # bytes and time of a roofline figure cover the same kernels
+    r = bench.roofline_block("f32", True, 31, 1_000_000, 4.0e-3, 5.3e-3, None, None, None)
+    assert r["algorithmic_bytes_per_particle_step"] == 48 * 31 + 992 and r["kernel"].count("+") == 4
+    assert abs(r["frac"] - 2480e6 / 4.0e-3 / 1e9 / 8000.0) < 1e-12
+    assert r["whole_step"]["algorithmic_bytes_per_particle_step"] == 976 + 48 * 31 + 992
+
+
 @pytest.mark.gpu
 def test_two_rank_rehearsal_of_the_benchmark():
     r = _run(["--gpus", "2", "--workload", "config4", "--grid", "128x64x20", "--numpar", "40000", "--steps", "3",
