@@ -622,6 +622,21 @@ def main():
         if static_window and stats["active"] != n:
             sys.stderr.write(f"bench.py: static stream window, but {stats['active']} of {n} particles were tracked\n")
             return 3, None
+        # what a device-side re-sort of the particle order costs (one every 32 steps inside lt_step): if none has
+        # happened yet, a few untimed steps more until one has
+        resort_ms = stats["last_resort_ms"] if stats["resorts"] else None
+        if resort_ms is None and not args.emulate_rank:
+            for _ in range(40):
+                if st.needs_rotation():
+                    st.rotate()
+                one_step()
+                c2 = e.counters()
+                if c2["resorts"]:
+                    resort_ms = c2["last_resort_ms"]
+                    break
+            fence()
+        resorts_in = stats["resorts"] - resorts0
+        resort_excl = (max(args.steps / 32.0 - resorts_in, 0.0) * resort_ms * 1e-3) if resort_ms is not None else None
 
         wall_t = torch.tensor([wall], dtype=torch.float64, device=coll_dev)
         if world > 1:
@@ -653,8 +668,10 @@ def main():
                        "sigerr_last_step": stats["sigerr"], "slab_rotation_s_excluded": upload_s,
                        # the device-side re-sort of the particle order (every `resort_every` = 32 steps inside lt_step):
                        # how many fell into the timed region -- they are part of `value` -- and what one costs
-                       "resorts_in_timed_region": stats["resorts"] - resorts0, "resort_every_steps": 32,
-                       "resort_ms_each": stats["last_resort_ms"] if stats["resorts"] else None,
+                       "resorts_in_timed_region": resorts_in, "resort_every_steps": 32, "resort_ms_each": resort_ms,
+                       # the re-sorts a run of `steps` steps has on average (steps / 32) that did not fall into the
+                       # timed region, in seconds: add it to the region's wall time for the steady-state figure
+                       "resort_s_excluded": resort_excl,
                        "rng_window": (("static (validated on the device every step)" if static_window
                                        else "exchanged per step") if draws else None),
                        "collective_backend": (backend if world > 1 else None), "device_index": dev_index,

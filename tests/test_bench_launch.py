@@ -120,6 +120,9 @@ def test_single_gpu_line_carries_config3_and_hash():
     assert t["roofline"]["whole_step"]["algorithmic_bytes_per_particle_step"] == 976 + 48 * 21 + 992
     assert t["rng_window"].startswith("static") and t["create_to_first_step_s"] > 0
     assert d["config"]["resorts_in_timed_region"] == 0 and d["config"]["total_s"] > d["config"]["setup_s"] > 0
+    # no re-sort fell into the 3 timed steps: the line says what the window left out (3/32 of a re-sort)
+    assert d["config"]["resort_ms_each"] > 0
+    assert abs(d["config"]["resort_s_excluded"] - 3 / 32 * d["config"]["resort_ms_each"] * 1e-3) < 1e-12
     assert len(d["config"]["kernel_source_hash"]) == 16
     assert d["roofline"]["traffic"] is None          # not the profiled shape
 
