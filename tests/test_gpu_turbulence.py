@@ -251,3 +251,20 @@ def test_long_run_without_host_waits_equals_the_run_with_windows_per_step():
     assert np.array_equal(a["par"], b["par"])
     assert np.array_equal(a["P_r_element"], b["P_r_element"]) and np.array_equal(a["err_code"], b["err_code"])
     assert np.array_equal(a["rng"][0], b["rng"][0]) and a["rng"][1] == b["rng"][1]
+
+
+@pytest.mark.parametrize("name,numpar,idt", [("tiny_turb", 500, 90), ("tiny_vturb", 333, 100), ("tiny_turb", 65, 40),
+                                               ("tiny_hturb", 129, 90)])
+def test_odd_shapes_are_bit_identical(oracle, name, numpar, idt):
+    """shapes the fixed cases do not have: a number of walk sub-steps (idt/2) that is not a multiple of the eight the
+    deviates are formed at a time, particle counts that are not multiples of a wave or a workgroup, either kind of
+    turbulence alone"""
+    hip = cases.run_case(cases.build_case(name, numpar=numpar, idt=idt), ltrans_amd.Engine, {}, n_external=1, max_internal=12)
+    ora = cases.run_case(cases.build_case(name, numpar=numpar, idt=idt), ltrans_amd.Engine, dict(lib=oracle, prefix="lto_"),
+                         n_external=1, max_internal=12)
+    for k in ("P_r_element", "err_code", "hitBottom", "hitLand"):
+        assert np.array_equal(hip[k], ora[k]), k
+    if not np.array_equal(hip["par"][:, :9], ora["par"][:, :9]):
+        err = cases.rel_error(hip["par"], ora["par"])
+        assert err <= 1e-6, err
+        pytest.xfail(f"within 1e-6 but not bit-identical (max rel err {err:.2e}): the host libm is not the one lt_libm.h restates")
