@@ -25,9 +25,7 @@
 #include <vector>
 
 #include "../../include/ltrans_hip.h"
-#ifndef LT_RK_WAVES
-#define LT_RK_WAVES 2  // k_rk is held to 256 VGPRs (2 waves per SIMD); the few spills sit outside the slot loop
-#endif
+#include "lt_rk_launch.h"  // k_rk lives in lt_rk_kernel.hip (its own compiler options)
 #include "lt_kernels.h"
 #include "lt_bounds_host.h"
 #include "lt_mt.h"
@@ -804,19 +802,6 @@ int rng_ensure(lt_engine* e, uint64_t first, uint64_t last, hipStream_t gen_stre
   return LT_OK;
 }
 
-// k_rk is instantiated per slab type and per Vtransform (the s-level formula is
-// then straight-line code in the hot loop)
-template <typename SlabT>
-void launch_rk_t(lt_engine* e, const StepParams& P, unsigned blocks) {
-  // (a multiple of 8 workgroups: k_rk maps them to particle chunks per XCD)
-  const unsigned rkblocks = ((unsigned)(((size_t)blocks * 256 + LT_RK_BLOCK - 1) / LT_RK_BLOCK) + 7u) & ~7u;
-  static const unsigned dynlds = getenv("LT_RK_DYNLDS") ? (unsigned)atoi(getenv("LT_RK_DYNLDS")) : 0u;  // occupancy experiments
-  switch (e->cfg.Vtransform) {
-    case 1: hipLaunchKernelGGL((k_rk<SlabT, 1, LT_RK_WAVES>), dim3(rkblocks), dim3(LT_RK_BLOCK), dynlds, e->stream, P); break;
-    case 2: hipLaunchKernelGGL((k_rk<SlabT, 2, LT_RK_WAVES>), dim3(rkblocks), dim3(LT_RK_BLOCK), dynlds, e->stream, P); break;
-    default: hipLaunchKernelGGL((k_rk<SlabT, 3, LT_RK_WAVES>), dim3(rkblocks), dim3(LT_RK_BLOCK), dynlds, e->stream, P); break;
-  }
-}
 // the first consumer of the step's random words waits for the generators
 void wait_rng(lt_engine* e) {
   if (e->rng_pending) (void)hipStreamWaitEvent(e->stream, e->rng_done, 0);
@@ -847,9 +832,13 @@ void launch_vturb(lt_engine* e, const StepParams& P, unsigned blocks) {
   if (e->cfg.slab_storage == LT_SLAB_F32) launch_vturb_t<float>(e, P, blocks);
   else launch_vturb_t<double>(e, P, blocks);
 }
+// k_rk is instantiated per slab type and per Vtransform (the s-level formula is then straight-line code in
+// the hot loop), in lt_rk_kernel.hip
 void launch_rk(lt_engine* e, const StepParams& P, unsigned blocks) {
-  if (e->cfg.slab_storage == LT_SLAB_F32) launch_rk_t<float>(e, P, blocks);
-  else launch_rk_t<double>(e, P, blocks);
+  // (a multiple of 8 workgroups: k_rk maps them to particle chunks per XCD)
+  const unsigned rkblocks = ((unsigned)(((size_t)blocks * 256 + LT_RK_BLOCK - 1) / LT_RK_BLOCK) + 7u) & ~7u;
+  static const unsigned dynlds = getenv("LT_RK_DYNLDS") ? (unsigned)atoi(getenv("LT_RK_DYNLDS")) : 0u;  // occupancy experiments
+  launch_k_rk(e->cfg.slab_storage == LT_SLAB_F32, e->cfg.Vtransform, rkblocks, dynlds, e->stream, P);
 }
 
 }  // namespace
@@ -2500,9 +2489,12 @@ int lt_get_stats(lt_engine* e, lt_step_stats* out) {
 #ifdef LT_RK_TIMING
 int lt_diag(unsigned long long* out) {
   hipDeviceSynchronize();
+  // (k_vt_table's sections are counted in this unit's copy of g_tim, k_rk's in lt_rk_kernel.hip's)
   hipMemcpyFromSymbol(out, HIP_SYMBOL(ltd::g_tim), 128);
-  unsigned long long z[16] = {0};
+  unsigned long long z[16] = {0}, r[16];
   hipMemcpyToSymbol(HIP_SYMBOL(ltd::g_tim), z, 128);
+  ltd::rk_timing_fetch(r, true);
+  for (int i = 0; i < 16; i++) out[i] += r[i];
   return 0;
 }
 #endif

@@ -63,9 +63,11 @@ template <> struct SlabTraits<double> { using zeta4 = double4; };
 
 #include "lt_grid.h"
 #include "lt_rk.h"
+#ifndef LT_KERNELS_RK_ONLY  // (lt_rk_kernel.hip: the kernels below are not templates and belong to lt_engine.hip)
 #include "lt_vturb.h"
 #include "lt_post.h"
 #include "lt_io.h"
 #include "lt_init.h"
+#endif
 
 }  // namespace ltd

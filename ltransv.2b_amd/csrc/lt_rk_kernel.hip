@@ -1,0 +1,48 @@
+// lt_rk_kernel.hip -- k_rk (lt_rk.h) in a translation unit of its own, because it is compiled with
+// `-mllvm -disable-machine-licm` and the rest of the library is not.
+//
+// Pass B of k_rk (the Newton iterations of SIGS, lt_math.h: sigs_newton_k, exp_core, hval_interval_s) works with
+// some twenty double-precision constants -- polynomial coefficients, the constants of libm's exp.  A double that
+// is not an inline constant occupies a pair of scalar registers, and the machine-level loop-invariant code
+// motion of the compiler moves their `s_mov`s out of every loop of the kernel: ~45 scalar registers held from
+// the first instruction to the last.  Pass A then has no scalar registers left for its own lane masks and loop
+// counters, which the register allocator parks in lanes of a vector register and fetches back with
+// v_readlane -- a vector-ALU issue slot each, inside the slot loop the kernel spends its time in.  With the
+// constants materialised where they are used (scalar-ALU instructions, which issue beside the other wave's
+// vector instructions) k_rk issues 24.2k instead of 25.1k vector instructions per wave and step at 212
+// instead of 256 vector registers, and takes 0.946 instead of 0.971 ms.  The VTurb
+// kernels lose with the same option (k_vt_sigs, k_vt_norm), hence the separate unit.
+#include <hip/hip_runtime.h>
+
+#include "../../include/ltrans_hip.h"
+#define LT_KERNELS_RK_ONLY
+#include "lt_kernels.h"
+#include "lt_rk_launch.h"
+
+namespace ltd {
+
+template <typename SlabT>
+static void launch_k_rk_t(int Vtransform, unsigned grid, unsigned dynlds, hipStream_t stream, const StepParams& P) {
+  switch (Vtransform) {
+    case 1: hipLaunchKernelGGL((k_rk<SlabT, 1, LT_RK_WAVES>), dim3(grid), dim3(LT_RK_BLOCK), dynlds, stream, P); break;
+    case 2: hipLaunchKernelGGL((k_rk<SlabT, 2, LT_RK_WAVES>), dim3(grid), dim3(LT_RK_BLOCK), dynlds, stream, P); break;
+    default: hipLaunchKernelGGL((k_rk<SlabT, 3, LT_RK_WAVES>), dim3(grid), dim3(LT_RK_BLOCK), dynlds, stream, P); break;
+  }
+}
+
+void launch_k_rk(bool f32, int Vtransform, unsigned grid, unsigned dynlds, hipStream_t stream, const StepParams& P) {
+  if (f32) launch_k_rk_t<float>(Vtransform, grid, dynlds, stream, P);
+  else launch_k_rk_t<double>(Vtransform, grid, dynlds, stream, P);
+}
+
+#ifdef LT_RK_TIMING
+void rk_timing_fetch(unsigned long long* out16, bool reset) {
+  hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_tim), 128);
+  if (reset) {
+    const unsigned long long z[16] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_tim), z, 128);
+  }
+}
+#endif
+
+}  // namespace ltd
