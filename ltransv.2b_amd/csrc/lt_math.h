@@ -615,11 +615,23 @@ LT_DEV bool sigs_candidate(double S, double S1, double S2, double& num, double& 
   return (D1 * D2 > 0.0) && ((ab ? a : b) > 2.0 * (ab ? b : a));
 }
 
+// Lane conditions as 64-bit lane masks -- what a vector compare writes -- combined with scalar instructions
+// (k_rk's pass A).  lm() must be evaluated with every lane of the wave active; lm_lane() is the lane's own bit.
+typedef unsigned long long LaneMask;
+LT_DEV LaneMask lm(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+LT_DEV bool lm_lane(LaneMask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
 // the test alone (the operands of the quotient are formed only for the few candidates)
 LT_DEV bool sigs_candidate_test(double S, double S1, double S2) {
   const double D1 = S - S1, D2 = S2 - S;
   const double a = fabs(D1), b = fabs(D2);
   return (D1 * D2 > 0.0) & (__builtin_fmax(a, b) > 2.0 * __builtin_fmin(a, b));
+}
+
+LT_DEV LaneMask sigs_candidate_mask(double S, double S1, double S2) {
+  const double D1 = S - S1, D2 = S2 - S;
+  const double a = fabs(D1), b = fabs(D2);
+  return lm(D1 * D2 > 0.0) & lm(__builtin_fmax(a, b) > 2.0 * __builtin_fmin(a, b));
 }
 
 // Screening of the EVALUATION interval: true = its tension factor is known
@@ -654,7 +666,22 @@ LT_DEV bool sigs_eval_zero(double S, double S1, double S2) {
   const double T0 = 3.0 * S - S1 - S2;
   const double D0 = T0 * T0 - S1 * S2;
   const bool nconv_zero = (S1 * S < 0.0) | (S2 * S < 0.0) | (D0 <= 0.0) | (S * T0 >= 0.0);
-  return !inf_t & ((D1D2 >= 0.0) ? conv_zero : nconv_zero);
+  const bool conv = D1D2 >= 0.0;
+  return !inf_t & ((conv & conv_zero) | (!conv & nconv_zero));
+}
+
+// (the same as lane masks)
+LT_DEV LaneMask sigs_eval_zero_mask(double S, double S1, double S2) {
+  const double D1 = S - S1, D2 = S2 - S, D1D2 = D1 * D2;
+  const LaneMask d0 = lm(D1D2 == 0.0);
+  const LaneMask inf_t = (d0 & lm(S1 != S2)) | (lm(S == 0.0) & lm(S1 * S2 > 0.0));
+  const double a = fabs(D1), b = fabs(D2);
+  const LaneMask conv_zero = d0 | lm(__builtin_fmax(a, b) <= 2.0 * __builtin_fmin(a, b));
+  const double T0 = 3.0 * S - S1 - S2;
+  const double D0 = T0 * T0 - S1 * S2;
+  const LaneMask nconv_zero = lm(S1 * S < 0.0) | lm(S2 * S < 0.0) | lm(D0 <= 0.0) | lm(S * T0 >= 0.0);
+  const LaneMask conv = lm(D1D2 >= 0.0);
+  return ~inf_t & ((conv & conv_zero) | (~conv & nconv_zero));
 }
 
 // convexity Newton iteration, tension_module.f90:531-580.  Returns the tension
@@ -1050,6 +1077,33 @@ LT_DEV void quad_weights_outside(QuadWeights& w, double xp, double yp, double x1
   }
 }
 
+// the same for k_rk's fast path: the four weights divide by the same sum and the four distances are inverted --
+// twelve divisions' worth of scaling, reciprocal and fix-up steps, of which prep_div / div_prep keep the part that
+// acts on operands of ordinary magnitude (metres and their reciprocals: bit-identical to `/` there)
+LT_DEV void quad_weights_outside_f(QuadWeights& w, double xp, double yp, double x1, double x2, double x3, double x4,
+                                   double y1, double y2, double y3, double y4) {
+  const bool n1 = (xp == x1) & (yp == y1), n2 = (xp == x2) & (yp == y2), n3 = (xp == x3) & (yp == y3),
+             n4 = (xp == x4) & (yp == y4);
+  if (n1 || n2 || n3 || n4) {
+    w.regime = 4;
+    if (n1) { w.W1 = 1.0; w.node_hit = 1; }
+    if (n2) { w.W2 = 1.0; w.node_hit = 2; }
+    if (n3) { w.W3 = 1.0; w.node_hit = 3; }
+    if (n4) { w.W4 = 1.0; w.node_hit = 4; }
+  } else {
+    const double Dis1 = div_prep(1., prep_div(sqrt((x1 - xp) * (x1 - xp) + (y1 - yp) * (y1 - yp))));
+    const double Dis2 = div_prep(1., prep_div(sqrt((x2 - xp) * (x2 - xp) + (y2 - yp) * (y2 - yp))));
+    const double Dis3 = div_prep(1., prep_div(sqrt((x3 - xp) * (x3 - xp) + (y3 - yp) * (y3 - yp))));
+    const double Dis4 = div_prep(1., prep_div(sqrt((x4 - xp) * (x4 - xp) + (y4 - yp) * (y4 - yp))));
+    const Divisor dT = prep_div(Dis1 + Dis2 + Dis3 + Dis4);
+    w.W1 = div_prep(Dis1, dT);
+    w.W2 = div_prep(Dis2, dT);
+    w.W3 = div_prep(Dis3, dT);
+    w.W4 = div_prep(Dis4, dT);
+    w.regime = 3;
+  }
+}
+
 LT_DEV QuadWeights quad_weights(double xp, double yp, const double (&x)[4], const double (&y)[4]) {
   QuadWeights w;
   w.W1 = w.W2 = w.W3 = w.W4 = 0.0;
@@ -1087,7 +1141,7 @@ LT_DEV QuadWeights quad_weights_f(double xp, double yp, const double (&x)[4], co
     w.t = div_prep((xp - x3) * (y1 - y3) + (y3 - yp) * (x1 - x3), d);
     w.u = div_prep((xp - x3) * (y4 - y3) + (y3 - yp) * (x4 - x3), neg_div(d));
     w.regime = 2;
-    if (w.t < 0. || w.u < 0. || (w.t + w.u) > 1.0) quad_weights_outside(w, xp, yp, x1, x2, x3, x4, y1, y2, y3, y4);
+    if (w.t < 0. || w.u < 0. || (w.t + w.u) > 1.0) quad_weights_outside_f(w, xp, yp, x1, x2, x3, x4, y1, y2, y3, y4);
   }
   return w;
 }

@@ -87,6 +87,11 @@ LT_DEV double level_at(const LevCoef& q, double zeta, double h, int Vtransform) 
 #else
 #define TICKB(slot) do { } while (0)
 #endif
+#ifdef LT_RK_WAVETIME
+// development aid (tools/dev/rk_wavetime.py): start / end of every wave on the 100 MHz clock, its shader cycles
+__device__ unsigned long long g_wavetime[40000];
+__device__ unsigned long long g_wavecyc[20000];
+#endif
 #ifdef LT_RK_TIMING
 // development aid: wave time per section, accumulated in the wave's LDS scratch and
 // added to g_tim once at the end of the kernel
@@ -257,6 +262,7 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
     }
   }
   const bool spl = act && !zero && !loglayer;  // this lane fits splines
+  const LaneMask SPL = lm(spl);
   unsigned degenerate = 0;
   const double ixv = (version == 1) ? P.ix0 : (version == 2) ? P.ix1 : P.ix2;
   ws.errmask[lane] = 0;
@@ -373,8 +379,11 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
       }
       if (s < 2) request(s + 1);
       const double DX1 = X[1] - X[0], DX2 = X[2] - X[1], DX3 = X[3] - X[2];
-      const bool ok = spl & (DX1 > 0.0) & (DX2 > 0.0) & (DX3 > 0.0);
-      degenerate |= (spl & !ok) ? (1u << slot9) : 0u;
+      // Lane conditions are kept as 64-bit lane masks (LaneMask: the scalar result of a vector compare) and
+      // combined with scalar instructions; written as `bool`s the compiler turns every and-or of them into a
+      // select, which it builds in a vector register and compares back: ~18 vector instructions per slot.
+      const LaneMask OK = SPL & lm(DX1 > 0.0) & lm(DX2 > 0.0) & lm(DX3 > 0.0);
+      degenerate |= lm_lane(SPL & ~OK) ? (1u << slot9) : 0u;
       // YPC1 (tension_module.f90:852-977) with the chord slopes kept for SIGS/HVAL
       // (seven quotients over five divisors: the reciprocals are prepared once)
       const Divisor d1 = prep_div(DX1), d2 = prep_div(DX2), d3 = prep_div(DX3);
@@ -389,9 +398,8 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
       YP[3] = ypc1_end_b(SL[2], SL[2] + div_prep(DX3 * (SL[2] - SL[1]), d23));
       // the evaluation interval :1044-1053 (extrapolates with the end intervals)
       // (for strictly increasing knots "T > X(4) -> interval 3" is implied; other windows are redone by k_rk_slow)
-      const bool i1 = (Pzs < X[1]);
-      const bool i2 = !i1 & (Pzs < X[2]);
-      const int I = i1 ? 1 : i2 ? 2 : 3;
+      const LaneMask I1 = lm(Pzs < X[1]), I2 = ~I1 & lm(Pzs < X[2]), I3 = ~I1 & ~I2;
+      const bool i1 = lm_lane(I1), i2 = lm_lane(I2);
       const double x1 = i1 ? X[0] : i2 ? X[1] : X[2];
       const double x2 = i1 ? X[1] : i2 ? X[2] : X[3];
       const double y1 = i1 ? Y[0] : i2 ? Y[1] : Y[2];
@@ -406,21 +414,19 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
       // Only the evaluation interval's tension is used by HVAL; the other two
       // matter only through SigErr, which only the convexity Newton iteration
       // can raise, so they are queued just when they are Newton candidates.
-      const bool c0 = sigs_candidate_test(SL[0], YP[0], YP[1]) & ok;
-      const bool c1 = sigs_candidate_test(SL[1], YP[1], YP[2]) & ok;
-      const bool c2 = sigs_candidate_test(SL[2], YP[2], YP[3]) & ok;
+      const LaneMask C0 = sigs_candidate_mask(SL[0], YP[0], YP[1]), C1 = sigs_candidate_mask(SL[1], YP[1], YP[2]),
+                     C2 = sigs_candidate_mask(SL[2], YP[2], YP[3]);
       // the two non-evaluation intervals: I=1 -> (2,3), I=2 -> (1,3), I=3 -> (1,2)
-      const bool ca = i1 ? c1 : c0, cb = (I == 3) ? c1 : c2;
+      const LaneMask ma = OK & ((I1 & C1) | (~I1 & C0)), mb = OK & ((I3 & C1) | (~I3 & C2));
       // the evaluation interval: done here when its tension is known to be ZERO (the cubic form);
       // everything else (an iteration, or the rare known SBIG) goes to pass B
-      const bool neede = ok & !sigs_eval_zero(Sv, p1, p2);
-      const unsigned long long mc = __ballot(ca | cb), me = __ballot(neede);
+      const LaneMask me = OK & ~sigs_eval_zero_mask(Sv, p1, p2);
+      const LaneMask mc = ma | mb;
       const unsigned long long below = (1ull << lane) - 1ull;
       if (mc) {  // ~1 % of the intervals are candidates: the operands of T = MAX(D1/D2, D2/D1)
-        const unsigned long long ma = __ballot(ca), mb = __ballot(cb);
-        if (ca) {
+        if (lm_lane(ma)) {
           double na, da;
-          if (I == 1) (void)sigs_candidate(SL[1], YP[1], YP[2], na, da);
+          if (i1) (void)sigs_candidate(SL[1], YP[1], YP[2], na, da);
           else (void)sigs_candidate(SL[0], YP[0], YP[1], na, da);
           const int idx = nchk + __popcll(ma & below);
           if (idx < LT_CHK_CAP) {
@@ -429,9 +435,9 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
           } else degenerate |= (1u << slot9);
         }
         nchk += __popcll(ma);
-        if (cb) {
+        if (lm_lane(mb)) {
           double nb, db;
-          if (I == 3) (void)sigs_candidate(SL[1], YP[1], YP[2], nb, db);
+          if (lm_lane(I3)) (void)sigs_candidate(SL[1], YP[1], YP[2], nb, db);
           else (void)sigs_candidate(SL[2], YP[2], YP[3], nb, db);
           const int idx = nchk + __popcll(mb & below);
           if (idx < LT_CHK_CAP) {
@@ -441,7 +447,7 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
         }
         nchk += __popcll(mb);
       }
-      if (neede) {
+      if (lm_lane(me)) {
         const int idx = nev + __popcll(me & below);
         double* e = ws.ev[idx];
         e[0] = x1; e[1] = x2; e[2] = y1; e[3] = p1; e[4] = p2; e[5] = Sv; e[6] = Pzs;
@@ -839,6 +845,9 @@ void k_rk(const StepParams P) {
 #else
   const unsigned vb = blockIdx.x;
 #endif
+#ifdef LT_RK_WAVETIME
+  const unsigned long long wt0_ = wall_clock64(), wc0_ = __builtin_readcyclecounter();
+#endif
   const int n = (int)(vb * blockDim.x + threadIdx.x);
   const size_t N = (size_t)P.numpar;
   const bool act = (n < P.numpar) && ((P.ws_i[n] & FL_ACT) != 0);
@@ -927,6 +936,12 @@ void k_rk(const StepParams P) {
   unsigned v = (unsigned)sigerr_count;
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   if ((threadIdx.x & 63) == 0 && v) atomicAdd(&P.counters[CNT_SIGERR], (unsigned long long)v);
+#ifdef LT_RK_WAVETIME
+  if (threadIdx.x == 0 && vb < 20000u) {
+    g_wavetime[2 * vb] = wt0_; g_wavetime[2 * vb + 1] = wall_clock64();
+    g_wavecyc[vb] = __builtin_readcyclecounter() - wc0_;
+  }
+#endif
 }
 
 // ---- k_rk_slow: the particle-steps k_rk could not finish on its fast path

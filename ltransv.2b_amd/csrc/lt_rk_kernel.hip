@@ -46,3 +46,14 @@ void rk_timing_fetch(unsigned long long* out16, bool reset) {
 #endif
 
 }  // namespace ltd
+
+#ifdef LT_RK_WAVETIME
+extern "C" int lt_diag_wavetime(unsigned long long* out40000) {
+  hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(out40000, HIP_SYMBOL(ltd::g_wavetime), 40000 * 8);
+}
+extern "C" int lt_diag_wavecyc(unsigned long long* out20000) {
+  hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(out20000, HIP_SYMBOL(ltd::g_wavecyc), 20000 * 8);
+}
+#endif
