@@ -1088,6 +1088,9 @@ int lt_set_grid(lt_engine* e, const lt_grid* g) {
   // slabs: ALLOCATE + zero (hydrodynamic_module.f90:682-698)
   const size_t se = slab_elem(e);
   const size_t us = e->cfg.us, ws = e->cfg.ws;
+  // (k_rk addresses the velocity slabs by 32-bit byte offsets)
+  if ((size_t)std::max(std::max(e->u_nodes, e->v_nodes), e->rho_nodes) * ws * LT_SLOTS * se >= (size_t)0xfffff000u)
+    return fail(e, LT_ERR_UNSUPPORTED, "lt_set_grid: a velocity slab of 4 GiB or more (shard the grid, or LT_SLAB_F32)");
   TRY(dev_alloc(e, e->U, (size_t)e->u_nodes * us * LT_SLOTS * se));
   TRY(dev_alloc(e, e->V, (size_t)e->v_nodes * us * LT_SLOTS * se));
   TRY(dev_alloc(e, e->W, (size_t)e->rho_nodes * ws * LT_SLOTS * se));

@@ -50,6 +50,17 @@ LT_DEV Quad load_quad_xy(const XYNode* nodes, int4 n) {
   q.x[2] = c.x; q.y[2] = c.y; q.x[3] = d.x; q.y[3] = d.y;
   return q;
 }
+// the same for k_rk: one 16-byte load per node at a 32-bit offset from the (uniform) base of the table, where
+// the 8-byte-aligned struct reads above are two loads each at a 64-bit address formed per lane
+LT_DEV Quad load_quad16(const void* nodes, int4 n, unsigned stride) {
+  const char* b = (const char*)nodes;
+  const double2 p0 = *(const double2*)(b + (unsigned)(n.x - 1) * stride), p1 = *(const double2*)(b + (unsigned)(n.y - 1) * stride);
+  const double2 p2 = *(const double2*)(b + (unsigned)(n.z - 1) * stride), p3 = *(const double2*)(b + (unsigned)(n.w - 1) * stride);
+  Quad q;
+  q.x[0] = p0.x; q.y[0] = p0.y; q.x[1] = p1.x; q.y[1] = p1.y;
+  q.x[2] = p2.x; q.y[2] = p2.y; q.x[3] = p3.x; q.y[3] = p3.y;
+  return q;
+}
 LT_DEV Quad load_quad_rho(const RhoNode* nodes, int4 n) {
   Quad q;
   q.x[0] = nodes[n.x - 1].x; q.y[0] = nodes[n.x - 1].y;

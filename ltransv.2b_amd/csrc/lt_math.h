@@ -621,6 +621,11 @@ typedef unsigned long long LaneMask;
 LT_DEV LaneMask lm(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 LT_DEV bool lm_lane(LaneMask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
+// exchange of two vector registers
+LT_DEV void reg_swap(float& a, float& b) { asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+LT_DEV void reg_swap(unsigned& a, unsigned& b) { asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+LT_DEV void reg_swap(double& a, double& b) { const double t = a; a = b; b = t; }
+
 // the test alone (the operands of the quotient are formed only for the few candidates)
 LT_DEV bool sigs_candidate_test(double S, double S1, double S2) {
   const double D1 = S - S1, D2 = S2 - S;
@@ -1136,12 +1141,13 @@ LT_DEV QuadWeights quad_weights_f(double xp, double yp, const double (&x)[4], co
     w.u = div_prep((xp - x1) * (y2 - y1) + (y1 - yp) * (x2 - x1), neg_div(d));
   }
   w.regime = 1;
-  if (w.t < 0. || w.u < 0. || (w.t + w.u) > 1.0) {
+  // (the three comparisons as lane masks: written with || the compiler forms min(t, u) first, quieting both operands)
+  if (lm_lane(lm(w.t < 0.) | lm(w.u < 0.) | lm((w.t + w.u) > 1.0))) {
     const Divisor d = prep_div((x4 - x3) * (y1 - y3) - (y4 - y3) * (x1 - x3));
     w.t = div_prep((xp - x3) * (y1 - y3) + (y3 - yp) * (x1 - x3), d);
     w.u = div_prep((xp - x3) * (y4 - y3) + (y3 - yp) * (x4 - x3), neg_div(d));
     w.regime = 2;
-    if (w.t < 0. || w.u < 0. || (w.t + w.u) > 1.0) quad_weights_outside_f(w, xp, yp, x1, x2, x3, x4, y1, y2, y3, y4);
+    if (lm_lane(lm(w.t < 0.) | lm(w.u < 0.) | lm((w.t + w.u) > 1.0))) quad_weights_outside_f(w, xp, yp, x1, x2, x3, x4, y1, y2, y3, y4);
   }
   return w;
 }

@@ -293,15 +293,17 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
     // The 16 field values (4 nodes x 4 levels) of a time slot -- one 16-byte access per node in
     // the level-fastest layout -- its zeta and its depth are requested one slot ahead of their
     // use, into the registers the previous slot's values just left.
-    const SlabT* b0 = F + (size_t)(nd.x - 1) * LT_SLOTS * L + (k0 - 1);
-    const SlabT* b1 = F + (size_t)(nd.y - 1) * LT_SLOTS * L + (k0 - 1);
-    const SlabT* b2 = F + (size_t)(nd.z - 1) * LT_SLOTS * L + (k0 - 1);
-    const SlabT* b3 = F + (size_t)(nd.w - 1) * LT_SLOTS * L + (k0 - 1);
+    // (32-bit byte offsets from the slab's base -- lt_set_grid refuses a slab of 4 GiB: a scalar base and a vector
+    // offset are what a global load takes; 64-bit pointers per node cost ten vector instructions each to form)
+    const unsigned esz = (unsigned)sizeof(SlabT), rowb = (unsigned)(LT_SLOTS * L) * esz, kb = (unsigned)(k0 - 1) * esz;
+    unsigned e0 = (unsigned)(nd.x - 1) * rowb + kb, e1 = (unsigned)(nd.y - 1) * rowb + kb;
+    unsigned e2 = (unsigned)(nd.z - 1) * rowb + kb, e3 = (unsigned)(nd.w - 1) * rowb + kb;
+    const char* Fb = (const char*)F;
     auto request = [&](int s) {
       const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
-      const int o = ps * L;
-      const Win4<SlabT> q0 = *(const Win4<SlabT>*)(b0 + o), q1 = *(const Win4<SlabT>*)(b1 + o);
-      const Win4<SlabT> q2 = *(const Win4<SlabT>*)(b2 + o), q3 = *(const Win4<SlabT>*)(b3 + o);
+      const unsigned o = (unsigned)(ps * L) * esz;
+      const Win4<SlabT> q0 = *(const Win4<SlabT>*)(Fb + (e0 + o)), q1 = *(const Win4<SlabT>*)(Fb + (e1 + o));
+      const Win4<SlabT> q2 = *(const Win4<SlabT>*)(Fb + (e2 + o)), q3 = *(const Win4<SlabT>*)(Fb + (e3 + o));
 #pragma unroll
       for (int l = 0; l < 4; l++) {
         raw[4 * l + 0] = q0.v[l]; raw[4 * l + 1] = q1.v[l];
@@ -312,9 +314,9 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
     };
     request(0);
     Quad q;
-    if (var == 2) q = load_quad_rho(P.rnode, nd);
-    else if (var == 0) q = load_quad_xy(P.unode, nd);
-    else q = load_quad_xy(P.vnode, nd);
+    if (var == 2) q = load_quad16(P.rnode, nd, (unsigned)sizeof(RhoNode));
+    else if (var == 0) q = load_quad16(P.unode, nd, (unsigned)sizeof(XYNode));
+    else q = load_quad16(P.vnode, nd, (unsigned)sizeof(XYNode));
     if (var == 0) nd_next = P.VE[ev_ - 1];
     else if (var == 1) nd_next = P.RE[er - 1];
     const QuadWeights w = quad_weights_f(Xs, Ys, q.x, q.y);
@@ -323,16 +325,10 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
     // interpolations of this variable, the node order itself is rotated once: the values of
     // slot 0 (already requested) with one select each on the stored type, the base pointers
     // for the two later requests.  Regimes 3 / 4 (inverse distance, on a node) keep (1,2,3,4).
-    {
-      const bool rot = (w.regime == 2);
+    if (w.regime == 2) {   // (register swaps: v_swap_b32, which the compiler does not use, is one instruction per pair)
 #pragma unroll
-      for (int l = 0; l < 4; l++) {
-        const SlabT r0 = raw[4 * l + 0], r1 = raw[4 * l + 1];
-        raw[4 * l + 0] = rot ? raw[4 * l + 2] : r0; raw[4 * l + 1] = rot ? raw[4 * l + 3] : r1;
-        raw[4 * l + 2] = rot ? r0 : raw[4 * l + 2]; raw[4 * l + 3] = rot ? r1 : raw[4 * l + 3];
-      }
-      const SlabT *t0 = b0, *t1 = b1;
-      b0 = rot ? b2 : b0; b1 = rot ? b3 : b1; b2 = rot ? t0 : b2; b3 = rot ? t1 : b3;
+      for (int l = 0; l < 4; l++) { reg_swap(raw[4 * l + 0], raw[4 * l + 2]); reg_swap(raw[4 * l + 1], raw[4 * l + 3]); }
+      reg_swap(e0, e2); reg_swap(e1, e3);
     }
 #ifdef LT_RK_TIMING
     { const unsigned long long m3 = __ballot(spl && w.regime >= 3); if (lane == 0) ws.tim[7] += __popcll(m3) + ((m3 != 0) ? (1ull << 32) : 0ull); }
