@@ -602,6 +602,27 @@ LT_DEV int sigs_classify(double S, double S1, double S2, double& sigma, double& 
   return SIGK_SECANT;
 }
 
+// The same classification without its quotient: want_T = the interval is convex with |big| > 2 |small|, and
+// num / den are the operands of T = MAX(D1/D2, D2/D1); the caller divides (pass B of k_rk forms the quotients of
+// its evaluation and check intervals with ONE division) and decides T <= 2 -> SIGK_DONE, else SIGK_NEWTON.
+// Without want_T the returned kind is final.  Straight-line: every comparison is evaluated.
+LT_DEV int sigs_classify_nd(double S, double S1, double S2, double& sigma, double& num, double& den, bool& want_T) {
+  const double D1 = S - S1, D2 = S2 - S, D1D2 = D1 * D2;
+  const bool sbig = ((D1D2 == 0.0) & (S1 != S2)) | ((S == 0.0) & (S1 * S2 > 0.0));
+  const bool convex = D1D2 >= 0.0;
+  const double a = fabs(D1), b = fabs(D2);
+  const bool ab = a > b;
+  const double big = ab ? a : b, small = ab ? b : a;
+  want_T = !sbig & convex & !(D1D2 == 0.0) & !(big <= 2.0 * small);
+  num = ab ? D1 : D2;
+  den = ab ? D2 : D1;
+  const double T0 = 3.0 * S - S1 - S2;
+  const double D0 = T0 * T0 - S1 * S2;
+  const bool nc_done = (S1 * S < 0.0) | (S2 * S < 0.0) | (D0 <= 0.0) | (S * T0 >= 0.0);
+  sigma = sbig ? LT_SBIG : 0.0;
+  return (sbig | convex | nc_done) ? SIGK_DONE : SIGK_SECANT;
+}
+
 // Division-free screening of one SIGS interval.  Newton CANDIDATE: the data
 // are convex on the interval (D1*D2 > 0) and the larger second difference
 // exceeds twice the smaller, i.e. T = MAX(D1/D2,D2/D1) is not certainly <= 2.
@@ -836,6 +857,84 @@ LT_DEV void sigs_newton_k(const double (&T)[K], const bool (&need)[K], double (&
     const double v = dmin(SIG[j], SBIG);
     sg[j] = (failed[j] | !(v > 0.0)) ? 0.0 : v;
   }
+}
+
+// sigs_newton_k<1> for a whole wave, one task per lane, with the lane conditions (live, failed, the stopping
+// tests) as lane masks: loop-carried booleans are otherwise kept as 0 / 1 in vector registers and rebuilt with a
+// select and a compare in every trip.  Same operations on the same operands, the same cycle detection.  NEED: the
+// lanes with a task.  The operands of the two quotients are selected only in the trips in which a live task is at
+// SIG <= .5 (a minority): otherwise they are the exponential form's.
+LT_DEV void sigs_newton_w(double T, LaneMask NEED, double& sg, LaneMask& FAILED) {
+  const double SBIG = LT_SBIG, RTOL = LT_SIGS_RTOL, FTOL = 0.0;
+  const double P1 = -3.51754964808151394800e5, P2 = -1.15614435765005216044e4,
+               P3 = -1.63725857525983828727e2, P4 = -7.89474443963537015605e-1;
+  const double Q1 = -2.11052978884890840399e6, Q2 = 3.61578279834431989373e4,
+               Q3 = -2.77711081420602794433e2, Q4 = 1.0;
+  const double TP1 = T + 1.0;
+  double SIG = lm_lane(NEED) ? sqrt(10.0 * T - 20.0) : 1.0;
+  double mark = 0.0;
+  int power = 1, lam = 0;
+  LaneMask LIVE = NEED;
+  FAILED = 0ull;
+  int NIT = 0;
+  for (;;) {
+    NIT = NIT + 1;
+    const double s = SIG;
+    const LaneMask SMALL = lm(s <= .5);
+    const bool any_small = (SMALL & LIVE) != 0ull;
+    // the exponential form
+    double EMS = exp_core((s < 512.0) ? -s : 0.0);
+    if (s >= 512.0) EMS = lt_exp(-s);  // T > 26000: rare
+    double den = 1.0 - EMS * (EMS + s + s);        // SSM
+    double n1 = (1.0 - EMS) * (1.0 - EMS);         // TM
+    double n2 = 2.0 * s * EMS;                     // N2
+    if (any_small) {
+      // SNHCSH, |X| <= .5 (tension_module.f90:822-834)
+      const double XS = s * s, XC = s * XS;
+      double Pp = ((P4 * XS + P3) * XS + P2) * XS + P1;
+      double Qq = ((Q4 * XS + Q3) * XS + Q2) * XS + Q1;
+      const double SINHM = XC * (Pp / Qq);
+      const double XSD4 = .25 * XS, XSD2 = XSD4 + XSD4;
+      Pp = ((P4 * XSD4 + P3) * XSD4 + P2) * XSD4 + P1;
+      Qq = ((Q4 * XSD4 + Q3) * XSD4 + Q2) * XSD4 + Q1;
+      const double Fc = XSD4 * (Pp / Qq);
+      const double COSHMM = XSD2 * Fc * (Fc + 2.0);
+      const double COSHM = COSHMM + XSD2;
+      const bool small = lm_lane(SMALL);
+      den = small ? SINHM : den;
+      n1 = small ? COSHM : n1;
+      n2 = small ? s : n2;
+    }
+    const Divisor ds = prep_div(den);
+    const double T1 = div_prep(n1, ds);
+    const double FP = T1 + s * (div_prep(n2, ds) - T1 * T1 + 1.0);
+    const double F = s * T1 - TP1;
+    const bool capped = NIT > 10000;
+    // (FP is of order one where the step is used -- FP <= 0 stops the iteration -- and F is a rounded
+    // difference of such numbers or zero: the prepared-divisor quotient is the value of -F / FP, lt_math.h above)
+    const double DSIG = div_prep(-F, prep_div(FP));
+    const LaneMask STOP = lm(FP <= 0.0) | lm(fabs(DSIG) <= RTOL * s) | (lm(F >= 0.0) & lm(F <= FTOL)) | lm(fabs(F) <= RTOL);
+    const LaneMask ADV = capped ? 0ull : (LIVE & ~STOP);
+    const double nx = s + DSIG;
+    // Cycle detection (NewtonCycle) for a task that moves on, from the 8th step (sigs_newton_k)
+    LaneMask REP = ADV & lm(nx != nx);
+    if (NIT == LT_NEWTON_CYC_START) {
+      mark = nx; power = 1; lam = 0;
+    } else if (NIT > LT_NEWTON_CYC_START) {
+      REP = REP | (ADV & lm(nx == mark));
+      const LaneMask ROLL = ADV & ~REP & lm(lam + 1 == power);
+      const bool roll = lm_lane(ROLL);
+      lam = roll ? 0 : (lm_lane(ADV) ? lam + 1 : lam);
+      mark = roll ? nx : mark;
+      power = roll ? (power << 1) : power;
+    }
+    FAILED = FAILED | (capped ? LIVE : 0ull) | REP;
+    SIG = lm_lane(ADV) ? nx : s;
+    LIVE = ADV & ~REP;
+    if (LIVE == 0ull) break;
+  }
+  const double v = dmin(SIG, SBIG);
+  sg = (lm_lane(FAILED) | !(v > 0.0)) ? 0.0 : v;
 }
 
 // monotonicity secant iteration, tension_module.f90:638-760 (out of line: rare)

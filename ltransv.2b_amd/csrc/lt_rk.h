@@ -149,32 +149,54 @@ LT_DEV void run_task_batch(WaveScratch& ws, int nev, int total, int t0) {
     is_ev[j] = t < nev;
     tq[j] = is_ev[j] ? t : (valid[j] ? t - nev : 0);
     o[j] = is_ev[j] ? ws.ev_owner[tq[j]] : ws.chk_owner[tq[j]];
-    sg[j] = 0.0; T[j] = 0.0;
+    sg[j] = 0.0;
     kind[j] = SIGK_DONE;
+    // the quotient T = MAX(D1/D2, D2/D1) of an evaluation interval (full SIGS decision) and of a check
+    // interval (only the convergence of its Newton iteration matters): one division for both kinds
+    double num = 0.0, den = 1.0;
+    bool want_T = false;
     if (is_ev[j]) {
-      // the evaluation interval: full SIGS decision
       const double* e = ws.ev[tq[j]];
-      kind[j] = sigs_classify(e[5], e[3], e[4], sg[j], T[j]);
+      kind[j] = sigs_classify_nd(e[5], e[3], e[4], sg[j], num, den, want_T);
     } else if (valid[j]) {
-      // a non-evaluation interval: only the convergence of its Newton iteration matters
-      T[j] = ws.chk[tq[j]][0] / ws.chk[tq[j]][1];
-      kind[j] = (T[j] > 2.0) ? SIGK_NEWTON : SIGK_DONE;
+      num = ws.chk[tq[j]][0]; den = ws.chk[tq[j]][1];
+      want_T = true;
     }
+    if (!want_T) { num = 0.0; den = 1.0; }
+    T[j] = num / den;
+    // (SIGS' own test is T <= 2 -> done, the check interval's was queued as T > 2 -> iterate: a NaN differs)
+    if (want_T) kind[j] = (is_ev[j] ? !(T[j] <= 2.0) : (T[j] > 2.0)) ? SIGK_NEWTON : SIGK_DONE;
     need[j] = kind[j] == SIGK_NEWTON;
   }
-  double sgn[K];
   TICKB(20);
-  sigs_newton_k<K>(T, need, sgn, failed);
-  TICKB(21);
-#pragma unroll
-  for (int j = 0; j < K; ++j) {
-    if (need[j]) sg[j] = sgn[j];
-    else if (kind[j] == SIGK_SECANT) sg[j] = sigs_secant(ws.ev[tq[j]][5], ws.ev[tq[j]][3], ws.ev[tq[j]][4]);  // rare
-    if (is_ev[j]) {
-      const double* e = ws.ev[tq[j]];
-      ws.res[o[j] >> 6][o[j] & 63] = hval_interval_s(e[6], e[0], e[1], e[2], e[3], e[4], e[5], sg[j]);
+  if (K == 1) {
+    // one task per lane: the wave version with the lane conditions as lane masks (lt_math.h)
+    double sgn;
+    LaneMask FAILED;
+    const LaneMask NEED = lm(need[0]);
+    sigs_newton_w(T[0], NEED, sgn, FAILED);
+    TICKB(21);
+    if (need[0]) sg[0] = sgn;
+    else if (kind[0] == SIGK_SECANT) sg[0] = sigs_secant(ws.ev[tq[0]][5], ws.ev[tq[0]][3], ws.ev[tq[0]][4]);  // rare
+    if (is_ev[0]) {
+      const double* e = ws.ev[tq[0]];
+      ws.res[o[0] >> 6][o[0] & 63] = hval_interval_s(e[6], e[0], e[1], e[2], e[3], e[4], e[5], sg[0]);
     }
-    if (need[j] && failed[j]) atomicOr(&ws.errmask[o[j] & 63], 1u << (o[j] >> 6));
+    if (lm_lane(NEED & FAILED)) atomicOr(&ws.errmask[o[0] & 63], 1u << (o[0] >> 6));
+  } else {
+    double sgn[K];
+    sigs_newton_k<K>(T, need, sgn, failed);
+    TICKB(21);
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      if (need[j]) sg[j] = sgn[j];
+      else if (kind[j] == SIGK_SECANT) sg[j] = sigs_secant(ws.ev[tq[j]][5], ws.ev[tq[j]][3], ws.ev[tq[j]][4]);  // rare
+      if (is_ev[j]) {
+        const double* e = ws.ev[tq[j]];
+        ws.res[o[j] >> 6][o[j] & 63] = hval_interval_s(e[6], e[0], e[1], e[2], e[3], e[4], e[5], sg[j]);
+      }
+      if (need[j] && failed[j]) atomicOr(&ws.errmask[o[j] & 63], 1u << (o[j] >> 6));
+    }
   }
   TICKB(22);
 }

@@ -514,16 +514,17 @@ __global__ __launch_bounds__(256) void k_vt_sigs(const StepParams P) {
     const double S = Q.S[ti], S1 = Q.S1[ti], S2 = Q.S2[ti];
     const unsigned wl = Q.wl[ti];
     double sg = 0.0;
-    double T[1] = {0.0}, sgn[1];
-    const int kind = have ? sigs_classify(S, S1, S2, sg, T[0]) : SIGK_DONE;
-    const bool need[1] = {kind == SIGK_NEWTON};
-    bool failed[1];
-    sigs_newton_k<1>(T, need, sgn, failed);      // the whole wave, lanes without a Newton task idle in it
-    if (need[0]) sg = sgn[0];
+    double T = 0.0, sgn;
+    const int kind = have ? sigs_classify(S, S1, S2, sg, T) : SIGK_DONE;
+    const bool need = kind == SIGK_NEWTON;
+    const LaneMask NEED = lm(need);
+    LaneMask FAILED;
+    sigs_newton_w(T, NEED, sgn, FAILED);      // the whole wave, lanes without a Newton task idle in it
+    if (need) sg = sgn;
     else if (kind == SIGK_SECANT) sg = sigs_secant(S, S1, S2);
     if (have) {
       P.vt_tab[((size_t)wave * (size_t)p2 + (wl >> 6)) * VT_TS + (wl & 63u)].w = sg;
-      if (need[0] && failed[0]) atomicOr(&P.ws_i[(size_t)wave * 64 + (wl & 63u)], (int)FL_VT_SIGERR);
+      if (lm_lane(NEED & FAILED)) atomicOr(&P.ws_i[(size_t)wave * 64 + (wl & 63u)], (int)FL_VT_SIGERR);
     }
   }
   if (lane == 0 && rounds) atomicAdd(&P.counters[CNT_VT_ROUNDS], (unsigned long long)rounds);
