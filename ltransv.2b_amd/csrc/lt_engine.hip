@@ -2035,6 +2035,16 @@ int lt_test_leaf(int32_t kind, const double* in, int32_t n, int32_t in_per_item,
   return rc == hipSuccess ? LT_OK : LT_ERR_DEVICE;
 }
 
+/* test aid: the cursor of the engine's stream moved on by `nwords` as if that many words had been drawn (a run that
+ * has been going for thousands of steps): the next draws are generated from there. */
+int lt_test_rng_skip(lt_engine* e, uint64_t nwords) {
+  if (!e) return LT_ERR_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  if (!e->rng_ready) TRY(rng_init_device(e));
+  e->rng_cur += nwords;
+  return LT_OK;
+}
+
 /* test aid (device): n tempered words of the engine's stream starting `offset` words
  * after the cursor, read back from the materialised ring. */
 int lt_test_mt_ring(lt_engine* e, uint64_t offset, int32_t n, uint32_t* out) {

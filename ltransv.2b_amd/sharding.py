@@ -28,10 +28,12 @@ def shard_sizes(numpar, world):
             for r in range(world)]
 
 
-def allgather_positions(dist, torch, local_xyz, numpar_global, world, rank):
+def allgather_positions(dist, torch, local_xyz, numpar_global, world, rank, sizes=None):
     """local_xyz: tensor (3*n_local,) = xyz(n_local,3) column-major of this shard.
-    Returns a (numpar_global, 3) tensor in global particle order on every rank."""
-    sizes = shard_sizes(numpar_global, world)
+    Returns a (numpar_global, 3) tensor in global particle order on every rank.
+    sizes: the shards' particle counts when they are not shard_sizes() (ragged or empty shards)."""
+    sizes = shard_sizes(numpar_global, world) if sizes is None else [int(m) for m in sizes]
+    assert len(sizes) == world and sum(sizes) == numpar_global
     nmax = max(sizes)
     send = local_xyz.new_zeros(3 * nmax)
     n = sizes[rank]
