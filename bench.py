@@ -151,6 +151,29 @@ def launch_children(args):
     return 0
 
 
+_LINE_FD = None
+
+
+def claim_stdout():
+    """The process's stdout carries ONE thing: rank 0's JSON line.  Whatever else a rank or a library under it writes
+    to file descriptor 1 -- gloo's and RCCL's banners, warnings of the runtime -- goes to stderr instead: fd 1 is
+    kept aside for the line and replaced by a copy of fd 2.  (Under torch.distributed.run the ranks share the
+    launcher's stdout, so every rank does this, not only rank 0.)"""
+    global _LINE_FD
+    if _LINE_FD is None:
+        sys.stdout.flush()
+        _LINE_FD = os.dup(1)
+        os.dup2(2, 1)
+    return _LINE_FD
+
+
+def emit_line(obj):
+    data = (json.dumps(obj) + "\n").encode()
+    fd = claim_stdout()
+    while data:
+        data = data[os.write(fd, data):]
+
+
 def selftest_launch(args, world, rank):
     """the launcher alone (CPU, gloo): rendezvous, one collective, rank 0's line"""
     import torch
@@ -164,7 +187,7 @@ def selftest_launch(args, world, rank):
     if args.selftest_launch == "fail" and rank == world - 1:
         return 3
     if rank == 0:
-        print(json.dumps({"selftest": "launch", "n_gpus": world, "sum_ok": bool(ok)}))
+        emit_line({"selftest": "launch", "n_gpus": world, "sum_ok": bool(ok)})
     return 0 if ok else 4
 
 
@@ -464,6 +487,7 @@ def main():
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         return launch_children(args)                     # before anything touches torch.cuda / HIP
+    claim_stdout()                                       # before any library can write to it
     world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -828,7 +852,7 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         out["config"]["total_s"] = time.perf_counter() - t_start
-        print(json.dumps(out))
+        emit_line(out)
     return 0
 
 

@@ -22,14 +22,26 @@ def _run(args, env_extra=None, timeout=600):
 
 
 def _json_line(stdout):
-    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, stdout
-    return json.loads(lines[0])
+    """the WHOLE standard output is one JSON line (library banners of any rank go to stderr: bench.claim_stdout)"""
+    assert stdout.endswith("\n") and stdout.count("\n") == 1, stdout[:2000]
+    return json.loads(stdout)
 
 
 def test_launcher_starts_n_ranks_and_relays_rank0():
     r = _run(["--gpus", "2", "--selftest-launch", "ok"])
     assert r.returncode == 0, r.stderr
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["sum_ok"] is True
+
+
+def test_under_torchrun_the_whole_stdout_is_one_json_line():
+    """the way the driver starts N > 1: python -m torch.distributed.run ... bench.py --gpus N.  The ranks share the
+    launcher's stdout; gloo's "[Gloo] Rank r is connected ..." banner of every rank must not land in it."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29613", BENCH, "--gpus", "2",
+                        "--selftest-launch", "ok"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["sum_ok"] is True
 
