@@ -642,10 +642,21 @@ def main():
         e.profile_begin(args.steps)
         wall, upload_s = timed_steps(st, args.steps, one_step, fence)
         k_ms, k_n = e.profile_end()
-        stats = e.counters()      # (fails if a static stream window did not hold)
-        if static_window and stats["active"] != n:
-            sys.stderr.write(f"bench.py: static stream window, but {stats['active']} of {n} particles were tracked\n")
-            return 3, None
+        # (a rank that fails here must not leave the others waiting in the collectives below: the verdict is the job's)
+        rc_local, stats = 0, None
+        try:
+            stats = e.counters()      # (fails if a static stream window did not hold)
+            if static_window and stats["active"] != n:
+                sys.stderr.write(f"bench.py: rank {rank}: static stream window, but {stats['active']} of {n} particles were tracked\n")
+                rc_local = 3
+        except Exception as ex:       # noqa: BLE001 -- reported, then every rank leaves together
+            sys.stderr.write(f"bench.py: rank {rank}: {ex}\n")
+            rc_local = 3
+        rc_t = torch.tensor([rc_local], dtype=torch.int64, device=coll_dev)
+        if world > 1:
+            dist.all_reduce(rc_t, op=dist.ReduceOp.MAX)
+        if int(rc_t.item()) != 0:
+            return int(rc_t.item()), None
         # what a device-side re-sort of the particle order costs (one every 32 steps inside lt_step): if none has
         # happened yet, a few untimed steps more until one has
         resort_ms = stats["last_resort_ms"] if stats["resorts"] else None
@@ -777,17 +788,26 @@ def main():
             # said so) when the run has already used more than --single-ref-budget seconds; --no-single-ref skips it.
             # (the other ranks hand their shards over through files in the node's temporary directory: generating
             # them again on rank 0 took longer than everything else together)
+            # (a directory rank 0 makes for this run -- mkdtemp: unpredictable name, owner-only -- and removes again)
+            import shutil
             import tempfile
-            shard_dir = os.path.join(tempfile.gettempdir(), "ltbench_%s" % os.environ.get("MASTER_PORT", "0"))
-            if rank > 0:
-                os.makedirs(shard_dir, exist_ok=True)
+            box = [tempfile.mkdtemp(prefix="ltbench_") if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            shard_dir = box[0]
+            seen = torch.tensor([1 if os.path.isdir(shard_dir) else 0], dtype=torch.int64, device=coll_dev)
+            dist.all_reduce(seen, op=dist.ReduceOp.MIN)
+            same_node = int(seen.item()) == 1      # (ranks on another node do not see rank 0's directory)
+            if rank > 0 and same_node:
                 np.savez(os.path.join(shard_dir, f"rank{rank}.npz"), **parts)
             torch.cuda.synchronize()
             dist.barrier()
             elapsed = time.perf_counter() - t_start
-            if rank == 0 and elapsed > args.single_ref_budget:
+            if rank == 0 and not same_node:
+                out["config"]["single_gpu_same_workload"] = {"skipped": "the ranks do not share a node"}
+            elif rank == 0 and elapsed > args.single_ref_budget:
                 out["config"]["single_gpu_same_workload"] = {"skipped": f"{elapsed:.0f} s used, budget {args.single_ref_budget} s"}
             elif rank == 0:
+              try:
                 t_ref = time.perf_counter()
                 shards = [parts]
                 for r in range(1, world):
@@ -814,13 +834,14 @@ def main():
                     "note": "all the particles on rank 0's GPU alone, no all-gather",
                     "wall_s_incl_setup": time.perf_counter() - t_ref}
                 e1.close()
+              except Exception as ex:    # noqa: BLE001 -- the reference point is an extra: the line goes out without it
+                sys.stderr.write(f"bench.py: single-GPU reference failed: {ex}\n")
+                out["config"]["single_gpu_same_workload"] = {"skipped": f"failed: {ex}"}
+              finally:
+                shutil.rmtree(shard_dir, ignore_errors=True)
             dist.barrier()
-            if rank > 0:
-                try:
-                    os.remove(os.path.join(shard_dir, f"rank{rank}.npz"))
-                    os.rmdir(shard_dir)
-                except OSError:
-                    pass
+            if rank == 0:
+                shutil.rmtree(shard_dir, ignore_errors=True)
 
         if main_line and rank == 0 and world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ltrans_amd, args, spec, g, geo, bounds, records)

@@ -45,6 +45,7 @@ program ltrans_hip_driver
   double precision :: z0, constZeta, constSalt, constTemp, constU, constV, constW, constAks, constDens
   logical :: readZeta, readSalt, readTemp, readU, readV, readW, readAks, readDens
   logical :: HTurbOn, VTurbOn
+  logical :: late_release
   double precision :: ConstantHTurb
   integer :: Behavior
   logical :: OpenOceanBoundary, mortality
@@ -206,6 +207,9 @@ program ltrans_hip_driver
   if (maxisland > 0) read(2) hx(1:maxisland), hy(1:maxisland), hid(1:maxisland)
   read(2) par, P_r_element, P_u_element, P_v_element
   allocate(zeta(rho_nodes), Uvel(u_nodes,us), Vvel(v_nodes,us), Wvel(rho_nodes,ws), Kh(rho_nodes,ws))
+  ! (a particle of ANY rank that is released later -- LTRANS.f90:790: ix(3) <= par(n,pDOB) -> cycle, before any
+  ! draw -- does not draw until then: the draw counts of the job change during the run)
+  late_release = any(par(:,11) > 0.0_c_double)
   ! ---- this rank's contiguous block of the particles (everything below sees numpar = the shard)
   numpar_global = numpar
   allocate(counts(nranks))
@@ -222,6 +226,13 @@ program ltrans_hip_driver
     par = par_g(n0+1:n1, :)
     P_r_element = er_g(n0+1:n1); P_u_element = eu_g(n0+1:n1); P_v_element = ev_g(n0+1:n1)
     deallocate(par_g, er_g, eu_g, ev_g)
+  endif
+  ! A sharded run with turbulence sets each shard's window of the serial random stream ONCE (below:
+  ! lt_set_rng_window_static); that holds only while no particle of the job can start or stop drawing.  Checked
+  ! here, before anything is created: every rank reads the same case file and stops with the same message.
+  if (nranks > 1 .and. (HTurbOn .or. VTurbOn)) then
+    if (settlementon .or. mortality .or. OpenOceanBoundary .or. (Behavior >= 1 .and. Behavior <= 5) .or. late_release) &
+      error stop 'sharded run: the shards'' draw counts can change; exchange them before each step (lt_count_active)'
   endif
 
   ! ---- initBehave (behavior_module.f90:94-160) / initSettlement state
@@ -266,8 +277,6 @@ program ltrans_hip_driver
                                     int(myrank, c_int32_t), 120_c_int32_t), eng, 'lt_comm_init_file')
   endif
   if (nranks > 1 .and. (HTurbOn .or. VTurbOn)) then
-    if (settlementon .or. mortality .or. OpenOceanBoundary .or. (Behavior >= 1 .and. Behavior <= 5)) &
-      stop 'sharded run: the shards'' draw counts can change; exchange them before each step (lt_count_active)'
     ! the shard's window of the serial stream: the tracked particles of the lower ranks come first
     call lt_check(lt_set_rng_window_static(eng, int(n0, c_int64_t), int(numpar_global, c_int64_t)), eng, &
                   'lt_set_rng_window_static')

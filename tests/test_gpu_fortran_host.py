@@ -67,6 +67,28 @@ def test_fortran_driver_rank_mode(tmp_path):
     assert not (tmp_path / "comm_id").exists()
 
 
+@pytest.mark.parametrize("what", ["late_release", "mortality"])
+def test_fortran_driver_rank_mode_refuses_a_static_window_that_cannot_hold(tmp_path, what):
+    """two ranks with turbulence set their windows of the stream once; a particle that is released later (LTRANS.f90:790:
+    no draw before its release) or can die makes the job's draw counts change, so the harness stops before it creates
+    anything (rank 0 alone is enough to see it: no second process, no communicator)"""
+    if not os.path.exists(DRIVER):
+        pytest.skip("Fortran harness not built (flang absent at build time)")
+    case = cases.build_case("tiny_turb", **({"mortality": 1, "deadage": 1.0e9} if what == "mortality" else {}))
+    if what == "late_release":
+        case["parts"]["par"][17, 10] = 300.0      # par(18,pDOB): ONE particle, in the other rank's half or not
+    casefile.write_ltrans_data(tmp_path / "LTRANS.data", case["cfg"], days=1.0)
+    casefile.write_case(tmp_path / "case.bin", case["g"], case["geo"], case["bounds"], case["parts"],
+                        [case["record"](r) for r in range(2)], case["cfg"].numpar)
+    env = dict(os.environ, LT_NRANKS="2", LT_RANK="1", LT_COMM_FILE=str(tmp_path / "comm_id"), LT_DEVICE="0")
+    r = subprocess.run([DRIVER, str(tmp_path / "LTRANS.data"), str(tmp_path / "case.bin"),
+                        str(tmp_path / "out.bin"), "1", "3", "0"], capture_output=True, text=True, cwd=tmp_path, env=env,
+                       timeout=120)
+    assert r.returncode != 0
+    assert "draw counts can change" in r.stdout + r.stderr
+    assert not (tmp_path / "out.bin.rank1").exists()
+
+
 def test_fortran_driver_writes_errorlog_and_timing(tmp_path):
     """the harness's ErrorLog.txt (one line per particle error in the reference's formats, LTRANS.f90:761-775,
     858-877) and, with WriteModelTiming, Timing.csv (header :471-476, one row per print interval :1669-1689)."""
