@@ -319,8 +319,10 @@ int lt_set_rng_window(lt_engine *e, int64_t active_before, int64_t active_total)
  * the shards' counts never change and need not be exchanged before each step.  The shard's draws are
  * read back in the first step after this call only; the following lt_step calls enqueue the step
  * without waiting for the device, and the device compares every step's draw total with that figure:
- * if a particle did stop (or start) drawing, lt_get_stats / lt_get_counters / lt_get_particles return
- * LT_ERR_STATE. */
+ * if a particle did stop (or start) drawing, lt_get_stats / lt_get_counters / lt_get_particles /
+ * lt_get_output return LT_ERR_STATE, lt_pack_positions / lt_allgather_positions do so one call later (they
+ * do not wait for the device), and the lt_set_rng_window that ends the static window reports it once (the
+ * new window is set all the same). */
 int lt_set_rng_window_static(lt_engine *e, int64_t active_before, int64_t active_total);
 /* Behaviours 1-5 draw a data-dependent number of deviates per particle
  * (genrand_real1, behavior_module.f90:256-452), so a shard's place in the stream is a
@@ -361,8 +363,10 @@ void *lt_stream(lt_engine *e);
  *                       travel is the host's business (a file, MPI_Bcast, ...)
  *   lt_comm_init_file   the same through a file: rank 0 creates `path` (atomically), the others wait
  *                       for it up to timeout_s seconds; rank 0 removes the file once the communicator
- *                       exists, and a file older than (process start - timeout_s) -- left by a crashed
- *                       run -- is ignored.  Use a path that is unique per run.
+ *                       exists, and a file last written more than timeout_s before the call -- left by an
+ *                       earlier or crashed run -- is ignored (so the ranks must call within timeout_s of each
+ *                       other).  Use a path that is unique per run: a fixed path shared by successive runs
+ *                       is NOT safe (a rank may read the id of a run that crashed seconds ago).
  *   lt_allgather_positions  counts(nranks) = numpar of every rank; result xyz(sum(counts),3), column-major,
  *                       shards in rank order, each in the reference's particle order, into host memory
  *                       (xyz_host: the call returns when the array is complete) and / or device memory
@@ -435,11 +439,13 @@ int lt_get_phase_times(lt_engine *e, double *ms4, int32_t reset);
  * max_steps (start, stop) pairs, then synchronise and sum them. */
 int lt_profile_begin(lt_engine *e, int32_t max_steps);
 int lt_profile_end(lt_engine *e, double *total_ms, int32_t *launches);
-/* diagnostics of the last step: [0] active [1] errors [2] SigErr fallbacks
- * [3] brute-force boundary scans [4] full point-in-polygon evaluations [5] VTurb spline intervals
- * iterated [6] rounds of that iteration; [7] (not per step) device-side re-sorts of the particle
- * order so far << 32 | GPU microseconds of the last one */
+/* diagnostics of the last step: [0] tracked particles [1] particles that raised an error [2] SigErr fallbacks
+ * [3] brute-force boundary scans [4] full point-in-polygon evaluations [5] VTurb spline intervals iterated
+ * [6] rounds of that iteration [7] particle-steps the RK4 kernel handed to its reference-shaped redo */
 int lt_get_counters(lt_engine *e, uint64_t *out8);
+/* device-side re-sorts of the particle order so far (one every resort_every steps inside lt_step) and the GPU
+ * milliseconds of the last one (-1: none yet) */
+int lt_get_resort_stats(lt_engine *e, int64_t *resorts, double *last_ms);
 
 #ifdef __cplusplus
 }

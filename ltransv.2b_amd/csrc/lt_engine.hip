@@ -74,7 +74,8 @@ struct lt_engine {
   std::vector<int> h_adj[3];                 // [element][10]
   std::vector<int32_t> h_polyspecs, h_holespecs, h_ep_ptr, h_ep_ids, h_ph_ptr, h_ph_ids;
   // particles
-  DevBuf ws_d, ws_i, orig, ele_ok, block_active, count_slots, out_cols, out_hits;
+  DevBuf ws_d, ws_i, orig, ele_ok, block_active, count_slots, out_cols, out_hits, get_stage;
+  size_t get_stage_used = 0;
   // internal particle order: slot i of every device array holds the reference's
   // particle perm[i] (0-based); sorted by rho element for memory locality
   std::vector<int> perm;
@@ -135,6 +136,11 @@ struct lt_engine {
   unsigned long long* h_counters = nullptr;  // pinned
   lt_step_stats stats{};
   bool stats_valid = true, counters_fetched = true;
+  // the static-window word read back without a wait (check_static_miss_async): pinned copy, its event, in flight?
+  unsigned long long* h_miss = nullptr;
+  hipEvent_t miss_ev = nullptr;
+  bool miss_inflight = false;
+  bool quiet_window_switch = false;
   // optional HIP-event timing of the step kernel (lt_profile_*)
   bool prof_on = false;
   std::vector<hipEvent_t> prof_ev;  // pairs (start, stop)
@@ -459,20 +465,33 @@ int put_field(lt_engine* e, DevBuf& buf, const T* src, int cols) {
   return LT_OK;
 }
 
+// Download of per-particle arrays in the reference's order (lt_get_particles, the endfile.csv / restart path of
+// LTRANS.f90:632-658): each array is put into the reference's order ON THE DEVICE (k_unpermute through `orig`)
+// into its part of one staging buffer and copied to the caller's memory from there; nothing waits until
+// get_fields_end.  (Round 3 copied each array to a pageable temporary, waited, and scattered it on the host:
+// 100 ms for the 240 MB of a million particles.)
+int get_fields_begin(lt_engine* e, size_t total_bytes) {
+  TRY(dev_alloc(e, e->get_stage, total_bytes + 256));
+  e->get_stage_used = 0;
+  return LT_OK;
+}
 template <typename T>
 int get_field(lt_engine* e, const DevBuf& buf, T* dst, int cols) {
   if (!dst || !buf.p) return LT_OK;
-  TRY(sync_perm(e));
   const size_t n = (size_t)e->cfg.numpar;
-  std::vector<T> tmp(n * cols);
-  HIPCHK(e, hipMemcpyAsync(tmp.data(), buf.p, n * cols * sizeof(T), hipMemcpyDeviceToHost, e->stream));
+  const size_t bytes = n * cols * sizeof(T);
+  if (!bytes) return LT_OK;
+  if (e->get_stage_used + bytes > e->get_stage.bytes) return fail(e, LT_ERR_STATE, "get_field: staging buffer too small");
+  T* stage = (T*)((char*)e->get_stage.p + e->get_stage_used);
+  e->get_stage_used += (bytes + 255) & ~(size_t)255;
+  hipLaunchKernelGGL((ltd::k_unpermute<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, (const T*)buf.p, stage,
+                     (const int*)e->orig.p, (int)n, cols);
+  HIPCHK(e, hipMemcpyAsync(dst, stage, bytes, hipMemcpyDeviceToHost, e->stream));
+  return LT_OK;
+}
+int get_fields_end(lt_engine* e) {
+  HIPCHK(e, hipGetLastError());
   HIPCHK(e, hipStreamSynchronize(e->stream));
-  const int* pm = e->perm.data();
-  for (int c = 0; c < cols; c++) {
-    const T* s = tmp.data() + (size_t)c * n;
-    T* d = dst + (size_t)c * n;
-    for (size_t i = 0; i < n; i++) d[pm[i]] = s[i];
-  }
   return LT_OK;
 }
 
@@ -976,7 +995,7 @@ int lt_destroy(lt_engine* e) {
                     &e->ep_ptr, &e->ep_ids, &e->ph_ptr, &e->ph_ids, &e->par, &e->pr, &e->pu,
                     &e->pv, &e->P_behave, &e->dead, &e->oob, &e->settle, &e->endpoly,
                     &e->hitBottom, &e->hitLand, &e->err_code, &e->P_swim, &e->P_pediage,
-                    &e->P_deadage, &e->settletime, &e->timer, &e->P_Sprev, &e->P_zprev, &e->bottom, &e->P_Salt, &e->P_Temp, &e->S, &e->T, &e->counters, &e->ws_d, &e->ws_i, &e->orig, &e->ele_ok, &e->block_active, &e->count_slots, &e->out_cols, &e->out_hits, &e->rng_states, &e->rng_ring, &e->rng_polys, &e->flag, &e->rank, &e->scan_tmp,
+                    &e->P_deadage, &e->settletime, &e->timer, &e->P_Sprev, &e->P_zprev, &e->bottom, &e->P_Salt, &e->P_Temp, &e->S, &e->T, &e->counters, &e->ws_d, &e->ws_i, &e->orig, &e->ele_ok, &e->block_active, &e->get_stage, &e->count_slots, &e->out_cols, &e->out_hits, &e->rng_states, &e->rng_ring, &e->rng_polys, &e->flag, &e->rank, &e->scan_tmp,
                     &e->vt_tab, &e->vt_qS, &e->vt_qS1, &e->vt_qS2, &e->vt_qwl, &e->vt_qcount, &e->vt_wl, &e->vt_dev, &e->slow_list, &e->sort_keys, &e->sort_keys_in, &e->tile_key, &e->sort_idx_in, &e->sort_idx_out,
                     &e->sort_tmp, &e->permute_tmp};
   for (DevBuf* b : bufs)
@@ -984,6 +1003,8 @@ int lt_destroy(lt_engine* e) {
   for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : e->phase_ev) (void)hipEventDestroy(ev);
   if (e->h_counters) (void)hipHostFree(e->h_counters);
+  if (e->h_miss) (void)hipHostFree(e->h_miss);
+  if (e->miss_ev) (void)hipEventDestroy(e->miss_ev);
   if (e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);
   for (int i = 0; i < 2; i++) {
     if (e->pin[i]) (void)hipHostFree(e->pin[i]);
@@ -1609,12 +1630,52 @@ int lt_set_particles(lt_engine* e, const lt_particles* p) {
 }
 
 static int fetch_counters(lt_engine* e);
+// Under a static stream window (lt_set_rng_window_static) the calls that hand positions out without waiting for the
+// device -- lt_pack_positions, lt_allgather_positions -- look at the word k_post counts broken windows in without
+// waiting either: an asynchronous copy per call, examined by the next one (the report is one call late, not absent).
+static int check_static_miss_async(lt_engine* e) {
+  if (!e->rng_static) return LT_OK;
+  if (!e->h_miss) {
+    if (hipHostMalloc((void**)&e->h_miss, sizeof(unsigned long long)) != hipSuccess) return LT_ERR_NOMEM;
+    *e->h_miss = 0ull;
+    if (hipEventCreateWithFlags(&e->miss_ev, hipEventDisableTiming) != hipSuccess) return LT_ERR_DEVICE;
+  }
+  if (e->miss_inflight && hipEventQuery(e->miss_ev) == hipSuccess) {
+    e->miss_inflight = false;
+    if (*e->h_miss)
+      return fail(e, LT_ERR_STATE, "static random-stream window: the shard's draws changed (%llu step(s)); a particle "
+                                   "stopped or started drawing -- set the window before each step instead", *e->h_miss);
+  }
+  if (!e->miss_inflight) {
+    HIPCHK(e, hipMemcpyAsync(e->h_miss, (unsigned long long*)e->counters.p + CNT_STATIC_MISS, sizeof(unsigned long long),
+                             hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipEventRecord(e->miss_ev, e->stream));
+    e->miss_inflight = true;
+  }
+  return LT_OK;
+}
 int lt_get_particles(lt_engine* e, lt_particles* out) {
   if (!e || !out) return LT_ERR_ARG;
   if (!e->have_particles) return fail(e, LT_ERR_STATE, "no particles uploaded");
   HIPCHK(e, hipSetDevice(e->device));
   if (e->rng_static) TRY(fetch_counters(e));  // (reports a static stream window that did not hold)
-  TRY(sync_perm(e));
+  {
+    // the staging buffer: one part per array that is asked for and exists
+    const size_t n = (size_t)e->cfg.numpar;
+    size_t total = 0;
+    auto want = [&](const DevBuf& b, const void* dst, size_t elem, int cols) {
+      if (dst && b.p) total += ((n * cols * elem) + 255) & ~(size_t)255;
+    };
+    want(e->par, out->par, 8, 13); want(e->pr, out->P_r_element, 4, 1); want(e->pu, out->P_u_element, 4, 1);
+    want(e->pv, out->P_v_element, 4, 1); want(e->P_behave, out->P_behave, 4, 1); want(e->dead, out->dead, 4, 1);
+    want(e->oob, out->oob, 4, 1); want(e->P_swim, out->P_swim, 8, 3); want(e->P_pediage, out->P_pediage, 8, 1);
+    want(e->P_deadage, out->P_deadage, 8, 1); want(e->settle, out->settle, 4, 1); want(e->settletime, out->settletime, 8, 1);
+    want(e->endpoly, out->endpoly, 4, 1); want(e->hitBottom, out->hitBottom, 4, 1); want(e->hitLand, out->hitLand, 4, 1);
+    want(e->err_code, out->err_code, 4, 1); want(e->timer, out->timer, 8, 1); want(e->P_Sprev, out->P_Sprev, 8, 1);
+    want(e->P_zprev, out->P_zprev, 8, 1); want(e->bottom, out->bottom, 4, 1); want(e->P_Salt, out->P_Salt, 8, 1);
+    want(e->P_Temp, out->P_Temp, 8, 1);
+    TRY(get_fields_begin(e, total));
+  }
   TRY(get_field<double>(e, e->par, out->par, 13));
   TRY(get_field<int32_t>(e, e->pr, out->P_r_element, 1));
   TRY(get_field<int32_t>(e, e->pu, out->P_u_element, 1));
@@ -1637,7 +1698,7 @@ int lt_get_particles(lt_engine* e, lt_particles* out) {
   TRY(get_field<int32_t>(e, e->bottom, out->bottom, 1));
   TRY(get_field<double>(e, e->P_Salt, out->P_Salt, 1));
   TRY(get_field<double>(e, e->P_Temp, out->P_Temp, 1));
-  return LT_OK;
+  return get_fields_end(e);
 }
 
 int lt_get_output(lt_engine* e, lt_output* out, int32_t reset_hits) {
@@ -1645,6 +1706,7 @@ int lt_get_output(lt_engine* e, lt_output* out, int32_t reset_hits) {
   if (!e->have_particles) return fail(e, LT_ERR_STATE, "no particles uploaded");
   if (e->pre_valid) return fail(e, LT_ERR_STATE, "not between lt_count_draws and its lt_step");
   HIPCHK(e, hipSetDevice(e->device));
+  if (e->rng_static) TRY(fetch_counters(e));  // (reports a static stream window that did not hold; the call waits anyway)
   const size_t n = (size_t)e->cfg.numpar;
   if (!n) return LT_OK;
   TRY(dev_alloc(e, e->out_cols, 5 * n * 8));
@@ -1660,10 +1722,12 @@ int lt_get_output(lt_engine* e, lt_output* out, int32_t reset_hits) {
     if (dst[c]) HIPCHK(e, hipMemcpyAsync(dst[c], (double*)e->out_cols.p + c * n, n * 8, hipMemcpyDeviceToHost, e->stream));
   if (out->hitBottom) HIPCHK(e, hipMemcpyAsync(out->hitBottom, (int*)e->out_hits.p, n * 4, hipMemcpyDeviceToHost, e->stream));
   if (out->hitLand) HIPCHK(e, hipMemcpyAsync(out->hitLand, (int*)e->out_hits.p + n, n * 4, hipMemcpyDeviceToHost, e->stream));
+  if (out->salt || out->temp) {
+    TRY(get_fields_begin(e, 2 * ((n * 8 + 255) & ~(size_t)255)));
+    if (out->salt) TRY(get_field<double>(e, e->P_Salt, out->salt, 1));
+    if (out->temp) TRY(get_field<double>(e, e->P_Temp, out->temp, 1));
+  }
   HIPCHK(e, hipStreamSynchronize(e->stream));
-  if (out->salt || out->temp) TRY(sync_perm(e));
-  if (out->salt) TRY(get_field<double>(e, e->P_Salt, out->salt, 1));
-  if (out->temp) TRY(get_field<double>(e, e->P_Temp, out->temp, 1));
   return LT_OK;
 }
 
@@ -2230,17 +2294,35 @@ int lt_set_rng_window(lt_engine* e, int64_t active_before, int64_t active_total)
   const int64_t D = (e->cfg.HTurbOn ? 4 : 0) + (e->cfg.VTurbOn ? 2 * (e->cfg.idt / 2) : 0);
   e->rng_before = active_before * D;
   e->rng_total = active_total * D;
+  // A static window ends here.  Whether it held is read from the device NOW (nobody may have asked yet), the word
+  // is cleared -- a window set anew: the report is spent -- and the switch is made; a window that did not hold is
+  // this call's error, once.
+  unsigned long long missed = 0;
+  const bool reported = e->h_counters && e->h_counters[CNT_STATIC_MISS] != 0;  // (an earlier call has said so already)
+  if (e->rng_static && !reported) {
+    HIPCHK(e, hipMemcpyAsync(e->h_counters + CNT_STATIC_MISS, (unsigned long long*)e->counters.p + CNT_STATIC_MISS,
+                             sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+  }
   e->rng_static = false;
   e->rng_static_own = -1;
-  if (e->h_counters && e->h_counters[CNT_STATIC_MISS]) {   // a window set anew: the earlier report is spent
+  e->miss_inflight = false;
+  if (e->h_counters && e->h_counters[CNT_STATIC_MISS]) {
+    missed = e->h_counters[CNT_STATIC_MISS];
     e->h_counters[CNT_STATIC_MISS] = 0;
     HIPCHK(e, hipMemsetAsync((unsigned long long*)e->counters.p + CNT_STATIC_MISS, 0, sizeof(unsigned long long), e->stream));
   }
+  if (missed && !reported && !e->quiet_window_switch)
+    return fail(e, LT_ERR_STATE, "static random-stream window: the shard's draws changed in %llu step(s) before this call "
+                                 "ended the window (the steps since then used wrong positions of the stream); the new window is set", missed);
   return LT_OK;
 }
 
 int lt_set_rng_window_static(lt_engine* e, int64_t active_before, int64_t active_total) {
+  if (!e) return LT_ERR_ARG;
+  e->quiet_window_switch = true;   // (setting a static window anew spends the report of the one before, as it always did)
   const int rc = lt_set_rng_window(e, active_before, active_total);
+  e->quiet_window_switch = false;
   if (rc != LT_OK) return rc;
   e->rng_static = active_total > 0;
   e->rng_static_before = e->rng_before;
@@ -2497,8 +2579,10 @@ int lt_get_stats(lt_engine* e, lt_step_stats* out) {
   return LT_OK;
 }
 
-/* diagnostics of the last step: [0] active [1] errors [2] SigErr fallbacks
- * [3] brute-force boundary scans [4] full point-in-polygon evaluations */
+/* diagnostics of the last step (the kernels' counters, lt_device.h: Counter): [0] tracked particles [1] particles
+ * that raised an error [2] SigErr fallbacks of k_rk [3] brute-force boundary scans [4] full point-in-polygon
+ * evaluations [5] VTurb spline intervals iterated [6] rounds of that iteration [7] particle-steps k_rk handed
+ * to k_rk_slow.  (The re-sorts of the particle order are not per-step figures: lt_get_resort_stats.) */
 #ifdef LT_RK_TIMING
 int lt_diag(unsigned long long* out) {
   hipDeviceSynchronize();
@@ -2516,10 +2600,18 @@ int lt_get_counters(lt_engine* e, uint64_t* out8) {
   TRY(lt_sync(e));
   TRY(fetch_counters(e));
   for (int i = 0; i < CNT_COUNT; i++) out8[i] = e->h_counters[i];
-  {  // [7]: re-sorts of the particle order so far << 32 | GPU microseconds of the last one
+  return LT_OK;
+}
+
+int lt_get_resort_stats(lt_engine* e, int64_t* resorts, double* last_ms) {
+  if (!e || !resorts || !last_ms) return LT_ERR_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  *resorts = (int64_t)e->resorts;
+  *last_ms = -1.0;   // (no re-sort yet, or its events could not be read)
+  if (e->resorts) {
+    HIPCHK(e, hipStreamSynchronize(e->stream));
     float ms = 0.f;
-    if (e->resorts && hipEventElapsedTime(&ms, e->resort_ev[0], e->resort_ev[1]) != hipSuccess) ms = 0.f;
-    out8[7] = ((uint64_t)e->resorts << 32) | (uint64_t)(unsigned)(ms * 1000.0f + 0.5f);
+    if (hipEventElapsedTime(&ms, e->resort_ev[0], e->resort_ev[1]) == hipSuccess) *last_ms = (double)ms;
   }
   return LT_OK;
 }
@@ -2658,10 +2750,11 @@ int lt_comm_init(lt_engine* e, const void* id128, int32_t nranks, int32_t rank) 
 
 // The id file is good for ONE communicator: rank 0 removes whatever lies at `path` before it writes, and removes
 // its own file once ncclCommInitRank has returned (every rank has joined by then, so every rank has read it);
-// the other ranks ignore a file last written before (their own start - timeout_s) -- what a crashed run left
-// behind -- and keep waiting for rank 0's.  (Ranks are expected to start within timeout_s of each other; a path
-// that is unique per run needs none of this and is what INTEGRATION.md recommends.)
-static const time_t g_lib_loaded = time(nullptr);
+// the other ranks ignore a file last written more than timeout_s (+ 2 s) before THIS CALL -- what an earlier or a
+// crashed attempt left behind, also one of this very process -- and keep waiting for rank 0's.  Ranks are
+// therefore expected to make the call within timeout_s of each other.  A fixed path shared by successive runs is
+// still not safe (a rank that polls before rank 0 has removed the file of a run that crashed seconds ago reads a
+// dead id and waits in ncclCommInitRank): use a path that is unique per run, as INTEGRATION.md says.
 int lt_comm_init_file(lt_engine* e, const char* path, int32_t nranks, int32_t rank, int32_t timeout_s) {
   if (!e || !path || nranks < 1 || rank < 0 || rank >= nranks) return LT_ERR_ARG;
   unsigned char id[128];
@@ -2675,7 +2768,7 @@ int lt_comm_init_file(lt_engine* e, const char* path, int32_t nranks, int32_t ra
     if (rename(tmp.c_str(), path) != 0) return fail(e, LT_ERR_ARG, "lt_comm_init_file: cannot rename to %s", path);
   } else {
     bool ok = false;
-    const time_t oldest = g_lib_loaded - (time_t)(timeout_s > 0 ? timeout_s : 0) - 2;
+    const time_t oldest = time(nullptr) - (time_t)(timeout_s > 0 ? timeout_s : 0) - 2;
     for (int waited_ms = 0; waited_ms <= timeout_s * 1000 && !ok; waited_ms += 50) {
       struct stat sb;
       if (stat(path, &sb) == 0 && sb.st_size == 128 && sb.st_mtime >= oldest) {
@@ -2774,6 +2867,7 @@ int lt_allgather_positions(lt_engine* e, const int32_t* counts, double* xyz_host
   RcclApi* R = rccl();
   if (!R) return LT_ERR_UNSUPPORTED;
   HIPCHK(e, hipSetDevice(e->device));
+  TRY(check_static_miss_async(e));
   AgPlan A;
   TRY(ag_pack(e, e->comm_nranks, e->comm_rank, counts, xyz_device, A));
   if (A.total == 0) return LT_OK;
@@ -2887,6 +2981,7 @@ int lt_pack_positions(lt_engine* e, void* dst_device) {
   if (!e || !dst_device) return LT_ERR_ARG;
   if (!e->have_particles) return fail(e, LT_ERR_STATE, "no particles uploaded");
   HIPCHK(e, hipSetDevice(e->device));
+  TRY(check_static_miss_async(e));
   unsigned blocks = (unsigned)(((size_t)e->cfg.numpar + 255) / 256);
   if (blocks)
     hipLaunchKernelGGL(k_pack_positions, dim3(blocks), dim3(256), 0, e->stream,

@@ -165,6 +165,16 @@ __global__ void k_permute(const T* __restrict__ src, T* __restrict__ dst, const 
   const int j = idx[i];
   for (int c = 0; c < cols; c++) dst[(size_t)c * n + i] = src[(size_t)c * n + j];
 }
+// the inverse, for handing an array out in the reference's particle order: dst[c*n + orig[i]] = src[c*n + i]
+// (orig[i] = reference index of internal slot i)
+template <typename T>
+__global__ void k_unpermute(const T* __restrict__ src, T* __restrict__ dst, const int* __restrict__ orig, int n,
+                            int cols) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int j = orig[i];
+  for (int c = 0; c < cols; c++) dst[(size_t)c * n + j] = src[(size_t)c * n + i];
+}
 // sort key of every particle: the tile key of its rho element (lt_set_grid)
 __global__ void k_tile_keys(const int* __restrict__ pr, const int* __restrict__ tile_key, int* __restrict__ keys, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -495,9 +495,16 @@ class Engine:
         f.restype = C.c_int
         a = np.zeros(8, dtype=np.uint64)
         self._check(f(self._h, a.ctypes.data_as(C.c_void_p)), "get_counters")
-        return {"active": int(a[0]), "errors": int(a[1]), "sigerr": int(a[2]),
-                "brute_bounds": int(a[3]), "pip_full": int(a[4]), "vt_queued": int(a[5]), "vt_rounds": int(a[6]),
-                "resorts": int(a[7]) >> 32, "last_resort_ms": (int(a[7]) & 0xFFFFFFFF) * 1e-3}
+        out = {"active": int(a[0]), "errors": int(a[1]), "sigerr": int(a[2]),
+               "brute_bounds": int(a[3]), "pip_full": int(a[4]), "vt_queued": int(a[5]), "vt_rounds": int(a[6]),
+               "rk_slow": int(a[7]), "resorts": 0, "last_resort_ms": 0.0}
+        g = getattr(self.lib, "lt_get_resort_stats", None)     # (not in the oracle)
+        if g is not None:
+            g.restype = C.c_int
+            n, ms = C.c_int64(), C.c_double()
+            self._check(g(self._h, C.byref(n), C.byref(ms)), "get_resort_stats")
+            out["resorts"], out["last_resort_ms"] = n.value, max(ms.value, 0.0)
+        return out
 
     def stream(self):
         f = self.lib.lt_stream

@@ -148,6 +148,12 @@ def test_comm_id_file_of_an_earlier_run_is_ignored(tmp_path):
     os.utime(stale, (old, old))
     with pytest.raises(RuntimeError, match="did not appear"):
         e.comm_init_file(stale, 2, 1, timeout_s=1)
+    # a long-lived process: a file of an attempt ten seconds ago (after this library was loaded, for all it knows)
+    # is as stale as one of an hour ago -- the age counts from the call
+    recent = time.time() - 10
+    os.utime(stale, (recent, recent))
+    with pytest.raises(RuntimeError, match="did not appear"):
+        e.comm_init_file(stale, 2, 1, timeout_s=1)
     e.close()
 
 

@@ -209,6 +209,45 @@ def test_static_window_that_does_not_hold_is_reported():
     e.close()
 
 
+def test_broken_static_window_is_reported_by_the_calls_that_do_not_wait_and_by_the_call_that_ends_it():
+    """the same broken promise, met by a host that never asks for statistics: lt_pack_positions (no wait for the
+    device) reports it one call late, lt_get_output at once, and -- if nobody has asked -- the lt_set_rng_window that
+    ends the static window reports it once and sets the new window all the same"""
+    import torch
+    case = cases.build_case("tiny_turb", mortality=1, deadage=500.0)
+    n = case["cfg"].numpar
+    from ltrans_amd.driver import LtransRun
+    for how in ("pack", "output", "window"):
+        e = cases.make_engine(case, ltrans_amd.Engine, {})
+        run = LtransRun(e, case["cfg"].dt, case["cfg"].idt, case["record"])
+        run.init_hydro()
+        e.set_rng_window(0, n, persistent=True)
+        ex = run.external_times(1)
+        dst = torch.zeros(3 * n, dtype=torch.float64, device="cuda")
+        reported = None
+        for it in range(1, 13):
+            ix = run.internal_times(ex, it)
+            e.update_particles(ex, ix, 1, it)
+            try:
+                if how == "pack":
+                    e.pack_positions(dst.data_ptr())
+                    torch.cuda.synchronize()
+                elif how == "output":
+                    e.get_output()
+            except ltrans_amd.LtError as err:
+                reported = (it, str(err))
+                break
+        if how == "window":
+            with pytest.raises(ltrans_amd.LtError, match="before this call"):
+                e.set_rng_window(0, e.count_active(run.internal_times(ex, 13)))
+            e.update_particles(ex, run.internal_times(ex, 13), 1, 13)      # the new window was set: the run goes on
+            assert e.stats()["active"] < n
+        else:
+            assert reported is not None and "static random-stream window" in reported[1], (how, reported)
+            assert reported[0] >= 3
+        e.close()
+
+
 def test_long_run_without_host_waits_equals_the_run_with_windows_per_step():
     """400 internal steps (14 external steps) of 20k particles with HTurb + VTurb, once under a static stream window --
     the host enqueues every step without waiting for the device, hundreds of steps ahead: the generators' ring, their
