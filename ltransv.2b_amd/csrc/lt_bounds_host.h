@@ -363,4 +363,60 @@ class Bounds {
   int last_dir_ = 5;
 };
 
+// createBounds' output arrays (boundary_module.f90:1040-1215) from the walk: bx / by (the main polygon, closed),
+// hx / hy / hid (the islands, each closed, ids from 1001), bnd_x / bnd_y / land (the segments; land = 0 between two
+// open-ocean points).  x_u(vi-1,uj), x_v(vi,uj-1) column-major; every output has room for `cap` entries (2*cap for
+// bnd_x / bnd_y).  Returns 0, or 1 when the mask cannot be walked or the arrays are too small.
+inline int create_bounds_arrays(int32_t vi, int32_t uj, const int32_t* mask_rho, const double* x_u, const double* y_u,
+                                const double* x_v, const double* y_v, int32_t cap, int32_t* nbounds_o, int32_t* maxbound_o,
+                                int32_t* maxisland_o, int32_t* numislands_o, double* bx, double* by, double* hx, double* hy,
+                                int32_t* hid, double* bnd_x, double* bnd_y, int32_t* land) {
+  Bounds B(vi, uj, mask_rho);
+  if (B.build() != 0) return 1;
+  const std::vector<Point>& P = B.points();
+  const int ui = vi - 1, numpoly = P.back().poly, numislands = numpoly - 1;
+  std::vector<int> size(numpoly + 1, 0), first(numpoly + 2, 0);
+  for (const Point& p : P) size[p.poly]++;
+  for (int m = 1; m <= numpoly; m++) first[m + 1] = first[m] + size[m];
+  const int maxbound = size[1] + 1;
+  int maxisland = numislands;
+  for (int m = 2; m <= numpoly; m++) maxisland += size[m];
+  const int nbounds = maxbound + maxisland - numislands - 1;
+  if (maxbound > cap || maxisland > cap || nbounds > cap) return 1;
+  auto xy = [&](const Point& p, double& x, double& y) {
+    if (p.onU) { x = x_u[(size_t)(p.i - 1) + (size_t)ui * (p.j - 1)]; y = y_u[(size_t)(p.i - 1) + (size_t)ui * (p.j - 1)]; }
+    else { x = x_v[(size_t)(p.i - 1) + (size_t)vi * (p.j - 1)]; y = y_v[(size_t)(p.i - 1) + (size_t)vi * (p.j - 1)]; }
+  };
+  // open ocean: a point on the rim of the grid next to a water node of the outermost ring (:1071-1079)
+  auto open_ocean = [&](const Point& p) {
+    if (p.onU) return (p.i == 1 && B.water(1, p.j)) || (p.i == vi - 1 && B.water(vi, p.j));
+    return (p.j == 1 && B.water(p.i, 1)) || (p.j == uj - 1 && B.water(p.i, uj));
+  };
+  std::vector<char> oo(maxbound, 0);
+  for (int k = 0; k < maxbound; k++) {   // the main polygon, closed by repeating its first point
+    const Point& p = P[first[1] + (k < size[1] ? k : 0)];
+    xy(p, bx[k], by[k]);
+    oo[k] = open_ocean(p);
+  }
+  int c = 0;
+  for (int m = 2; m <= numpoly; m++)
+    for (int k = 0; k <= size[m]; k++, c++) {
+      xy(P[first[m] + (k < size[m] ? k : 0)], hx[c], hy[c]);
+      hid[c] = m + 999;   // island ids start at 1001
+    }
+  for (int i = 0; i < maxbound - 1; i++) {
+    bnd_x[2 * i] = bx[i]; bnd_y[2 * i] = by[i]; bnd_x[2 * i + 1] = bx[i + 1]; bnd_y[2 * i + 1] = by[i + 1];
+    land[i] = (oo[i] && oo[i + 1]) ? 0 : 1;
+  }
+  int q = maxbound - 1;
+  for (int i = 0; i + 1 < maxisland; i++) {
+    if (hid[i] != hid[i + 1]) continue;   // (the closing point of one island and the first of the next)
+    bnd_x[2 * q] = hx[i]; bnd_y[2 * q] = hy[i]; bnd_x[2 * q + 1] = hx[i + 1]; bnd_y[2 * q + 1] = hy[i + 1];
+    land[q] = 1;
+    q++;
+  }
+  *nbounds_o = nbounds; *maxbound_o = maxbound; *maxisland_o = maxisland; *numislands_o = numislands;
+  return q == nbounds ? 0 : 1;
+}
+
 }  // namespace ltb

@@ -28,6 +28,7 @@
 #include "lt_rk_launch.h"  // k_rk lives in lt_rk_kernel.hip (its own compiler options)
 #include "lt_kernels.h"
 #include "lt_bounds_host.h"
+#include "lt_init_host.h"
 #include "lt_mt.h"
 
 using namespace ltd;
@@ -1276,67 +1277,6 @@ int lt_build_adjacency(int32_t device, int32_t elements, int32_t row, const int3
   return rc;
 }
 
-namespace {
-
-// uniform bins over the elements' bounding boxes, ids ascending in every bin
-void build_ele_bins(const std::vector<double>& nx, const std::vector<double>& ny, const std::vector<int32_t>& E,
-                    int elements, ltd::EleBins& B, HostIndex& H) {
-  double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
-  std::vector<double> bb((size_t)elements * 4);
-  for (int i = 0; i < elements; i++) {
-    double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
-    for (int k = 0; k < 4; k++) {
-      const int nd = E[(size_t)i * 4 + k] - 1;
-      x0 = std::min(x0, nx[nd]); x1 = std::max(x1, nx[nd]);
-      y0 = std::min(y0, ny[nd]); y1 = std::max(y1, ny[nd]);
-    }
-    bb[(size_t)i * 4] = x0; bb[(size_t)i * 4 + 1] = x1; bb[(size_t)i * 4 + 2] = y0; bb[(size_t)i * 4 + 3] = y1;
-    xmin = std::min(xmin, x0); xmax = std::max(xmax, x1); ymin = std::min(ymin, y0); ymax = std::max(ymax, y1);
-  }
-  const double wx = std::max(xmax - xmin, 1e-300), wy = std::max(ymax - ymin, 1e-300);
-  double cell = std::sqrt(wx * wy / std::max(elements, 1));
-  if (!(cell > 0.0)) cell = std::max(wx, wy);
-  while ((wx / cell + 1.0) * (wy / cell + 1.0) > 4.0e6) cell *= 2.0;
-  B.x0 = xmin; B.y0 = ymin; B.inv = 1.0 / cell;
-  B.ncx = (int)std::floor(wx / cell) + 1;
-  B.ncy = (int)std::floor(wy / cell) + 1;
-  // the same expression as k_locate's, so that bin(min) <= bin(x) <= bin(max) for min <= x <= max
-  auto cx = [&](double x) { double f = std::floor((x - B.x0) * B.inv); return (int)std::min(std::max(f, 0.0), (double)(B.ncx - 1)); };
-  auto cy = [&](double y) { double f = std::floor((y - B.y0) * B.inv); return (int)std::min(std::max(f, 0.0), (double)(B.ncy - 1)); };
-  const size_t ncell = (size_t)B.ncx * B.ncy;
-  H.ptr.assign(ncell + 1, 0);
-  for (int pass = 0; pass < 2; pass++) {
-    std::vector<int> cur;
-    if (pass) {
-      for (size_t c = 0; c < ncell; c++) H.ptr[c + 1] += H.ptr[c];
-      H.ids.assign((size_t)H.ptr[ncell], 0);
-      cur.assign(H.ptr.begin(), H.ptr.end() - 1);
-    }
-    for (int i = 0; i < elements; i++) {
-      const int a0 = cx(bb[(size_t)i * 4]), a1 = cx(bb[(size_t)i * 4 + 1]);
-      const int b0 = cy(bb[(size_t)i * 4 + 2]), b1 = cy(bb[(size_t)i * 4 + 3]);
-      for (int b = b0; b <= b1; b++)
-        for (int a = a0; a <= a1; a++) {
-          const size_t c = (size_t)a + (size_t)b * B.ncx;
-          if (pass) H.ids[(size_t)cur[c]++] = i + 1; else H.ptr[c + 1]++;
-        }
-    }
-  }
-}
-
-// a scan of all elements (gridcell without checkele): the first element that ends the scan, else
-// the last one that set P_ele (gridcell_kind 2), 0 if none
-int full_scan_result(const int* codes, int c) {
-  int res = 0;
-  for (int t = 0; t < c; t++) {
-    if ((codes[t] & 3) == 1) return codes[t] >> 2;
-    res = codes[t] >> 2;
-  }
-  return res;
-}
-
-}  // namespace
-
 int lt_locate_particles(lt_engine* e, int32_t n, const double* Xpar, const double* Ypar, int32_t* P_r_element,
                         int32_t* P_u_element, int32_t* P_v_element, int32_t* err, int32_t* par) {
   if (!e) return LT_ERR_ARG;
@@ -1347,7 +1287,7 @@ int lt_locate_particles(lt_engine* e, int32_t n, const double* Xpar, const doubl
   const int nele[3] = {e->rho_elements, e->u_elements, e->v_elements};
   const void* nodes[3] = {e->rnode.p, e->unode.p, e->vnode.p};
   const int4* EL[3] = {(const int4*)e->RE.p, (const int4*)e->UE.p, (const int4*)e->VE.p};
-  std::vector<std::vector<int>> codes(3), cnt(3);
+  std::vector<int> codes[3], cnt[3];
   if (n > 0) {
     DevBuf dX, dY, dcodes, dcnt, dptr, dids;
     int rc = LT_OK;
@@ -1359,7 +1299,9 @@ int lt_locate_particles(lt_engine* e, int32_t n, const double* Xpar, const doubl
       for (int g = 0; g < 3; g++) {
         ltd::EleBins B;
         HostIndex H;
-        build_ele_bins(e->h_nx[g], e->h_ny[g], e->h_E[g], nele[g], B, H);
+        ltih::BinGeom G;
+        ltih::build_ele_bins(e->h_nx[g], e->h_ny[g], e->h_E[g], nele[g], G, H.ptr, H.ids);
+        B.x0 = G.x0; B.y0 = G.y0; B.inv = G.inv; B.ncx = G.ncx; B.ncy = G.ncy;
         if (H.ids.empty()) H.ids.push_back(0);
         TRY(upload(e, dptr, H.ptr.data(), H.ptr.size() * 4));
         TRY(upload(e, dids, H.ids.data(), H.ids.size() * 4));
@@ -1388,37 +1330,10 @@ int lt_locate_particles(lt_engine* e, int32_t n, const double* Xpar, const doubl
         if (cnt[g][k] > LT_LOC_CAP)
           return fail(e, LT_ERR_ARG, "lt_locate_particles: particle %d lies in more than %d elements", k + 1, LT_LOC_CAP);
   }
-  // the particle loop of setEle_all: only the ORDER of the tests depends on the previous particle
+  // the particle loop of setEle_all: only the ORDER of the tests depends on the previous particle (lt_init_host.h)
   std::vector<int32_t> out[3];
-  for (int g = 0; g < 3; g++) out[g].assign((size_t)n, 0);
   int error = 0, p = 0;
-  if (n >= 1) {
-    for (int g = 0; g < 3; g++) {  // :1553-1583, no early exit between the three grids
-      out[g][0] = full_scan_result(&codes[g][0], cnt[g][0]);
-      if (out[g][0] == 0) { error = g + 1; p = 1; }
-    }
-  }
-  for (int k = 1; k < n && error == 0; k++) {
-    for (int g = 0; g < 3; g++) {
-      const int* cd = &codes[g][(size_t)k * LT_LOC_CAP];
-      const int c = cnt[g][k];
-      int res = 0;
-      if (c == 1) {
-        res = cd[0] >> 2;  // the only element that contains it, whichever test finds it
-      } else if (c > 1) {
-        const int* row = &e->h_adj[g][(size_t)(out[g][k - 1] - 1) * 10];
-        bool done = false;
-        for (int i = 0; i < 10 && !done; i++) {
-          const int a = row[i];
-          if (a == 0) { res = full_scan_result(cd, c); done = true; break; }
-          for (int t = 0; t < c; t++)
-            if ((cd[t] >> 2) == a) { res = a; done = true; break; }
-        }
-      }
-      if (res == 0) { error = g + 1; p = k + 1; break; }
-      out[g][k] = res;
-    }
-  }
+  ltih::replay_set_ele_all((int)n, codes, cnt, e->h_adj, out, error, p);
   for (int g = 0; g < 3; g++)
     if (outp[g] && n > 0) memcpy(outp[g], out[g].data(), (size_t)n * 4);
   if (err) *err = error;
@@ -1436,48 +1351,14 @@ int lt_create_polyspecs(lt_engine* e, const lt_habitat* h) {
   const int pedges = h->pedges, hedges = h->hedges;
   const int npoly = h->maxpolyid - h->minpolyid + 1;
   const int nhole = (hedges > 0) ? h->maxholeid - h->minholeid + 1 : 0;
-  auto POLYS = [&](int i, int k) { return h->polys[((size_t)i - 1) + (size_t)pedges * (k - 1)]; };
-  auto HOLES = [&](int i, int k) { return h->holes[((size_t)i - 1) + (size_t)hedges * (k - 1)]; };
-  for (int i = 1; i <= pedges; i++) {
-    const long id = lround(POLYS(i, 1));
-    if (id < h->minpolyid || id > h->maxpolyid) return fail(e, LT_ERR_ARG, "lt_create_polyspecs: polygon id %ld outside minpolyid..maxpolyid", id);
-  }
-  for (int i = 1; i <= hedges; i++) {
-    const long id = lround(HOLES(i, 1));
-    if (id < h->minholeid || id > h->maxholeid) return fail(e, LT_ERR_ARG, "lt_create_polyspecs: hole id %ld outside minholeid..maxholeid", id);
-  }
-  // polyspecs / holespecs: first row and number of edge points of every id, settlement_module.f90:277-289,393-405
-  std::vector<int32_t> ps((size_t)npoly * 2, 0), hs((size_t)std::max(nhole, 1) * 2, 0);
-  auto specs = [](std::vector<int32_t>& sp, int n, int nrow, int minid, auto ID) {
-    int count = 1;
-    sp[(size_t)(lround(ID(1)) - minid)] = 1;
-    for (int i = 2; i <= nrow; i++) {
-      if (ID(i) != ID(i - 1)) {
-        sp[(size_t)(lround(ID(i)) - minid)] = i;
-        sp[(size_t)(lround(ID(i - 1)) - minid) + n] = count;
-        count = 1;
-      } else if (i == nrow) {
-        sp[(size_t)(lround(ID(i)) - minid) + n] = count + 1;
-      } else {
-        count = count + 1;
-      }
-    }
-  };
-  specs(ps, npoly, pedges, h->minpolyid, [&](int i) { return POLYS(i, 1); });
-  if (hedges > 0) specs(hs, nhole, hedges, h->minholeid, [&](int i) { return HOLES(i, 1); });
-  // holes of every polygon :410-468
-  std::vector<int32_t> php((size_t)npoly + 1, 0), phi;
-  for (int id = h->minpolyid; id <= h->maxpolyid; id++) {
-    int count = 0;
-    const int first = ps[(size_t)(id - h->minpolyid)];
-    if (hedges > 0 && first != 0) {
-      for (int j = 1; j <= hedges; j++)
-        if ((j == 1 || HOLES(j, 1) != HOLES(j - 1, 1)) && HOLES(j, 6) == POLYS(first, 1)) {
-          count++;
-          phi.push_back((int32_t)lround(HOLES(j, 1)));
-        }
-    }
-    php[(size_t)(id - h->minpolyid) + 1] = php[(size_t)(id - h->minpolyid)] + count;
+  // polyspecs / holespecs and the holes of every polygon: serial scans (lt_init_host.h)
+  std::vector<int32_t> ps, hs, php, phi;
+  {
+    long bad = 0;
+    const int rc = ltih::polyspecs_host(h->polys, pedges, h->minpolyid, h->maxpolyid, h->holes, hedges, h->minholeid,
+                                        h->maxholeid, ps, hs, php, phi, bad);
+    if (rc == 1) return fail(e, LT_ERR_ARG, "lt_create_polyspecs: polygon id %ld outside minpolyid..maxpolyid", bad);
+    if (rc == 2) return fail(e, LT_ERR_ARG, "lt_create_polyspecs: hole id %ld outside minholeid..maxholeid", bad);
   }
   // polygons of every rho element :293-386, on the device
   TRY(upload(e, e->polys, h->polys, (size_t)pedges * 5 * 8));
@@ -2929,52 +2810,8 @@ int lt_create_bounds(int32_t vi, int32_t uj, const int32_t* mask_rho, const doub
   if (vi < 5 || uj < 5 || !mask_rho || !x_u || !y_u || !x_v || !y_v || !nbounds_o || !maxbound_o || !maxisland_o ||
       !numislands_o || !bx || !by || !hx || !hy || !hid || !bnd_x || !bnd_y || !land)
     return LT_ERR_ARG;
-  ltb::Bounds B(vi, uj, mask_rho);
-  if (B.build() != 0) return LT_ERR_ARG;
-  const std::vector<ltb::Point>& P = B.points();
-  const int ui = vi - 1, numpoly = P.back().poly, numislands = numpoly - 1;
-  std::vector<int> size(numpoly + 1, 0), first(numpoly + 2, 0);
-  for (const ltb::Point& p : P) size[p.poly]++;
-  for (int m = 1; m <= numpoly; m++) first[m + 1] = first[m] + size[m];
-  const int maxbound = size[1] + 1;
-  int maxisland = numislands;
-  for (int m = 2; m <= numpoly; m++) maxisland += size[m];
-  const int nbounds = maxbound + maxisland - numislands - 1;
-  if (maxbound > cap || maxisland > cap || nbounds > cap) return LT_ERR_ARG;
-  auto xy = [&](const ltb::Point& p, double& x, double& y) {
-    if (p.onU) { x = x_u[(size_t)(p.i - 1) + (size_t)ui * (p.j - 1)]; y = y_u[(size_t)(p.i - 1) + (size_t)ui * (p.j - 1)]; }
-    else { x = x_v[(size_t)(p.i - 1) + (size_t)vi * (p.j - 1)]; y = y_v[(size_t)(p.i - 1) + (size_t)vi * (p.j - 1)]; }
-  };
-  // open ocean: a point on the rim of the grid next to a water node of the outermost ring (:1071-1079)
-  auto open_ocean = [&](const ltb::Point& p) {
-    if (p.onU) return (p.i == 1 && B.water(1, p.j)) || (p.i == vi - 1 && B.water(vi, p.j));
-    return (p.j == 1 && B.water(p.i, 1)) || (p.j == uj - 1 && B.water(p.i, uj));
-  };
-  std::vector<char> oo(maxbound, 0);
-  for (int k = 0; k < maxbound; k++) {   // the main polygon, closed by repeating its first point
-    const ltb::Point& p = P[first[1] + (k < size[1] ? k : 0)];
-    xy(p, bx[k], by[k]);
-    oo[k] = open_ocean(p);
-  }
-  int c = 0;
-  for (int m = 2; m <= numpoly; m++)
-    for (int k = 0; k <= size[m]; k++, c++) {
-      xy(P[first[m] + (k < size[m] ? k : 0)], hx[c], hy[c]);
-      hid[c] = m + 999;   // island ids start at 1001
-    }
-  for (int i = 0; i < maxbound - 1; i++) {
-    bnd_x[2 * i] = bx[i]; bnd_y[2 * i] = by[i]; bnd_x[2 * i + 1] = bx[i + 1]; bnd_y[2 * i + 1] = by[i + 1];
-    land[i] = (oo[i] && oo[i + 1]) ? 0 : 1;
-  }
-  int q = maxbound - 1;
-  for (int i = 0; i + 1 < maxisland; i++) {
-    if (hid[i] != hid[i + 1]) continue;   // (the closing point of one island and the first of the next)
-    bnd_x[2 * q] = hx[i]; bnd_y[2 * q] = hy[i]; bnd_x[2 * q + 1] = hx[i + 1]; bnd_y[2 * q + 1] = hy[i + 1];
-    land[q] = 1;
-    q++;
-  }
-  *nbounds_o = nbounds; *maxbound_o = maxbound; *maxisland_o = maxisland; *numislands_o = numislands;
-  return q == nbounds ? LT_OK : LT_ERR_ARG;
+  return ltb::create_bounds_arrays(vi, uj, mask_rho, x_u, y_u, x_v, y_v, cap, nbounds_o, maxbound_o, maxisland_o, numislands_o,
+                                  bx, by, hx, hy, hid, bnd_x, bnd_y, land) == 0 ? LT_OK : LT_ERR_ARG;
 }
 
 int lt_pack_positions(lt_engine* e, void* dst_device) {

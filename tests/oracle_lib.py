@@ -14,6 +14,9 @@ _vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
 
 
 def build_oracle():
+    # (tests/test_sanitizers.py: the sanitizer build of the oracle, made by `make -C oracle asan`)
+    if os.environ.get("LT_ORACLE_LIBRARY"):
+        return os.environ["LT_ORACLE_LIBRARY"]
     srcs = [os.path.join(ORACLE_DIR, f) for f in
             ("ltrans_oracle.c", "ltrans_oracle.h", "ltrans_oracle_engine.inc", "ltrans_oracle_init.inc")]
     if (not os.path.exists(ORACLE_SO)
