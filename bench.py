@@ -433,8 +433,19 @@ def cpu_baseline(ltrans_amd, args, spec, g, geo, bounds, records):
         e.update_particles(ex, run.internal_times(ex, it), 2, it)
     dt = time.perf_counter() - t0
     e.close()
+    # what the port costs against the reference's own Fortran where that compiles (oracle/_ref: the leaf modules,
+    # flang -O2): the same inputs through the same loops, oracle/time_leaves.py; None when _ref is not there
+    leaf = None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import time_leaves
+        leaf = time_leaves.measure(0.3)
+    except Exception as ex:          # noqa: BLE001 -- an extra of the baseline, never a reason to lose the line
+        sys.stderr.write(f"bench.py: leaf timing skipped: {ex}\n")
     return {"value": n * args.cpu_steps / dt, "unit": "particle-steps/s", "cores": 1,
             "kind": "port",
+            "port_vs_reference_leaf_ratio": (leaf["advection_step"]["ratio"] if leaf else None),
+            "port_vs_reference_leaves": leaf,
             "sample": f"{n} particles x {args.cpu_steps} internal steps on the same "
                       f"{spec['grid']} grid, {dt:.1f} s wall, {os.cpu_count()} host cores present"}
 

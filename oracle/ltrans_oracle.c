@@ -775,6 +775,51 @@ double lto_hpval(double T, int N, const double *X, const double *Y, const double
   }
 }
 
+/* ======================================================================== */
+/*  timing loops (oracle/time_leaves.py; bench.py's cpu_baseline leg): the  */
+/*  port's leaf routines called nrep times, as oracle/ref_shim.f90 calls    */
+/*  the reference's -- same inputs, same loop, so that the two compare.     */
+/* ======================================================================== */
+void lto_time_tspsi_hval(int nrep, int n, int nprof, const double *x, const double *y, const double *t, int neval,
+                         double *acc) {
+  double a = 0.0;
+  double xx[128], yy[128], yp[128], sigma[128];
+  if (n > 128) { *acc = 0.0; return; }
+  for (int r = 1; r <= nrep; r++) {
+    const int q = (r - 1) % nprof;
+    int ier = 0, sigerr = 0;
+    for (int i = 0; i < n; i++) { xx[i] = x[(size_t)q * n + i]; yy[i] = y[(size_t)q * n + i]; }
+    lto_tspsi(n, xx, yy, yp, sigma, &ier, &sigerr);
+    for (int k = 0; k < neval; k++) {
+      const double tt = t[(size_t)q * neval + k];
+      if (neval > 1) a += lto_hpval(tt, n, xx, yy, yp, sigma, &ier);
+      a += lto_hval(tt, n, xx, yy, yp, sigma, &ier);
+    }
+  }
+  *acc = a;
+}
+
+void lto_time_gridcell(int nrep, int elements, const double *ele_y, const double *ele_x, int npts, const double *px,
+                       const double *py, double *acc) {
+  double a = 0.0;
+  for (int r = 1; r <= nrep; r++) {
+    const int q = (r - 1) % npts, ce = (r - 1) % elements + 1;
+    int p_ele = 0, triangle = 0;
+    lto_gridcell(elements, ele_y, ele_x, px[q], py[q], &p_ele, &triangle, ce);
+    a += triangle;
+  }
+  *acc = a;
+}
+
+void lto_time_inpoly(int nrep, int n, const double *e, int npts, const double *px, const double *py, double *acc) {
+  double a = 0.0;
+  for (int r = 1; r <= nrep; r++) {
+    const int q = (r - 1) % npts;
+    if (lto_inpoly(px[q], py[q], n, e, -1)) a += 1.0;
+  }
+  *acc = a;
+}
+
 #include "ltrans_oracle_engine.inc"
 #include "ltrans_oracle_init.inc"
 #include "ltrans_oracle_bounds.inc"

@@ -145,4 +145,57 @@ contains
     call snhcsh(xx, sinhm, coshm, coshmm)
   end subroutine
 
+  ! ---- timing loops (oracle/time_leaves.py): the reference's routines called nrep times from Fortran, so that what is
+  ! timed is the routine and not the foreign-function call.  x, y, t hold nprof profiles / points that are cycled.
+  ! acc (a sum of the results) keeps the work alive.
+  subroutine ref_time_tspsi_hval(nrep, n, nprof, x, y, t, neval, acc) bind(C, name="ref_time_tspsi_hval")
+    use tension_mod, only: tspsi, hval, hpval
+    integer(c_int), value :: nrep, n, nprof, neval
+    real(c_double), intent(in) :: x(n, nprof), y(n, nprof), t(neval, nprof)
+    real(c_double), intent(out) :: acc
+    real(c_double) :: xx(n), yy(n), yp(n), sigma(n), tt
+    integer :: r, k, q, ier, sigerr
+    acc = 0.0d0
+    do r = 1, nrep
+      q = mod(r - 1, nprof) + 1
+      xx = x(:, q); yy = y(:, q)
+      sigerr = 0
+      call tspsi(n, xx, yy, yp, sigma, ier, sigerr)
+      do k = 1, neval
+        tt = t(k, q)
+        if (neval > 1) acc = acc + hpval(tt, n, xx, yy, yp, sigma, ier)
+        acc = acc + hval(tt, n, xx, yy, yp, sigma, ier)
+      enddo
+    enddo
+  end subroutine
+
+  subroutine ref_time_gridcell(nrep, elements, ele_y, ele_x, npts, px, py, acc) bind(C, name="ref_time_gridcell")
+    use gridcell_mod, only: gridcell
+    integer(c_int), value :: nrep, elements, npts
+    real(c_double), intent(in) :: ele_x(4, elements), ele_y(4, elements), px(npts), py(npts)
+    real(c_double), intent(out) :: acc
+    integer :: r, q, p_ele, triangle, ce
+    acc = 0.0d0
+    do r = 1, nrep
+      q = mod(r - 1, npts) + 1
+      ce = mod(r - 1, elements) + 1
+      p_ele = 0; triangle = 0
+      call gridcell(elements, ele_y, ele_x, px(q), py(q), p_ele, triangle, ce)
+      acc = acc + triangle
+    enddo
+  end subroutine
+
+  subroutine ref_time_inpoly(nrep, n, e, npts, px, py, acc) bind(C, name="ref_time_inpoly")
+    use pip_mod, only: inpoly
+    integer(c_int), value :: nrep, n, npts
+    real(c_double), intent(in) :: e(n, 2), px(npts), py(npts)
+    real(c_double), intent(out) :: acc
+    integer :: r, q
+    acc = 0.0d0
+    do r = 1, nrep
+      q = mod(r - 1, npts) + 1
+      if (inpoly(px(q), py(q), n, e)) acc = acc + 1.0d0
+    enddo
+  end subroutine
+
 end module ltrans_ref_shim
