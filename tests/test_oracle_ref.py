@@ -83,3 +83,34 @@ def test_inpoly_random(pair):
             x, y = (np.round(rng.uniform(-11, 11, 2)) if rng.random() < 0.5 else rng.uniform(-11, 11, 2))
             for onin in (-1, 0, 1):
                 assert O.inpoly(x, y, P, onin) == R.inpoly(x, y, P, onin)
+
+
+def test_timing_loops_of_port_and_reference_compute_the_same(pair):
+    """oracle/time_leaves.py compares the cost of the port with the reference's: the two loops must do the same work
+    -- their accumulated results are identical, bit for bit"""
+    import ctypes as C
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import time_leaves as tl
+    ora, ref = C.CDLL(tl.ORACLE_SO), C.CDLL(tl.REF_SO)
+    inp = tl._inputs()
+    vp = tl._vp
+
+    def acc_of(lib, prefix, name, args):
+        a = C.c_double()
+        getattr(lib, prefix + name)(*args, C.byref(a))
+        return a.value
+
+    for n in (4, 124):
+        x, y, t, neval = inp[n]
+        args = (C.c_int(3000), C.c_int(n), C.c_int(x.shape[0]), vp(x), vp(y), vp(t), C.c_int(neval))
+        assert acc_of(ora, "lto_time_", "tspsi_hval", args) == acc_of(ref, "ref_time_", "tspsi_hval", args)
+    ex, ey, px, py, ne = inp["gridcell"]
+    args = (C.c_int(20000), C.c_int(ne), vp(ey), vp(ex), C.c_int(px.size), vp(px), vp(py))
+    a, b = acc_of(ora, "lto_time_", "gridcell", args), acc_of(ref, "ref_time_", "gridcell", args)
+    assert a == b and a > 100
+    e, qx, qy = inp["inpoly"]
+    args = (C.c_int(4000), C.c_int(e.shape[0]), vp(e), C.c_int(qx.size), vp(qx), vp(qy))
+    a, b = acc_of(ora, "lto_time_", "inpoly", args), acc_of(ref, "ref_time_", "inpoly", args)
+    assert a == b and 100 < a < 3900
