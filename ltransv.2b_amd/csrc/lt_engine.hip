@@ -1459,9 +1459,12 @@ int lt_set_particles(lt_engine* e, const lt_particles* p) {
     if (e->cfg.VTurbOn) {
       // p2 = 4*ws knots per particle, [wave][knot][lane] records {x, y, yp, sigma}
       TRY(dev_alloc(e, e->vt_tab, (size_t)4 * e->cfg.ws * ((n + 63) / 64 * 64) * 32));
-      // task lists of the SIGS iterations: room for a quarter of a wave's intervals (~9 % need one)
+      // task lists of the SIGS iterations
       const size_t waves = (n + 63) / 64;
-      e->vt_qcap = 64 * e->cfg.ws;
+      // (room for every interval of every lane: 4*ws - 1 per profile.  ~9 % of them are listed on the bench
+      // workload, but a list that cannot overflow lets k_vt_table do without an in-lane SIGS iteration -- a real
+      // function call in its knot loop, with the scalar registers and the stack slots that go with one)
+      e->vt_qcap = 64 * 4 * e->cfg.ws;
       TRY(dev_alloc(e, e->vt_qS, waves * e->vt_qcap * 8)); TRY(dev_alloc(e, e->vt_qS1, waves * e->vt_qcap * 8));
       TRY(dev_alloc(e, e->vt_qS2, waves * e->vt_qcap * 8)); TRY(dev_alloc(e, e->vt_qwl, waves * e->vt_qcap * 2));
       TRY(dev_alloc(e, e->vt_qcount, waves * 4 + 4));

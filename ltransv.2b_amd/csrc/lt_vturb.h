@@ -204,18 +204,7 @@ LT_DEV void vt_seek(VtInterval& c, double T, int n, const double4* tab) {
 // wave in HBM (S, S1, S2, knot, lane: 26 bytes) and iterated by k_vt_sigs, 64 at a time, at the
 // occupancy that kernel's few registers allow.  (Iterating them inside the table kernel -- 255
 // VGPRs, two waves per SIMD -- cost 1.2 ms per step; a kernel that re-read the whole table to
-// find them 0.95 ms.)  A wave whose list is full iterates the interval in its own lane.
-
-// (the table kernel's overflow path: out of line, so that its registers are not the stream's)
-__device__ __noinline__ double sigs_in_lane(double S, double S1, double S2, int* failed) {
-  double sg = 0.0, T = 0.0;
-  bool f = false;
-  const int kind = sigs_classify(S, S1, S2, sg, T);
-  if (kind == SIGK_NEWTON) sg = sigs_newton(T, f);
-  else if (kind == SIGK_SECANT) sg = sigs_secant(S, S1, S2);
-  *failed = f ? 1 : 0;
-  return sg;
-}
+// find them 0.95 ms.)  A list has room for every interval of its wave.
 
 // VTurb, ver_turb_module.f90:30-380, as four kernels:
 //   k_vt_table  one lane per particle: builds the spline table of the time-interpolated, smoothed Kh
@@ -274,11 +263,28 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
   const SlabT* K = (const SlabT*)P.Kh;
   const int pslot[3] = {P.tb, P.tc, P.tf};
   const unsigned fsm = (P.FreeSlip && act) ? P.fsR[P.P_r_element[na] - 1] : 15u;  // free slip, :1934-1994
+  // getInterp (hydrodynamic_module.f90:1997-2003) is v1+(v2-v1)t+(v3-v1)u in the first triangle and the same form on
+  // the nodes (3,4,1) in the second (and on a node): the node ids of such a lane are rotated once, here, so that the
+  // ~400 interpolations of the profile are one expression without a branch on the lane's regime.  A lane whose
+  // element has a land node under free slip (the substitution works on the nodes in element order) or that takes
+  // the inverse-distance weights keeps the order and the general form (`plain` false: rare).
+  const bool plain = (fsm == 15u) && (w0.regime != 3);
+  if (plain && (w0.regime == 2 || w0.regime == 4)) {
+    const int tx = rn.x, ty = rn.y;
+    rn.x = rn.z; rn.y = rn.w; rn.z = tx; rn.w = ty;
+  }
+  auto GI = [&](double f1, double f2, double f3, double f4) -> double {
+    double r = f1 + (f2 - f1) * w0.t + (f3 - f1) * w0.u;
+    if (!plain) {
+      if (fsm != 15u) freeslip_sub(0, fsm, 15u, f1, f2, f3, f4);
+      r = apply_getinterp(w0, f1, f2, f3, f4);
+    }
+    return r;
+  };
   auto KH = [&](int s, int i) -> double {  // Pwc_KH{b,c,f}(i) :102-108
-    double f1 = fld(K, rn.x, ws, i, pslot[s]), f2 = fld(K, rn.y, ws, i, pslot[s]);
-    double f3 = fld(K, rn.z, ws, i, pslot[s]), f4 = fld(K, rn.w, ws, i, pslot[s]);
-    if (fsm != 15u) freeslip_sub(0, fsm, 15u, f1, f2, f3, f4);
-    return apply_getinterp(w0, f1, f2, f3, f4);
+    const double f1 = fld(K, rn.x, ws, i, pslot[s]), f2 = fld(K, rn.y, ws, i, pslot[s]);
+    const double f3 = fld(K, rn.z, ws, i, pslot[s]), f4 = fld(K, rn.w, ws, i, pslot[s]);
+    return GI(f1, f2, f3, f4);
   };
   const Divisor dvh = prep_div((VT == 2) ? P.hc + h : h);  // every level depth divides by it
   auto WZ = [&](int s, int i) -> double {  // Pwc_wz{b,c,f}(i)
@@ -300,10 +306,15 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
   int jlo[3] = {1, 1, 1};
   double slope[3], icpt[3], wzhi[3], khhi[3];
   SlabT rawn[3][4];
+  // (32-bit byte offsets from the slab's base: lt_set_grid refuses a slab of 4 GiB)
+  const unsigned esz = (unsigned)sizeof(SlabT), L3b = (unsigned)(ws * LT_SLOTS) * esz;
+  const unsigned nb0 = (unsigned)(rn.x - 1) * L3b, nb1 = (unsigned)(rn.y - 1) * L3b, nb2 = (unsigned)(rn.z - 1) * L3b,
+                 nb3 = (unsigned)(rn.w - 1) * L3b;
+  const char* Kb = (const char*)K;
   auto RAW = [&](int s, int i) {
-    const size_t o = (size_t)(i - 1) * LT_SLOTS + pslot[s], L3 = (size_t)ws * LT_SLOTS;
-    rawn[s][0] = K[(size_t)(rn.x - 1) * L3 + o]; rawn[s][1] = K[(size_t)(rn.y - 1) * L3 + o];
-    rawn[s][2] = K[(size_t)(rn.z - 1) * L3 + o]; rawn[s][3] = K[(size_t)(rn.w - 1) * L3 + o];
+    const unsigned o = (unsigned)((i - 1) * LT_SLOTS + pslot[s]) * esz;
+    rawn[s][0] = *(const SlabT*)(Kb + (nb0 + o)); rawn[s][1] = *(const SlabT*)(Kb + (nb1 + o));
+    rawn[s][2] = *(const SlabT*)(Kb + (nb2 + o)); rawn[s][3] = *(const SlabT*)(Kb + (nb3 + o));
   };
   auto LINE = [&](int s, double a, double b, double ka, double kb) {
     slope[s] = (ka - kb) / (a - b);
@@ -319,9 +330,7 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
   auto NEWY_AT = [&](int s, double xj) -> double {  // newy{b,c,f}(j) at its abscissa xj = newx(j), j = 5..p2+3
     while (!(wzhi[s] > xj) && jlo[s] < ws - 1) {
       jlo[s] += 1;
-      double g1 = (double)rawn[s][0], g2 = (double)rawn[s][1], g3 = (double)rawn[s][2], g4 = (double)rawn[s][3];
-      if (fsm != 15u) freeslip_sub(0, fsm, 15u, g1, g2, g3, g4);
-      const double kb = apply_getinterp(w0, g1, g2, g3, g4);
+      const double kb = GI((double)rawn[s][0], (double)rawn[s][1], (double)rawn[s][2], (double)rawn[s][3]);
       LINE(s, wzhi[s], WZ(s, jlo[s] + 1), khhi[s], kb);
       if (jlo[s] + 2 <= ws) RAW(s, jlo[s] + 2);
     }
@@ -344,23 +353,16 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
   int ntask = 0;  // wave-uniform: intervals on this wave's task list
   const VtQueue Q = P.vt_q;
   const size_t qb = (size_t)wave * (size_t)Q.cap;
-  bool lane_failed = false;
   // one interval of SIGS (tension_module.f90:448-776) as soon as its end derivatives exist: tension
   // zero, or onto the task list (the known-SBIG case goes through the list too: rare)
   auto SIGMA = [&](bool on, double S, double S1, double S2, int where) -> double {
-    double sg_here = 0.0;  // what the owner stores with the knot (the list's results are written later)
+    const double sg_here = 0.0;  // what the owner stores with the knot (the list's results are written later)
     const bool need = on && !sigs_eval_zero(S, S1, S2);
     const unsigned long long m = __ballot(need);
-    if (need) {
+    if (need) {   // (the list has room for every interval of the wave: lt_set_particles)
       const int idx = ntask + __popcll(m & ((1ull << lane) - 1ull));
-      if (idx < Q.cap) {
-        Q.S[qb + idx] = S; Q.S1[qb + idx] = S1; Q.S2[qb + idx] = S2;
-        Q.wl[qb + idx] = (unsigned short)((where << 6) | lane);
-      } else {  // list full (a profile that queues > 25 % of its intervals): iterate here, in this lane
-        int failed = 0;
-        sg_here = sigs_in_lane(S, S1, S2, &failed);
-        lane_failed = lane_failed || (failed != 0);
-      }
+      Q.S[qb + idx] = S; Q.S1[qb + idx] = S1; Q.S2[qb + idx] = S2;
+      Q.wl[qb + idx] = (unsigned short)((where << 6) | lane);
     }
     ntask += __popcll(m);
     return sg_here;
@@ -489,7 +491,6 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
   if (act) {
     int f2 = fl & ~(FL_VT_YPCFAIL | FL_VT_SIGERR);
     if (ypc_fail) f2 |= FL_VT_YPCFAIL;
-    else if (lane_failed) f2 |= FL_VT_SIGERR;
     if (f2 != fl) P.ws_i[n] = f2;
   }
 }
