@@ -355,17 +355,16 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
   const size_t qb = (size_t)wave * (size_t)Q.cap;
   // one interval of SIGS (tension_module.f90:448-776) as soon as its end derivatives exist: tension
   // zero, or onto the task list (the known-SBIG case goes through the list too: rare)
+  // (the screening as lane masks, lt_math.h: LaneMask; every lane of the wave is here)
   auto SIGMA = [&](bool on, double S, double S1, double S2, int where) -> double {
-    const double sg_here = 0.0;  // what the owner stores with the knot (the list's results are written later)
-    const bool need = on && !sigs_eval_zero(S, S1, S2);
-    const unsigned long long m = __ballot(need);
-    if (need) {   // (the list has room for every interval of the wave: lt_set_particles)
+    const LaneMask m = lm(on) & ~sigs_eval_zero_mask(S, S1, S2);
+    if (lm_lane(m)) {   // (the list has room for every interval of the wave: lt_set_particles)
       const int idx = ntask + __popcll(m & ((1ull << lane) - 1ull));
       Q.S[qb + idx] = S; Q.S1[qb + idx] = S1; Q.S2[qb + idx] = S2;
       Q.wl[qb + idx] = (unsigned short)((where << 6) | lane);
     }
     ntask += __popcll(m);
-    return sg_here;
+    return 0.0;  // what the owner stores with the knot (the list's results are written later by k_vt_sigs)
   };
   // newx(k+7) of the knot in hand is newx(k+8) of the one before: kept (the reference recomputes each newx
   // three times: as the end of the 8-point window, as its last-but-one point, and as its start)
