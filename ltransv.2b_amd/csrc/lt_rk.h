@@ -25,7 +25,7 @@ template <> struct __attribute__((packed, aligned(8))) Win4<double> { double v[4
 
 // what a stage of k_rk needs first and what the step to the next stage needs: requested before the
 // last round of pass B of the stage before, so that the round covers their latency
-struct StageIn { double zb, zc, zf; int4 nd0; int ii, iii; };   // zetas, node ids of the u element, last windows
+struct StageIn { double zb, zc, zf; int4 nd0, nd1; int ii, iii; };   // zetas, node ids of the u and v elements, last windows
 struct StageTail { double X, Y, Zpar, cosA, sinA, minpd, maxpd; };
 // the per-particle context that find_currents needs (registers)
 struct Column {
@@ -300,202 +300,265 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
   // NEXT variable's element, and the 4x4 field values + zeta + depth of the NEXT time
   // slot, are requested before the arithmetic of the current one (same registers: the
   // raw values are dead once the horizontal interpolation has produced Y).
-  int4 nd_next = SI.nd0;
   int nchk = 0, nev = 0;  // wave-uniform task counts of this stage
   double zt = 0.0, pz = 0.0;
   SlabT raw[16];
-  LevCoef lc[4];   // (kept from the U fit to the V fit: the same four rho levels)
-#pragma unroll 1
-  for (int var = 0; var < 3; var++) {
-    const int4 nd = nd_next;
-    const SlabT* F = (const SlabT*)((var == 0) ? P.U : (var == 1) ? P.V : P.W);
-    const int L = (var == 2) ? P.ws : P.us;
-    const double* tab = (var == 2) ? wtab : rtab;
-    const int k0 = (var == 2) ? iii : ii;
-    // The 16 field values (4 nodes x 4 levels) of a time slot -- one 16-byte access per node in
-    // the level-fastest layout -- its zeta and its depth are requested one slot ahead of their
-    // use, into the registers the previous slot's values just left.
-    // (32-bit byte offsets from the slab's base -- lt_set_grid refuses a slab of 4 GiB: a scalar base and a vector
-    // offset are what a global load takes; 64-bit pointers per node cost ten vector instructions each to form)
-    const unsigned esz = (unsigned)sizeof(SlabT), rowb = (unsigned)(LT_SLOTS * L) * esz, kb = (unsigned)(k0 - 1) * esz;
-    unsigned e0 = (unsigned)(nd.x - 1) * rowb + kb, e1 = (unsigned)(nd.y - 1) * rowb + kb;
-    unsigned e2 = (unsigned)(nd.z - 1) * rowb + kb, e3 = (unsigned)(nd.w - 1) * rowb + kb;
-    const char* Fb = (const char*)F;
-    auto request = [&](int s) {
-      const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
-      const unsigned o = (unsigned)(ps * L) * esz;
-      const Win4<SlabT> q0 = *(const Win4<SlabT>*)(Fb + (e0 + o)), q1 = *(const Win4<SlabT>*)(Fb + (e1 + o));
-      const Win4<SlabT> q2 = *(const Win4<SlabT>*)(Fb + (e2 + o)), q3 = *(const Win4<SlabT>*)(Fb + (e3 + o));
+  LevCoef lc[4];
+  const unsigned esz = (unsigned)sizeof(SlabT);
+  // one (variable, time slot) of a stage: the 16 field values (4 nodes x 4 levels: one 16-byte access per node in
+  // the level-fastest layout, at 32-bit byte offsets e[] from the slab's base -- lt_set_grid refuses a slab of
+  // 4 GiB) are requested one fit ahead of their use, into the registers the previous fit's values just left
+  auto request = [&](const char* Fb, const unsigned (&e)[4], int L, int s) {
+    const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
+    const unsigned o = (unsigned)(ps * L) * esz;
+    const Win4<SlabT> q0 = *(const Win4<SlabT>*)(Fb + (e[0] + o)), q1 = *(const Win4<SlabT>*)(Fb + (e[1] + o));
+    const Win4<SlabT> q2 = *(const Win4<SlabT>*)(Fb + (e[2] + o)), q3 = *(const Win4<SlabT>*)(Fb + (e[3] + o));
 #pragma unroll
-      for (int l = 0; l < 4; l++) {
-        raw[4 * l + 0] = q0.v[l]; raw[4 * l + 1] = q1.v[l];
-        raw[4 * l + 2] = q2.v[l]; raw[4 * l + 3] = q3.v[l];
-      }
-      zt = wsd[(size_t)(WS_ZETA0 + s) * N];
-      pz = wsd[(size_t)(WS_PZ0 + s) * N];
-    };
-    request(0);
-    Quad q;
-    if (var == 2) q = load_quad16(P.rnode, nd, (unsigned)sizeof(RhoNode));
-    else if (var == 0) q = load_quad16(P.unode, nd, (unsigned)sizeof(XYNode));
-    else q = load_quad16(P.vnode, nd, (unsigned)sizeof(XYNode));
-    if (var == 0) nd_next = P.VE[ev_ - 1];
-    else if (var == 1) nd_next = P.RE[er - 1];
-    const QuadWeights w = quad_weights_f(Xs, Ys, q.x, q.y);
-    // The second-triangle form (regime 2) is the first-triangle form on the nodes (3,4,1):
-    // v3+(v4-v3)t+(v1-v3)u.  Instead of selecting the operands at every one of the 12
-    // interpolations of this variable, the node order itself is rotated once: the values of
-    // slot 0 (already requested) with one select each on the stored type, the base pointers
-    // for the two later requests.  Regimes 3 / 4 (inverse distance, on a node) keep (1,2,3,4).
-    if (w.regime == 2) {   // (register swaps: v_swap_b32, which the compiler does not use, is one instruction per pair)
+    for (int l = 0; l < 4; l++) {
+      raw[4 * l + 0] = q0.v[l]; raw[4 * l + 1] = q1.v[l];
+      raw[4 * l + 2] = q2.v[l]; raw[4 * l + 3] = q3.v[l];
+    }
+  };
+  auto request_zp = [&](int s) {   // zeta and P_z of a time slot (the same for the three variables)
+    zt = wsd[(size_t)(WS_ZETA0 + s) * N];
+    pz = wsd[(size_t)(WS_PZ0 + s) * N];
+  };
+  auto offsets = [&](const int4& nd, int L, int k0, unsigned (&e)[4]) {
+    const unsigned rowb = (unsigned)(LT_SLOTS * L) * esz, kb = (unsigned)(k0 - 1) * esz;
+    e[0] = (unsigned)(nd.x - 1) * rowb + kb; e[1] = (unsigned)(nd.y - 1) * rowb + kb;
+    e[2] = (unsigned)(nd.z - 1) * rowb + kb; e[3] = (unsigned)(nd.w - 1) * rowb + kb;
+  };
+  // The second-triangle form (regime 2) is the first-triangle form on the nodes (3,4,1): v3+(v4-v3)t+(v1-v3)u.
+  // Instead of selecting the operands at every one of the 12 interpolations of a variable, the node order itself
+  // is rotated once (register swaps: v_swap_b32, which the compiler does not use, is one instruction per pair).
+  // Regimes 3 / 4 (inverse distance, on a node) keep (1,2,3,4).
+  auto rotate_offsets = [&](const QuadWeights& w, unsigned (&e)[4]) {
+    if (w.regime == 2) { reg_swap(e[0], e[2]); reg_swap(e[1], e[3]); }
+  };
+  auto rotate_raw = [&](const QuadWeights& w) {
+    if (w.regime == 2) {
 #pragma unroll
       for (int l = 0; l < 4; l++) { reg_swap(raw[4 * l + 0], raw[4 * l + 2]); reg_swap(raw[4 * l + 1], raw[4 * l + 3]); }
-      reg_swap(e0, e2); reg_swap(e1, e3);
     }
+  };
+  // the level geometry of a time slot -- the four level depths, their spacings, the five prepared divisors of YPC1 --
+  // is the same for U and V (the same four rho levels, the same zeta): formed once per slot for the two
+  double X[4], DX1 = 1.0, DX2 = 1.0, DX3 = 1.0;
+  Divisor d1, d2, d3, d12, d23;
+  LaneMask OK = 0ull;
+  auto geometry = [&](double zeta) {
+#pragma unroll
+    for (int l = 0; l < 4; l++) X[l] = level_at(lc[l], zeta, h, VT);
+    DX1 = X[1] - X[0]; DX2 = X[2] - X[1]; DX3 = X[3] - X[2];
+    // Lane conditions are kept as 64-bit lane masks (LaneMask: the scalar result of a vector compare) and
+    // combined with scalar instructions; written as `bool`s the compiler turns every and-or of them into a
+    // select, which it builds in a vector register and compares back: ~18 vector instructions per slot.
+    OK = SPL & lm(DX1 > 0.0) & lm(DX2 > 0.0) & lm(DX3 > 0.0);
+    // (seven quotients of YPC1 over five divisors: the reciprocals are prepared once)
+    d1 = prep_div(DX1); d2 = prep_div(DX2); d3 = prep_div(DX3);
+    d12 = prep_div(DX1 + DX2); d23 = prep_div(DX2 + DX3);
+  };
+  // horizontal interpolation of the 4 levels of the slot in `raw`
+  auto interp = [&](const QuadWeights& w, double (&Y)[4]) {
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+      const double v1 = (double)raw[4 * l + 0], v2 = (double)raw[4 * l + 1], v3 = (double)raw[4 * l + 2];
+      Y[l] = v1 + (v2 - v1) * w.t + (v3 - v1) * w.u;
+    }
+    if (w.regime >= 3) {  // the stage position has left the start element (a few % of the lanes)
+#pragma unroll
+      for (int l = 0; l < 4; l++) {
+        const double v1 = (double)raw[4 * l + 0], v2 = (double)raw[4 * l + 1], v3 = (double)raw[4 * l + 2],
+                     v4 = (double)raw[4 * l + 3];
+        if (w.regime == 3) Y[l] = w.W1 * v1 + w.W2 * v2 + w.W3 * v3 + w.W4 * v4;
+        else Y[l] = (w.node_hit == 1) ? v1 : (w.node_hit == 2) ? v2 : (w.node_hit == 3) ? v3 : v4;
+      }
+    }
+  };
+  // the queues must have room for a fit (up to 64 evaluation and 128 check intervals): else one full round of
+  // pass B first -- the check intervals waiting and the last 64 - nchk evaluation intervals (a second round if the
+  // check intervals alone filled the first).  Wave-uniform.
+  auto make_room = [&]() {
+    while (nev + 64 > LT_EV_CAP || nchk + 64 > LT_CHK_CAP) {
+      const int nc = (nchk < LT_CHK_CAP) ? nchk : LT_CHK_CAP;  // (entries beyond the capacity were not stored)
+      const int room = (nc < 64) ? 64 - nc : 0;
+      const int take = (nev < room) ? nev : room;
+      run_tasks(ws, nc, nev, lane, nev - take);
+      nev -= take;
+      nchk = 0;
+      TICK(4);
+    }
+  };
+  // YPC1, the screening of the three intervals, the queues, HVAL of the zero-tension case: the fit of one
+  // (variable, slot) on the geometry in hand
+  auto fit = [&](const double (&Y)[4], const int slot9, const double Pzs) {
+    degenerate |= lm_lane(SPL & ~OK) ? (1u << slot9) : 0u;
+    // YPC1 (tension_module.f90:852-977) with the chord slopes kept for SIGS/HVAL
+    double YP[4], SL[3];
+    SL[0] = div_prep(Y[1] - Y[0], d1);
+    SL[1] = div_prep(Y[2] - Y[1], d2);
+    SL[2] = div_prep(Y[3] - Y[2], d3);
+    YP[0] = ypc1_end_b(SL[0], SL[0] + div_prep(DX1 * (SL[0] - SL[1]), d12));
+    YP[1] = ypc1_mid_b(DX1, DX2, d12, SL[0], SL[1]);
+    YP[2] = ypc1_mid_b(DX2, DX3, d23, SL[1], SL[2]);
+    YP[3] = ypc1_end_b(SL[2], SL[2] + div_prep(DX3 * (SL[2] - SL[1]), d23));
+    // the evaluation interval :1044-1053 (extrapolates with the end intervals)
+    // (for strictly increasing knots "T > X(4) -> interval 3" is implied; other windows are redone by k_rk_slow)
+    const LaneMask I1 = lm(Pzs < X[1]), I2 = ~I1 & lm(Pzs < X[2]), I3 = ~I1 & ~I2;
+    const bool i1 = lm_lane(I1), i2 = lm_lane(I2);
+    const double x1 = i1 ? X[0] : i2 ? X[1] : X[2];
+    const double x2 = i1 ? X[1] : i2 ? X[2] : X[3];
+    const double y1 = i1 ? Y[0] : i2 ? Y[1] : Y[2];
+    const double p1 = i1 ? YP[0] : i2 ? YP[1] : YP[2];
+    const double p2 = i1 ? YP[1] : i2 ? YP[2] : YP[3];
+    const double Sv = i1 ? SL[0] : i2 ? SL[1] : SL[2];
+    Divisor dI;
+    dI.b = i1 ? d1.b : i2 ? d2.b : d3.b;
+    dI.y = i1 ? d1.y : i2 ? d2.y : d3.y;
+    TICK(2);
+    // SIGS (tension_module.f90:448-776), screened without divisions or loops.
+    // Only the evaluation interval's tension is used by HVAL; the other two
+    // matter only through SigErr, which only the convexity Newton iteration
+    // can raise, so they are queued just when they are Newton candidates.
+    const LaneMask C0 = sigs_candidate_mask(SL[0], YP[0], YP[1]), C1 = sigs_candidate_mask(SL[1], YP[1], YP[2]),
+                   C2 = sigs_candidate_mask(SL[2], YP[2], YP[3]);
+    // the two non-evaluation intervals: I=1 -> (2,3), I=2 -> (1,3), I=3 -> (1,2)
+    const LaneMask ma = OK & ((I1 & C1) | (~I1 & C0)), mb = OK & ((I3 & C1) | (~I3 & C2));
+    // the evaluation interval: done here when its tension is known to be ZERO (the cubic form);
+    // everything else (an iteration, or the rare known SBIG) goes to pass B
+    const LaneMask me = OK & ~sigs_eval_zero_mask(Sv, p1, p2);
+    const LaneMask mc = ma | mb;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (mc) {  // ~1 % of the intervals are candidates: the operands of T = MAX(D1/D2, D2/D1)
+      if (lm_lane(ma)) {
+        double na, da;
+        if (i1) (void)sigs_candidate(SL[1], YP[1], YP[2], na, da);
+        else (void)sigs_candidate(SL[0], YP[0], YP[1], na, da);
+        const int idx = nchk + __popcll(ma & below);
+        if (idx < LT_CHK_CAP) {
+          ws.chk[idx][0] = na; ws.chk[idx][1] = da;
+          ws.chk_owner[idx] = (unsigned short)(lane | (slot9 << 6));
+        } else degenerate |= (1u << slot9);
+      }
+      nchk += __popcll(ma);
+      if (lm_lane(mb)) {
+        double nb, db;
+        if (lm_lane(I3)) (void)sigs_candidate(SL[1], YP[1], YP[2], nb, db);
+        else (void)sigs_candidate(SL[2], YP[2], YP[3], nb, db);
+        const int idx = nchk + __popcll(mb & below);
+        if (idx < LT_CHK_CAP) {
+          ws.chk[idx][0] = nb; ws.chk[idx][1] = db;
+          ws.chk_owner[idx] = (unsigned short)(lane | (slot9 << 6));
+        } else degenerate |= (1u << slot9);
+      }
+      nchk += __popcll(mb);
+    }
+    if (lm_lane(me)) {
+      const int idx = nev + __popcll(me & below);
+      double* e = ws.ev[idx];
+      e[0] = x1; e[1] = x2; e[2] = y1; e[3] = p1; e[4] = p2; e[5] = Sv; e[6] = Pzs;
+      ws.ev_owner[idx] = (unsigned short)(lane | (slot9 << 6));
+    }
+    nev += __popcll(me);
+#ifdef LT_RK_TIMING
+    if (lane == 0) ws.tim[6] += __popcll(me);
+#endif
+    // HVAL of the zero-tension case, stored by every lane (pass B overwrites the queued ones,
+    // the log layer below the others that do not fit a spline)
+    ws.res[slot9][lane] = hval_cubic_d(Pzs, x1, dI, y1, p1, p2, Sv);
+    TICK(3);
+  };
+  // the log layer :1493-1522 (level 1 of u, v; level 2 of w) for the lanes below the deepest rho level: after the
+  // fits of the variable, whose stores it overwrites
+  auto log_layer = [&](int var, const int4& nd, const SlabT* F, int L) {
+    const int k = (var == 2) ? 2 : 1;
+    const Quad q = (var == 2) ? load_quad16(P.rnode, nd, (unsigned)sizeof(RhoNode))
+                 : load_quad16((var == 0) ? (const void*)P.unode : (const void*)P.vnode, nd, (unsigned)sizeof(XYNode));
+    const LevCoef qt = level_coef_d((var == 2) ? wtab : rtab, k, h, P.hc, VT, dv);
+    const QuadWeights wl = quad_weights(Xs, Ys, q.x, q.y);
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+      const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
+      const double zeta = wsd[(size_t)(WS_ZETA0 + s) * N];
+      double val = apply_interp(wl, fldv(F, nd.x, L, k, ps), fldv(F, nd.y, L, k, ps),
+                                fldv(F, nd.z, L, k, ps), fldv(F, nd.w, L, k, ps));
+      double ztop = level_at(qt, zeta, h, VT);
+      ws.res[var * 3 + s][lane] = val * log10_call((Zs - wzb1) / P.z0) / log10_call((ztop - wzb1) / P.z0);
+    }
+  };
+  // ---- U and V: the two set-ups, then slot by slot the shared geometry and the two fits
+  {
+    const int4 ndU = SI.nd0, ndV = SI.nd1;
+    const int L = P.us;
+    const char* FbU = (const char*)P.U;
+    const char* FbV = (const char*)P.V;
+    unsigned eU[4], eV[4];
+    offsets(ndU, L, ii, eU);
+    offsets(ndV, L, ii, eV);
+    request(FbU, eU, L, 0);
+    request_zp(0);
+    const Quad qU = load_quad16(P.unode, ndU, (unsigned)sizeof(XYNode));
+    const QuadWeights wU = quad_weights_f(Xs, Ys, qU.x, qU.y);
+    rotate_offsets(wU, eU);
+    rotate_raw(wU);
+    const Quad qV = load_quad16(P.vnode, ndV, (unsigned)sizeof(XYNode));
+    const QuadWeights wV = quad_weights_f(Xs, Ys, qV.x, qV.y);
+    rotate_offsets(wV, eV);
+#ifdef LT_RK_TIMING
+    { const unsigned long long m3 = __ballot(spl && (wU.regime >= 3 || wV.regime >= 3)); if (lane == 0) ws.tim[7] += __popcll(m3) + ((m3 != 0) ? (1ull << 32) : 0ull); }
+#endif
+    TICK(1);
+#pragma unroll
+    for (int l = 0; l < 4; l++) lc[l] = level_coef_d(rtab, ii + l, h, P.hc, VT, dv);
+#pragma unroll 1
+    for (int s = 0; s < 3; s++) {
+      make_room();
+      const double Pzs = pz;
+      geometry(zt);
+      double Y[4];
+      interp(wU, Y);
+      request(FbV, eV, L, s);            // V's values of this slot arrive while U is fitted
+      fit(Y, s, Pzs);
+      make_room();
+      interp(wV, Y);
+      if (s < 2) { request(FbU, eU, L, s + 1); request_zp(s + 1); }
+      fit(Y, 3 + s, Pzs);
+    }
+    if (loglayer) {
+      log_layer(0, ndU, (const SlabT*)P.U, L);
+      log_layer(1, ndV, (const SlabT*)P.V, L);
+    }
+  }
+  // ---- W
+  {
+    const int4 nd = P.RE[er - 1];
+    const int L = P.ws;
+    const char* Fb = (const char*)P.W;
+    unsigned e[4];
+    offsets(nd, L, iii, e);
+    request(Fb, e, L, 0);
+    request_zp(0);
+    const Quad q = load_quad16(P.rnode, nd, (unsigned)sizeof(RhoNode));
+    const QuadWeights w = quad_weights_f(Xs, Ys, q.x, q.y);
+    rotate_offsets(w, e);
+    rotate_raw(w);
 #ifdef LT_RK_TIMING
     { const unsigned long long m3 = __ballot(spl && w.regime >= 3); if (lane == 0) ws.tim[7] += __popcll(m3) + ((m3 != 0) ? (1ull << 32) : 0ull); }
 #endif
     TICK(1);
-#ifndef LT_RK_NO_LC_SHARE
-    if (var != 1)
-#endif
-    {
 #pragma unroll
-      for (int l = 0; l < 4; l++) lc[l] = level_coef_d(tab, k0 + l, h, P.hc, VT, dv);
-    }
+    for (int l = 0; l < 4; l++) lc[l] = level_coef_d(wtab, iii + l, h, P.hc, VT, dv);
 #pragma unroll 1
     for (int s = 0; s < 3; s++) {
-      const int slot9 = var * 3 + s;
-      while (nev + 64 > LT_EV_CAP || nchk + 64 > LT_CHK_CAP) {
-        // wave-uniform: the next slot (up to 64 evaluation and 128 check intervals) might not fit -> one
-        // full round: the check intervals waiting and the last 64 - nchk evaluation intervals (a second
-        // round if the check intervals alone filled the first)
-        const int nc = (nchk < LT_CHK_CAP) ? nchk : LT_CHK_CAP;  // (entries beyond the capacity were not stored)
-        const int room = (nc < 64) ? 64 - nc : 0;
-        const int take = (nev < room) ? nev : room;
-        run_tasks(ws, nc, nev, lane, nev - take);
-        nev -= take;
-        nchk = 0;
-        TICK(4);
-      }
-      const double zeta = zt, Pzs = pz;
-      double X[4], Y[4];
-#pragma unroll
-      for (int l = 0; l < 4; l++) {
-        X[l] = level_at(lc[l], zeta, h, VT);
-        const double v1 = (double)raw[4 * l + 0], v2 = (double)raw[4 * l + 1], v3 = (double)raw[4 * l + 2];
-        Y[l] = v1 + (v2 - v1) * w.t + (v3 - v1) * w.u;
-      }
-      if (w.regime >= 3) {  // the stage position has left the start element (a few % of the lanes)
-#pragma unroll
-        for (int l = 0; l < 4; l++) {
-          const double v1 = (double)raw[4 * l + 0], v2 = (double)raw[4 * l + 1], v3 = (double)raw[4 * l + 2],
-                       v4 = (double)raw[4 * l + 3];
-          if (w.regime == 3) Y[l] = w.W1 * v1 + w.W2 * v2 + w.W3 * v3 + w.W4 * v4;
-          else Y[l] = (w.node_hit == 1) ? v1 : (w.node_hit == 2) ? v2 : (w.node_hit == 3) ? v3 : v4;
-        }
-      }
-      if (s < 2) request(s + 1);
-      const double DX1 = X[1] - X[0], DX2 = X[2] - X[1], DX3 = X[3] - X[2];
-      // Lane conditions are kept as 64-bit lane masks (LaneMask: the scalar result of a vector compare) and
-      // combined with scalar instructions; written as `bool`s the compiler turns every and-or of them into a
-      // select, which it builds in a vector register and compares back: ~18 vector instructions per slot.
-      const LaneMask OK = SPL & lm(DX1 > 0.0) & lm(DX2 > 0.0) & lm(DX3 > 0.0);
-      degenerate |= lm_lane(SPL & ~OK) ? (1u << slot9) : 0u;
-      // YPC1 (tension_module.f90:852-977) with the chord slopes kept for SIGS/HVAL
-      // (seven quotients over five divisors: the reciprocals are prepared once)
-      const Divisor d1 = prep_div(DX1), d2 = prep_div(DX2), d3 = prep_div(DX3);
-      const Divisor d12 = prep_div(DX1 + DX2), d23 = prep_div(DX2 + DX3);
-      double YP[4], SL[3];
-      SL[0] = div_prep(Y[1] - Y[0], d1);
-      SL[1] = div_prep(Y[2] - Y[1], d2);
-      SL[2] = div_prep(Y[3] - Y[2], d3);
-      YP[0] = ypc1_end_b(SL[0], SL[0] + div_prep(DX1 * (SL[0] - SL[1]), d12));
-      YP[1] = ypc1_mid_b(DX1, DX2, d12, SL[0], SL[1]);
-      YP[2] = ypc1_mid_b(DX2, DX3, d23, SL[1], SL[2]);
-      YP[3] = ypc1_end_b(SL[2], SL[2] + div_prep(DX3 * (SL[2] - SL[1]), d23));
-      // the evaluation interval :1044-1053 (extrapolates with the end intervals)
-      // (for strictly increasing knots "T > X(4) -> interval 3" is implied; other windows are redone by k_rk_slow)
-      const LaneMask I1 = lm(Pzs < X[1]), I2 = ~I1 & lm(Pzs < X[2]), I3 = ~I1 & ~I2;
-      const bool i1 = lm_lane(I1), i2 = lm_lane(I2);
-      const double x1 = i1 ? X[0] : i2 ? X[1] : X[2];
-      const double x2 = i1 ? X[1] : i2 ? X[2] : X[3];
-      const double y1 = i1 ? Y[0] : i2 ? Y[1] : Y[2];
-      const double p1 = i1 ? YP[0] : i2 ? YP[1] : YP[2];
-      const double p2 = i1 ? YP[1] : i2 ? YP[2] : YP[3];
-      const double Sv = i1 ? SL[0] : i2 ? SL[1] : SL[2];
-      Divisor dI;
-      dI.b = i1 ? d1.b : i2 ? d2.b : d3.b;
-      dI.y = i1 ? d1.y : i2 ? d2.y : d3.y;
-      TICK(2);
-      // SIGS (tension_module.f90:448-776), screened without divisions or loops.
-      // Only the evaluation interval's tension is used by HVAL; the other two
-      // matter only through SigErr, which only the convexity Newton iteration
-      // can raise, so they are queued just when they are Newton candidates.
-      const LaneMask C0 = sigs_candidate_mask(SL[0], YP[0], YP[1]), C1 = sigs_candidate_mask(SL[1], YP[1], YP[2]),
-                     C2 = sigs_candidate_mask(SL[2], YP[2], YP[3]);
-      // the two non-evaluation intervals: I=1 -> (2,3), I=2 -> (1,3), I=3 -> (1,2)
-      const LaneMask ma = OK & ((I1 & C1) | (~I1 & C0)), mb = OK & ((I3 & C1) | (~I3 & C2));
-      // the evaluation interval: done here when its tension is known to be ZERO (the cubic form);
-      // everything else (an iteration, or the rare known SBIG) goes to pass B
-      const LaneMask me = OK & ~sigs_eval_zero_mask(Sv, p1, p2);
-      const LaneMask mc = ma | mb;
-      const unsigned long long below = (1ull << lane) - 1ull;
-      if (mc) {  // ~1 % of the intervals are candidates: the operands of T = MAX(D1/D2, D2/D1)
-        if (lm_lane(ma)) {
-          double na, da;
-          if (i1) (void)sigs_candidate(SL[1], YP[1], YP[2], na, da);
-          else (void)sigs_candidate(SL[0], YP[0], YP[1], na, da);
-          const int idx = nchk + __popcll(ma & below);
-          if (idx < LT_CHK_CAP) {
-            ws.chk[idx][0] = na; ws.chk[idx][1] = da;
-            ws.chk_owner[idx] = (unsigned short)(lane | (slot9 << 6));
-          } else degenerate |= (1u << slot9);
-        }
-        nchk += __popcll(ma);
-        if (lm_lane(mb)) {
-          double nb, db;
-          if (lm_lane(I3)) (void)sigs_candidate(SL[1], YP[1], YP[2], nb, db);
-          else (void)sigs_candidate(SL[2], YP[2], YP[3], nb, db);
-          const int idx = nchk + __popcll(mb & below);
-          if (idx < LT_CHK_CAP) {
-            ws.chk[idx][0] = nb; ws.chk[idx][1] = db;
-            ws.chk_owner[idx] = (unsigned short)(lane | (slot9 << 6));
-          } else degenerate |= (1u << slot9);
-        }
-        nchk += __popcll(mb);
-      }
-      if (lm_lane(me)) {
-        const int idx = nev + __popcll(me & below);
-        double* e = ws.ev[idx];
-        e[0] = x1; e[1] = x2; e[2] = y1; e[3] = p1; e[4] = p2; e[5] = Sv; e[6] = Pzs;
-        ws.ev_owner[idx] = (unsigned short)(lane | (slot9 << 6));
-      }
-      nev += __popcll(me);
-#ifdef LT_RK_TIMING
-      if (lane == 0) ws.tim[6] += __popcll(me);
-#endif
-      // HVAL of the zero-tension case, stored by every lane (pass B overwrites the queued ones,
-      // the log layer below the others that do not fit a spline)
-      ws.res[slot9][lane] = hval_cubic_d(Pzs, x1, dI, y1, p1, p2, Sv);
-      (void)x2;
-      TICK(3);
+      make_room();
+      const double Pzs = pz;
+      geometry(zt);
+      double Y[4];
+      interp(w, Y);
+      if (s < 2) { request(Fb, e, L, s + 1); request_zp(s + 1); }
+      fit(Y, 6 + s, Pzs);
     }
-    if (loglayer) {
-      // log layer :1493-1522: level 1 of u,v; level 2 of w
-      const int k = (var == 2) ? 2 : 1;
-      const LevCoef qt = level_coef_d((var == 2) ? wtab : rtab, k, h, P.hc, VT, dv);
-      const QuadWeights wl = quad_weights(Xs, Ys, q.x, q.y);
-#pragma unroll
-      for (int s = 0; s < 3; s++) {
-        const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
-        const double zeta = wsd[(size_t)(WS_ZETA0 + s) * N];
-        double val = apply_interp(wl, fldv(F, nd.x, L, k, ps), fldv(F, nd.y, L, k, ps),
-                                  fldv(F, nd.z, L, k, ps), fldv(F, nd.w, L, k, ps));
-        double ztop = level_at(qt, zeta, h, VT);
-        ws.res[var * 3 + s][lane] = val * log10_call((Zs - wzb1) / P.z0) / log10_call((ztop - wzb1) / P.z0);
-      }
-    }
+    if (loglayer) log_layer(2, nd, (const SlabT*)P.W, L);
   }
   // what the step to the next stage and the next stage itself need first (coalesced per-particle
   // constants, the node ids of the u element) is requested here: the round below covers the latency
@@ -508,6 +571,7 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
     ST.minpd = wsd[(size_t)WS_MINPD * N]; ST.maxpd = wsd[(size_t)WS_MAXPD * N];
     SI.zb = wsd[(size_t)WS_ZETA0 * N]; SI.zc = wsd[(size_t)WS_ZETA1 * N]; SI.zf = wsd[(size_t)WS_ZETA2 * N];
     SI.nd0 = P.UE[eu - 1];
+    SI.nd1 = P.VE[ev_ - 1];
   }
   // ---------------- pass B: what is left of this stage
   run_tasks(ws, (nchk < LT_CHK_CAP) ? nchk : LT_CHK_CAP, nev, lane, 0);
@@ -900,6 +964,7 @@ void k_rk(const StepParams P) {
   StageTail ST;
   SI.zb = wsd[(size_t)WS_ZETA0 * N]; SI.zc = wsd[(size_t)WS_ZETA1 * N]; SI.zf = wsd[(size_t)WS_ZETA2 * N];
   SI.nd0 = P.UE[eu - 1];
+  SI.nd1 = P.VE[ev_ - 1];
   SI.ii = 1; SI.iii = 1;
   ST.X = ST.Y = ST.Zpar = ST.cosA = ST.sinA = ST.minpd = ST.maxpd = 0.0;
 #pragma unroll 1
