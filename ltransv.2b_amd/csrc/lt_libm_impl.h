@@ -11,11 +11,14 @@
 // ------------------------------------------------------------------------------------ exp
 // exp(x) = scale * (1 + tmp): the polynomial part and the bits of the scale 2^(k/128); xtail is
 // added to the reduced argument (pow's low part; 0 for exp)
-LT_LM void LT_LM_NAME(exp_parts)(double x, double xtail, double* tmp, unsigned long long* sbits) {
-  const double InvLn2N = 0x1.71547652b82fep+7, Shift = 0x1.8p+52;
+// (Shift, C2, C4 -- the three constants that enter as ADDENDS of a fused multiply-add -- as arguments: a caller
+// that evaluates exp in a loop keeps them in registers, lt_math.h: ExpAcc; as literals each costs two register
+// moves per evaluation, because the accumulating form of the instruction overwrites its addend)
+LT_LM void LT_LM_NAME(exp_parts_k)(double x, double xtail, double* tmp, unsigned long long* sbits, double Shift, double C2,
+                                   double C4) {
+  const double InvLn2N = 0x1.71547652b82fep+7;
   const double NegLn2hiN = -0x1.62e42fefa0000p-8, NegLn2loN = -0x1.cf79abc9e3b3ap-47;
-  const double C2 = 0x1.ffffffffffdbdp-2, C3 = 0x1.555555555543cp-3;
-  const double C4 = 0x1.55555cf172b91p-5, C5 = 0x1.1111167a4d017p-7;
+  const double C3 = 0x1.555555555543cp-3, C5 = 0x1.1111167a4d017p-7;
   const double z = LT_LM_FMA(x, InvLn2N, Shift);
   const unsigned long long ki = LT_LM_ASU(z);
   const double kd = z - Shift;
@@ -31,6 +34,17 @@ LT_LM void LT_LM_NAME(exp_parts)(double x, double xtail, double* tmp, unsigned l
   double t = LT_LM_FMA(p23, r2, t3);
   const double r4 = r2 * r2;
   *tmp = LT_LM_FMA(r4, p45, t);
+}
+LT_LM void LT_LM_NAME(exp_parts)(double x, double xtail, double* tmp, unsigned long long* sbits) {
+  LT_LM_NAME(exp_parts_k)(x, xtail, tmp, sbits, 0x1.8p+52, 0x1.ffffffffffdbdp-2, 0x1.55555cf172b91p-5);
+}
+// exp_core with the three addend constants from the caller's registers (|x| < 512)
+LT_LM double LT_LM_NAME(exp_core_k)(double x, double Shift, double C2, double C4) {
+  double tmp;
+  unsigned long long sbits;
+  LT_LM_NAME(exp_parts_k)(x, 0.0, &tmp, &sbits, Shift, C2, C4);
+  const double scale = LT_LM_ASD(sbits);
+  return LT_LM_FMA(scale, tmp, scale);
 }
 // |x| < 512 (HVAL/HPVAL: |SIG*B| <= 170; SNHCSH; the secant loop, SIG <= 85; x2lon / y2lat)
 LT_LM double LT_LM_NAME(exp_core)(double x) {

@@ -859,12 +859,22 @@ LT_DEV void sigs_newton_k(const double (&T)[K], const bool (&need)[K], double (&
   }
 }
 
+// the three addend constants of exp (lt_libm_impl.h: exp_parts_k) held in vector registers over a loop: opaque to
+// the compiler, which would otherwise re-materialise each with two moves per evaluation
+struct ExpAcc { double Shift, C2, C4; };
+LT_DEV ExpAcc exp_acc() {
+  ExpAcc a;
+  a.Shift = 0x1.8p+52; a.C2 = 0x1.ffffffffffdbdp-2; a.C4 = 0x1.55555cf172b91p-5;
+  asm volatile("" : "+v"(a.Shift), "+v"(a.C2), "+v"(a.C4));
+  return a;
+}
+
 // sigs_newton_k<1> for a whole wave, one task per lane, with the lane conditions (live, failed, the stopping
 // tests) as lane masks: loop-carried booleans are otherwise kept as 0 / 1 in vector registers and rebuilt with a
 // select and a compare in every trip.  Same operations on the same operands, the same cycle detection.  NEED: the
 // lanes with a task.  The operands of the two quotients are selected only in the trips in which a live task is at
 // SIG <= .5 (a minority): otherwise they are the exponential form's.
-LT_DEV void sigs_newton_w(double T, LaneMask NEED, double& sg, LaneMask& FAILED) {
+LT_DEV void sigs_newton_w(double T, LaneMask NEED, double& sg, LaneMask& FAILED, const ExpAcc& ea) {
   const double SBIG = LT_SBIG, RTOL = LT_SIGS_RTOL, FTOL = 0.0;
   const double P1 = -3.51754964808151394800e5, P2 = -1.15614435765005216044e4,
                P3 = -1.63725857525983828727e2, P4 = -7.89474443963537015605e-1;
@@ -883,7 +893,7 @@ LT_DEV void sigs_newton_w(double T, LaneMask NEED, double& sg, LaneMask& FAILED)
     const LaneMask SMALL = lm(s <= .5);
     const bool any_small = (SMALL & LIVE) != 0ull;
     // the exponential form
-    double EMS = exp_core((s < 512.0) ? -s : 0.0);
+    double EMS = exp_core_k((s < 512.0) ? -s : 0.0, ea.Shift, ea.C2, ea.C4);
     if (s >= 512.0) EMS = lt_exp(-s);  // T > 26000: rare
     double den = 1.0 - EMS * (EMS + s + s);        // SSM
     double n1 = (1.0 - EMS) * (1.0 - EMS);         // TM
@@ -1015,7 +1025,7 @@ __device__ __noinline__ double sigs_secant(double S, double S1, double S2) {
 // HVAL on one interval with the chord slope S = (Y2-Y1)/DX supplied by the
 // caller (same expression as tension_module.f90:1074).
 LT_DEV double hval_interval_s(double T, double X1, double X2, double Y1, double YP1, double YP2,
-                              double S, double SIGMA) {
+                              double S, double SIGMA, const ExpAcc* ea = nullptr) {
   double DX = X2 - X1;
   double U = T - X1;
   double B2 = U / DX;
@@ -1038,7 +1048,8 @@ LT_DEV double hval_interval_s(double T, double X1, double X2, double Y1, double 
     double SB1 = SIG * B1;
     double SB2 = SIG - SB1;
     if (-SB1 > LT_SBIG || -SB2 > LT_SBIG) return Y1 + S * U;
-    double E1 = exp_core(-SB1), E2 = exp_core(-SB2);
+    const double E1 = ea ? exp_core_k(-SB1, ea->Shift, ea->C2, ea->C4) : exp_core(-SB1);
+    const double E2 = ea ? exp_core_k(-SB2, ea->Shift, ea->C2, ea->C4) : exp_core(-SB2);
     double EMS = E1 * E2;
     double TM = 1.0 - EMS;
     double TS = TM * TM;

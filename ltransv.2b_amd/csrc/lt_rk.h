@@ -137,7 +137,7 @@ struct WaveScratch {
 // batch whatever the mix (a separate loop for the few check intervals cost as much as the
 // one for the evaluation intervals).
 template <int K>
-LT_DEV void run_task_batch(WaveScratch& ws, int nev, int total, int t0) {
+LT_DEV void run_task_batch(WaveScratch& ws, int nev, int total, int t0, const ExpAcc& ea) {
   bool is_ev[K], valid[K], need[K], failed[K];
   int tq[K], kind[K];
   unsigned short o[K];
@@ -174,13 +174,13 @@ LT_DEV void run_task_batch(WaveScratch& ws, int nev, int total, int t0) {
     double sgn;
     LaneMask FAILED;
     const LaneMask NEED = lm(need[0]);
-    sigs_newton_w(T[0], NEED, sgn, FAILED);
+    sigs_newton_w(T[0], NEED, sgn, FAILED, ea);
     TICKB(21);
     if (need[0]) sg[0] = sgn;
     else if (kind[0] == SIGK_SECANT) sg[0] = sigs_secant(ws.ev[tq[0]][5], ws.ev[tq[0]][3], ws.ev[tq[0]][4]);  // rare
     if (is_ev[0]) {
       const double* e = ws.ev[tq[0]];
-      ws.res[o[0] >> 6][o[0] & 63] = hval_interval_s(e[6], e[0], e[1], e[2], e[3], e[4], e[5], sg[0]);
+      ws.res[o[0] >> 6][o[0] & 63] = hval_interval_s(e[6], e[0], e[1], e[2], e[3], e[4], e[5], sg[0], &ea);
     }
     if (lm_lane(NEED & FAILED)) atomicOr(&ws.errmask[o[0] & 63], 1u << (o[0] >> 6));
   } else {
@@ -207,15 +207,16 @@ LT_DEV void run_tasks(WaveScratch& ws, int nchk, int nev, int lane, int first) {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const int total = nev + nchk;
   int t0 = first;
+  const ExpAcc ea = exp_acc();   // (exp's addend constants in registers for the Newton trips and HVAL of every round)
 #ifdef LT_RK_PAIRS
   // two tasks per lane and trip (measured: 3 % slower than one -- the rounds are bound by issue slots once
   // the two forms of a Newton step interleave, and the second task costs registers)
 #pragma unroll 1
-  for (; total - t0 > 64; t0 += 128) run_task_batch<2>(ws, nev, total, t0 + lane);
+  for (; total - t0 > 64; t0 += 128) run_task_batch<2>(ws, nev, total, t0 + lane, ea);
 #endif
 #pragma unroll 1
   for (; t0 < total; t0 += 64)
-    if (t0 + lane < total) run_task_batch<1>(ws, nev, total, t0 + lane);
+    if (t0 + lane < total) run_task_batch<1>(ws, nev, total, t0 + lane, ea);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256) void k_vt_sigs(const StepParams P) {
     const bool need = kind == SIGK_NEWTON;
     const LaneMask NEED = lm(need);
     LaneMask FAILED;
-    sigs_newton_w(T, NEED, sgn, FAILED);      // the whole wave, lanes without a Newton task idle in it
+    sigs_newton_w(T, NEED, sgn, FAILED, exp_acc());      // the whole wave, lanes without a Newton task idle in it
     if (need) sg = sgn;
     else if (kind == SIGK_SECANT) sg = sigs_secant(S, S1, S2);
     if (have) {
