@@ -47,7 +47,7 @@ sys.path.insert(0, ROOT)
 A_ADV_F32 = 96 + 256 + 48 + 576          # = 976 B
 A_ADV_F64 = 96 + 256 + 96 + 1152         # = 1600 B
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_ADV, PROFILE_TURB = "r03_adv", "r03_turb"   # profiles/<tag>/pmc.json of the default workloads
+PROFILE_ADV, PROFILE_TURB = "r04_adv", "r04_turb"   # profiles/<tag>/pmc.json of the default workloads
 
 WORKLOADS = {
     # name: (grid, total particles, turbulence, reflect/behaviour-6/settlement)
