@@ -77,6 +77,13 @@ struct lt_engine {
   // particles
   DevBuf ws_d, ws_i, orig, ele_ok, block_active, count_slots, out_cols, out_hits, get_stage;
   size_t get_stage_used = 0;
+  // pinned host staging of the downloads (get_fields_*): the device-to-host copies land here at the link's rate and
+  // a few host threads move each array on to the caller's (pageable) memory while the next one arrives
+  void* get_pin = nullptr;
+  size_t get_pin_bytes = 0;
+  struct GetItem { const void* src; void* dst; size_t bytes; };
+  std::vector<GetItem> get_items;
+  std::vector<hipEvent_t> get_ev;
   // internal particle order: slot i of every device array holds the reference's
   // particle perm[i] (0-based); sorted by rho element for memory locality
   std::vector<int> perm;
@@ -474,6 +481,15 @@ int put_field(lt_engine* e, DevBuf& buf, const T* src, int cols) {
 int get_fields_begin(lt_engine* e, size_t total_bytes) {
   TRY(dev_alloc(e, e->get_stage, total_bytes + 256));
   e->get_stage_used = 0;
+  e->get_items.clear();
+  if (e->get_pin_bytes < total_bytes + 256 && !getenv("LT_GET_NOPIN")) {
+    if (e->get_pin) (void)hipHostFree(e->get_pin);
+    e->get_pin = nullptr; e->get_pin_bytes = 0;
+    // (kept for the next download; without it -- no pinned memory to be had -- the copies go to the caller's
+    // memory directly, at the rate of a pageable destination)
+    if (hipHostMalloc(&e->get_pin, total_bytes + 256, hipHostMallocDefault) == hipSuccess) e->get_pin_bytes = total_bytes + 256;
+    else { e->get_pin = nullptr; (void)hipGetLastError(); }
+  }
   return LT_OK;
 }
 template <typename T>
@@ -483,15 +499,76 @@ int get_field(lt_engine* e, const DevBuf& buf, T* dst, int cols) {
   const size_t bytes = n * cols * sizeof(T);
   if (!bytes) return LT_OK;
   if (e->get_stage_used + bytes > e->get_stage.bytes) return fail(e, LT_ERR_STATE, "get_field: staging buffer too small");
-  T* stage = (T*)((char*)e->get_stage.p + e->get_stage_used);
+  const size_t off = e->get_stage_used;
+  T* stage = (T*)((char*)e->get_stage.p + off);
   e->get_stage_used += (bytes + 255) & ~(size_t)255;
   hipLaunchKernelGGL((ltd::k_unpermute<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, (const T*)buf.p, stage,
                      (const int*)e->orig.p, (int)n, cols);
-  HIPCHK(e, hipMemcpyAsync(dst, stage, bytes, hipMemcpyDeviceToHost, e->stream));
+  if (!e->get_pin) {
+    HIPCHK(e, hipMemcpyAsync(dst, stage, bytes, hipMemcpyDeviceToHost, e->stream));
+    return LT_OK;
+  }
+  char* pin = (char*)e->get_pin + off;
+  HIPCHK(e, hipMemcpyAsync(pin, stage, bytes, hipMemcpyDeviceToHost, e->stream));
+  const size_t k = e->get_items.size();
+  if (e->get_ev.size() <= k) {
+    hipEvent_t ev;
+    HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    e->get_ev.push_back(ev);
+  }
+  HIPCHK(e, hipEventRecord(e->get_ev[k], e->stream));
+  e->get_items.push_back({pin, dst, bytes});
   return LT_OK;
 }
 int get_fields_end(lt_engine* e) {
   HIPCHK(e, hipGetLastError());
+  const size_t ni = e->get_items.size();
+  const bool tim = getenv("LT_GET_TIMING") != nullptr;
+  auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+  const double t_begin = now();
+  double t_wait = 0.0, t_copy = 0.0;
+  if (ni) {
+    // worker t copies the t-th slice of every array, as soon as the array has arrived
+    unsigned hw = std::thread::hardware_concurrency();
+    int nt = (int)std::max(1u, std::min(8u, hw ? hw : 1u));
+    if (getenv("LT_GET_THREADS")) nt = std::max(1, atoi(getenv("LT_GET_THREADS")));
+    std::atomic<size_t> ready{0};
+    std::atomic<bool> abort_{false};
+    auto work = [&](int t) {
+      for (size_t k = 0; k < ni; k++) {
+        while (ready.load(std::memory_order_acquire) <= k) {
+          if (abort_.load(std::memory_order_relaxed)) return;
+          std::this_thread::yield();
+        }
+        const lt_engine::GetItem& it = e->get_items[k];
+        const size_t per = ((it.bytes + nt - 1) / nt + 63) & ~(size_t)63;
+        const size_t a = std::min(it.bytes, per * (size_t)t), b = std::min(it.bytes, a + per);
+        if (b > a) memcpy((char*)it.dst + a, (const char*)it.src + a, b - a);
+      }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work, t);
+    hipError_t err = hipSuccess;
+    for (size_t k = 0; k < ni && err == hipSuccess; k++) {
+      const double t0 = now();
+      err = hipEventSynchronize(e->get_ev[k]);
+      const double t1 = now();
+      if (err == hipSuccess) {
+        ready.store(k + 1, std::memory_order_release);
+        const lt_engine::GetItem& it = e->get_items[k];   // (this thread takes slice 0 of the array that has just arrived)
+        const size_t per = ((it.bytes + nt - 1) / nt + 63) & ~(size_t)63;
+        memcpy(it.dst, it.src, std::min(it.bytes, per));
+      }
+      t_wait += t1 - t0; t_copy += now() - t1;
+    }
+    if (err != hipSuccess) abort_.store(true);
+    const double t_j = now();
+    for (auto& x : th) x.join();
+    if (tim) fprintf(stderr, "get_fields_end: %zu arrays, %d threads: waiting for arrivals %.2f ms, own copies %.2f ms, join %.2f ms, total %.2f ms\n",
+                     ni, nt, t_wait, t_copy, now() - t_j, now() - t_begin);
+    e->get_items.clear();
+    HIPCHK(e, err);
+  }
   HIPCHK(e, hipStreamSynchronize(e->stream));
   return LT_OK;
 }
@@ -1026,6 +1103,8 @@ int lt_destroy(lt_engine* e) {
   for (hipEvent_t ev : e->rng_job_ev) if (ev) (void)hipEventDestroy(ev);
   if (e->rng_jobs) (void)hipHostFree(e->rng_jobs);
   if (e->rng_stream) (void)hipStreamDestroy(e->rng_stream);
+  if (e->get_pin) (void)hipHostFree(e->get_pin);
+  for (auto ev : e->get_ev) (void)hipEventDestroy(ev);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return LT_OK;
@@ -1610,6 +1689,7 @@ int lt_get_output(lt_engine* e, lt_output* out, int32_t reset_hits) {
     TRY(get_fields_begin(e, 2 * ((n * 8 + 255) & ~(size_t)255)));
     if (out->salt) TRY(get_field<double>(e, e->P_Salt, out->salt, 1));
     if (out->temp) TRY(get_field<double>(e, e->P_Temp, out->temp, 1));
+    return get_fields_end(e);
   }
   HIPCHK(e, hipStreamSynchronize(e->stream));
   return LT_OK;
@@ -2475,7 +2555,8 @@ int lt_diag(unsigned long long* out) {
   unsigned long long z[16] = {0}, r[16];
   hipMemcpyToSymbol(HIP_SYMBOL(ltd::g_tim), z, 128);
   ltd::rk_timing_fetch(r, true);
-  for (int i = 0; i < 16; i++) out[i] += r[i];
+  if (!getenv("LT_DIAG_ENGINE_UNIT_ONLY"))   // (tools/dev/vt_walk_stats.py: slots 0..7 are k_vt_walk's there)
+    for (int i = 0; i < 16; i++) out[i] += r[i];
   return 0;
 }
 #endif
@@ -2573,10 +2654,17 @@ RcclApi* rccl() {
   static bool tried = false;
   if (!tried) {
     tried = true;
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      api.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    // (the copy the process has already loaded, if any -- a host that also imports torch has torch's; the symbols
+    // stay local to this handle)
+    for (const char* name : {"librccl.so.1", "librccl.so"}) {
+      api.h = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
       if (api.h) break;
     }
+    if (!api.h)
+      for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        api.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (api.h) break;
+      }
     if (api.h) {
       api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.h, "ncclGetUniqueId");
       api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.h, "ncclCommInitRank");

@@ -327,8 +327,14 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
     LINE(s, wz1[s], WZ(s, 2), kh1[s], KH(s, 2));
     RAW(s, 3);  // ws >= 6
   }
+#ifdef LT_VT_ADV_STATS
+  int adv_exec = 0, adv_lanes = 0;   // development aid: executions of the segment advance by this wave, lanes in them
+#endif
   auto NEWY_AT = [&](int s, double xj) -> double {  // newy{b,c,f}(j) at its abscissa xj = newx(j), j = 5..p2+3
     while (!(wzhi[s] > xj) && jlo[s] < ws - 1) {
+#ifdef LT_VT_ADV_STATS
+      adv_exec += 1; adv_lanes += __popcll(__ballot(1));
+#endif
       jlo[s] += 1;
       const double kb = GI((double)rawn[s][0], (double)rawn[s][1], (double)rawn[s][2], (double)rawn[s][3]);
       LINE(s, wzhi[s], WZ(s, jlo[s] + 1), khhi[s], kb);
@@ -482,6 +488,9 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
 #ifdef LT_RK_TIMING
   if (lane == 0)
     for (int q = 0; q < 6; q++) atomicAdd(&g_tim[8 + q], vt_acc[q]);
+#endif
+#ifdef LT_VT_ADV_STATS
+  if (lane == 0) { atomicAdd(&g_tim[6], (unsigned long long)adv_exec); atomicAdd(&g_tim[7], (unsigned long long)adv_lanes); atomicAdd(&g_tim[5], 1ull); }
 #endif
   if (lane == 0 && (size_t)wave * 64 < (size_t)P.numpar) {   // (the last workgroup may hold waves beyond the particles)
     Q.count[wave] = (ntask < Q.cap) ? ntask : Q.cap;
@@ -744,13 +753,25 @@ __global__ __launch_bounds__(256) void k_vt_walk(const StepParams P) {
   ci.I = 0; ci.X1 = ci.X2 = ci.Y1 = ci.Y2 = ci.P1 = ci.P2 = ci.SG = ci.SGhi = 0.0;
   ci.S = ci.D1 = ci.D2 = ci.SM = ci.CM = ci.CMM = 0.0; ci.dx.b = 1.0; ci.dx.y = 1.0;
   const bool cached = (sigerr == 0) && !ypc_fail;
+#ifdef LT_RK_TIMING
+  // development aid (tools/dev/vt_walk_stats.py): what the waves of this kernel spend their sub-steps on
+  unsigned long long st_t0 = __builtin_readcyclecounter();
+  int st_iter = 0, st_lane_iter = 0, st_lane_T = 0, st_anyT = 0, st_anyR = 0, st_anyE = 0;
+#endif
 #pragma unroll 1
   for (int i = i0; i <= loop; i++) {
     const double DEV = dev[(size_t)(i - 1) * 64];
     double Kprimec = 0.0;
+#ifdef LT_RK_TIMING
+    bool st_T = false, st_R = false, st_E = false;
+#define ST_NOTE() do { const double a_ = fabs(ci.SG); if (a_ >= 1.e-9) { st_T = true; if (a_ <= .5) st_R = true; else st_E = true; } } while (0)
+#else
+#define ST_NOTE() do { } while (0)
+#endif
     if (!(ParZc < P_depth || ParZc > P_zetac)) {
       if (cached) {
         vt_seek(ci, ParZc, p2, tab);
+        ST_NOTE();
         Kprimec = hpval_prepared(ParZc, ci);
       } else if (sigerr == 0) {
         Kprimec = hval_table<true>(ParZc, p2, tab, ypc_fail, il);
@@ -764,6 +785,7 @@ __global__ __launch_bounds__(256) void k_vt_walk(const StepParams P) {
     } else {
       if (cached) {
         vt_seek(ci, Z3rdc, p2, tab);
+        ST_NOTE();
         KH3rdc = hval_prepared(Z3rdc, ci);
       } else if (sigerr == 0) {
         KH3rdc = hval_table<false>(Z3rdc, p2, tab, ypc_fail, il);
@@ -772,7 +794,32 @@ __global__ __launch_bounds__(256) void k_vt_walk(const StepParams P) {
     }
     // (2/r * KH3rd * deltat)**0.5 with r = 1
     ParZc = ParZc + KprimeZc + DEV * lt_pow_half(2.0 / 1.0 * KH3rdc * deltat);
+#ifdef LT_RK_TIMING
+    st_iter += 1; st_lane_iter += 1; st_lane_T += st_T ? 1 : 0;
+    st_anyT += __ballot(st_T) ? 1 : 0; st_anyR += __ballot(st_R) ? 1 : 0; st_anyE += __ballot(st_E) ? 1 : 0;
+#endif
   }
+#ifdef LT_RK_TIMING
+  {
+    // per wave: iterations of the longest lane, lane-iterations, lane-iterations on a tension interval, iterations
+    // in which any lane was on one (any / rational form / exponential form), the most such sub-steps of one lane
+    int mx_iter = st_iter, mx_T = st_lane_T, s_li = st_lane_iter, s_lt = st_lane_T, aT = st_anyT, aR = st_anyR, aE = st_anyE;
+    for (int o = 32; o; o >>= 1) {
+      mx_iter = max(mx_iter, __shfl_xor(mx_iter, o, 64)); mx_T = max(mx_T, __shfl_xor(mx_T, o, 64));
+      s_li += __shfl_xor(s_li, o, 64); s_lt += __shfl_xor(s_lt, o, 64);
+      aT = max(aT, __shfl_xor(aT, o, 64)); aR = max(aR, __shfl_xor(aR, o, 64)); aE = max(aE, __shfl_xor(aE, o, 64));
+    }
+    if ((threadIdx.x & 63) == (__ffsll((long long)__ballot(1)) - 1)) {
+      atomicAdd(&g_tim[0], 1ull); atomicAdd(&g_tim[1], (unsigned long long)mx_iter);
+      atomicAdd(&g_tim[2], (unsigned long long)s_li); atomicAdd(&g_tim[3], (unsigned long long)s_lt);
+#ifndef LT_VT_ADV_STATS
+      atomicAdd(&g_tim[4], (unsigned long long)aT); atomicAdd(&g_tim[5], (unsigned long long)aR);
+      atomicAdd(&g_tim[6], (unsigned long long)aE); atomicAdd(&g_tim[7], (unsigned long long)mx_T);
+#endif
+      atomicAdd(&g_tim[14], __builtin_readcyclecounter() - st_t0);
+    }
+  }
+#endif
   wsd[(size_t)WS_TURBV * N] = P_zc - ParZc;  // :342
   if (sigerr != 0) atomicAdd(&P.counters[CNT_SIGERR], 1ull);
 }

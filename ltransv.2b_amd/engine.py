@@ -425,13 +425,21 @@ class Engine:
         return {"active": s.active, "errors": s.errors, "rng_draws": s.rng_draws}
 
     # -- downloads -----------------------------------------------------------
-    def get_particles(self, fields=None):
+    def get_particles(self, fields=None, out=None):
+        """-> {name: array}.  `out`: the dictionary an earlier call returned, to download into the same arrays (a host
+        that prints every few steps keeps its arrays; 240 MB of fresh pages per call cost as much as the download)"""
         s = LtParticles()
-        out = {}
+        reuse, out = out, {}
         for name, _, dt, cols in PARTICLE_FIELDS:
             if fields is not None and name not in fields:
                 continue
-            a = np.zeros(self.numpar * cols, dtype=np.dtype(dt))
+            a = None
+            if reuse is not None and name in reuse:
+                a = reuse[name].ravel(order="F")
+                if a.base is None or a.size != self.numpar * cols or a.dtype != np.dtype(dt) or not a.flags.writeable:
+                    a = None
+            if a is None:
+                a = np.zeros(self.numpar * cols, dtype=np.dtype(dt))
             out[name] = a
             setattr(s, name, _dp(a) if dt == "f8" else _ip(a))
         self._check(self._fn["get_particles"](self._h, C.byref(s)), "get_particles")

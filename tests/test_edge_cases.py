@@ -120,3 +120,23 @@ def test_hip_minimum_levels():
     finally:
         del cases.CASES["_tiny_us5"]
     assert cases.rel_error(hip["par"], orc["par"]) <= 1e-9 and np.array_equal(hip["err_code"], orc["err_code"])
+
+
+def test_get_particles_into_the_arrays_of_an_earlier_call():
+    """get_particles(out=...) downloads into the arrays an earlier call returned (the host keeps its arrays between
+    print steps) and gives the values a fresh download gives"""
+    case = cases.build_case("tiny_adv")
+    e = cases.make_engine(case, ltrans_amd.Engine, _oracle_kw())
+    run = LtransRun(e, case["cfg"].dt, case["cfg"].idt, case["record"])
+    run.init_hydro()
+    run.run(1, max_internal=2)
+    first = e.get_particles()
+    snapshot = {k: v.copy() for k, v in first.items()}
+    run.run_external_timestep(2, max_internal=2)
+    again = e.get_particles(out=first)
+    fresh = e.get_particles()
+    for k in fresh:
+        assert np.shares_memory(again[k], first[k]), k
+        assert again[k].shape == fresh[k].shape and np.array_equal(again[k], fresh[k]), k
+    assert not np.array_equal(again["par"], snapshot["par"])
+    e.close()
