@@ -922,8 +922,8 @@ void launch_vturb_t(lt_engine* e, const StepParams& P, unsigned blocks) {
   hipLaunchKernelGGL(k_vt_norm, dim3(blocks), dim3(256), 0, e->stream, P);
   // the walks on zero-tension intervals; then, for the ones that met a tension factor, the rest of the walk
   // (as many workgroups as could be needed: the ones beyond the list's end leave at once)
-  hipLaunchKernelGGL(k_vt_walk_fast, dim3(blocks), dim3(256), 0, e->stream, P);
-  hipLaunchKernelGGL(k_vt_walk, dim3(blocks), dim3(256), 0, e->stream, P);
+  hipLaunchKernelGGL(k_vt_walk_fast, dim3(blocks * (256 / LT_VT_WALKFAST_BLOCK)), dim3(LT_VT_WALKFAST_BLOCK), 0, e->stream, P);
+  hipLaunchKernelGGL(k_vt_walk, dim3(blocks * (256 / LT_VT_WALK_BLOCK)), dim3(LT_VT_WALK_BLOCK), 0, e->stream, P);
 }
 void launch_vturb(lt_engine* e, const StepParams& P, unsigned blocks) {
   if (e->cfg.slab_storage == LT_SLAB_F32) launch_vturb_t<float>(e, P, blocks);

@@ -168,7 +168,7 @@ LT_DEV double hpval_prepared(double T, const VtInterval& c) {
 }
 // (a move to the neighbouring interval loads ONE 32-byte record -- the new knot; the knot shared with
 // the old interval is kept)
-LT_DEV void vt_seek(VtInterval& c, double T, int n, const double4* tab) {
+LT_DEV bool vt_seek_move(VtInterval& c, double T, int n, const double4* tab) {
   bool moved = false;
   if (c.I == 0) {  // first use: the start of vt_seek_lite (the table is strictly increasing wherever this is called)
     const double xa = tab[0].x, xb = tab[(size_t)(n - 1) * VT_TS].x;
@@ -196,7 +196,21 @@ LT_DEV void vt_seek(VtInterval& c, double T, int n, const double4* tab) {
     c.X2 = r.x; c.Y2 = r.y; c.P2 = r.z; c.SGhi = r.w;
     moved = true;
   }
-  if (moved) vt_prepare(c);
+  return moved;
+}
+LT_DEV void vt_seek(VtInterval& c, double T, int n, const double4* tab) {
+  if (vt_seek_move(c, T, n, tab)) vt_prepare(c);
+}
+// The walk of a particle whose SIGS failed (SigErr: linint instead of HVAL / HPVAL, ver_turb_module.f90:296-331) on
+// the same cached interval.  linint's bisection (interpolation_module: the j with xa(j) <= x < xa(j+1), the end
+// intervals beyond the ends) and the stepping find the same interval of a strictly increasing table -- and the table is
+// one whenever YPC1 went through, which it did if SIGS ran.  (A bisection from scratch is seven dependent loads, twice
+// per sub-step: the 0.03 % of the particles that take this path were the longest waves of k_vt_walk, 0.2 ms of the step.)
+LT_DEV void vt_seek_plain(VtInterval& c, double T, int n, const double4* tab) { (void)vt_seek_move(c, T, n, tab); }
+LT_DEV void linint_interval(const VtInterval& c, double x, double& y, double& m) {
+  m = (c.Y1 - c.Y2) / (c.X1 - c.X2);
+  const double b = c.Y1 - m * c.X1;
+  y = m * x + b;
 }
 
 // The spline intervals of the VTurb table whose tension factor needs an iteration (SIGS,
@@ -654,7 +668,13 @@ LT_DEV void vt_seek_lite(VtLite& c, double T, int n, const double4* tab) {
     c.D2 = c.P2 - c.S;
   }
 }
-__global__ __launch_bounds__(256) void k_vt_walk_fast(const StepParams P) {
+#ifndef LT_VT_WALKFAST_BLOCK
+#define LT_VT_WALKFAST_BLOCK 256
+#endif
+#ifndef LT_VT_WALK_BLOCK
+#define LT_VT_WALK_BLOCK 256
+#endif
+__global__ __launch_bounds__(LT_VT_WALKFAST_BLOCK) void k_vt_walk_fast(const StepParams P) {
   libm_tables_load<LM_EXP | LM_POW>();  // (pow takes the exp table too)
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= P.numpar) return;
@@ -726,7 +746,7 @@ __global__ __launch_bounds__(256) void k_vt_walk_fast(const StepParams P) {
 }
 
 // :282-335 random displacement model, idt/2 sub-steps of 2 s: the listed walks, every form of HVAL / HPVAL
-__global__ __launch_bounds__(256) void k_vt_walk(const StepParams P) {
+__global__ __launch_bounds__(LT_VT_WALK_BLOCK) void k_vt_walk(const StepParams P) {
   const int nlisted = *P.vt_wl_count;
   if ((int)(blockIdx.x * blockDim.x) >= nlisted) return;   // (the whole workgroup: launched for the worst case)
   libm_tables_load<LM_EXP | LM_POW>();
@@ -775,6 +795,10 @@ __global__ __launch_bounds__(256) void k_vt_walk(const StepParams P) {
         Kprimec = hpval_prepared(ParZc, ci);
       } else if (sigerr == 0) {
         Kprimec = hval_table<true>(ParZc, p2, tab, ypc_fail, il);
+      } else if (!ypc_fail) {
+        vt_seek_plain(ci, ParZc, p2, tab);
+        double yy;
+        linint_interval(ci, ParZc, yy, Kprimec);
       } else { double yy; linint_n(&tab[0].x, &tab[0].y, p2, 4 * VT_TS, ParZc, yy, Kprimec); }
     }
     const double KprimeZc = -1.0 * Kprimec * deltat;
@@ -789,6 +813,10 @@ __global__ __launch_bounds__(256) void k_vt_walk(const StepParams P) {
         KH3rdc = hval_prepared(Z3rdc, ci);
       } else if (sigerr == 0) {
         KH3rdc = hval_table<false>(Z3rdc, p2, tab, ypc_fail, il);
+      } else if (!ypc_fail) {
+        vt_seek_plain(ci, Z3rdc, p2, tab);
+        double mm;
+        linint_interval(ci, Z3rdc, KH3rdc, mm);
       } else { double mm; linint_n(&tab[0].x, &tab[0].y, p2, 4 * VT_TS, Z3rdc, KH3rdc, mm); }
       if (KH3rdc < background) KH3rdc = background;
     }
@@ -817,6 +845,7 @@ __global__ __launch_bounds__(256) void k_vt_walk(const StepParams P) {
       atomicAdd(&g_tim[6], (unsigned long long)aE); atomicAdd(&g_tim[7], (unsigned long long)mx_T);
 #endif
       atomicAdd(&g_tim[14], __builtin_readcyclecounter() - st_t0);
+      atomicMax(&g_tim[15], __builtin_readcyclecounter() - st_t0);
     }
   }
 #endif

@@ -36,7 +36,7 @@ print("lane-iterations per wave                     %.0f  (%.0f %% of 64 x itera
 print("lane-iterations on a tension interval        %.0f  (%.1f %% of the lane-iterations)" % (v[3] / w, 100 * v[3] / v[2]))
 print("iterations with any lane on one              %.1f  rational form %.1f  exponential form %.1f" % (v[4] / w, v[5] / w, v[6] / w))
 print("most tension sub-steps of one lane of a wave %.1f" % (v[7] / w))
-print("cycles per wave %.0f, per iteration %.0f" % (v[14] / w, v[14] / v[1]))
+print("cycles per wave %.0f, per iteration %.0f; the longest wave of the %d steps %.0f" % (v[14] / w, v[14] / v[1], K, v[15] * K))
 if os.environ.get("LT_VT_ADV_STATS"):   # library built with -DLT_VT_ADV_STATS as well: slots 5..7 are k_vt_table's
     print("k_vt_table: waves %.0f, executions of the segment advance per wave %.1f (of %d knot x slot), lanes in one %.1f" % (
         v[5], v[6] / v[5], 3 * 4 * (us + 1), v[7] / v[6]))
