@@ -25,7 +25,8 @@
 #include <vector>
 
 #include "../../include/ltrans_hip.h"
-#include "lt_rk_launch.h"  // k_rk lives in lt_rk_kernel.hip (its own compiler options)
+#include "lt_rk_launch.h"  // k_rk, k_vt_table, k_vt_norm and k_vt_walk_fast live in lt_rk_kernel.hip (its own compiler options)
+#define LT_VT_DEFINE_B
 #include "lt_kernels.h"
 #include "lt_bounds_host.h"
 #include "lt_init_host.h"
@@ -904,30 +905,16 @@ void wait_rng(lt_engine* e) {
   if (e->rng_pending) (void)hipStreamWaitEvent(e->stream, e->rng_done, 0);
   e->rng_pending = false;
 }
-template <typename SlabT>
-void launch_vturb_t(lt_engine* e, const StepParams& P, unsigned blocks) {
-#define LT_LAUNCH_VT_TABLE(VT)                                                                         \
-  do {                                                                                                \
-    if (P.fastdiv) hipLaunchKernelGGL((k_vt_table<SlabT, VT, true>), dim3(blocks), dim3(256), 0, e->stream, P); \
-    else hipLaunchKernelGGL((k_vt_table<SlabT, VT, false>), dim3(blocks), dim3(256), 0, e->stream, P);          \
-  } while (0)
-  switch (e->cfg.Vtransform) {
-    case 1: LT_LAUNCH_VT_TABLE(1); break;
-    case 2: LT_LAUNCH_VT_TABLE(2); break;
-    default: LT_LAUNCH_VT_TABLE(3); break;
-  }
-#undef LT_LAUNCH_VT_TABLE
+void launch_vturb(lt_engine* e, const StepParams& P, unsigned blocks) {
+  // (k_vt_table, k_vt_norm and k_vt_walk_fast live in lt_rk_kernel.hip: lt_rk_launch.h)
+  launch_k_vt_table(e->cfg.slab_storage == LT_SLAB_F32, e->cfg.Vtransform, P.fastdiv != 0, blocks, e->stream, P);
   hipLaunchKernelGGL(k_vt_sigs, dim3(blocks), dim3(256), 0, e->stream, P);
   wait_rng(e);
-  hipLaunchKernelGGL(k_vt_norm, dim3(blocks), dim3(256), 0, e->stream, P);
+  launch_k_vt_norm(blocks, e->stream, P);
   // the walks on zero-tension intervals; then, for the ones that met a tension factor, the rest of the walk
   // (as many workgroups as could be needed: the ones beyond the list's end leave at once)
-  hipLaunchKernelGGL(k_vt_walk_fast, dim3(blocks * (256 / LT_VT_WALKFAST_BLOCK)), dim3(LT_VT_WALKFAST_BLOCK), 0, e->stream, P);
+  launch_k_vt_walk_fast(blocks, e->stream, P);
   hipLaunchKernelGGL(k_vt_walk, dim3(blocks * (256 / LT_VT_WALK_BLOCK)), dim3(LT_VT_WALK_BLOCK), 0, e->stream, P);
-}
-void launch_vturb(lt_engine* e, const StepParams& P, unsigned blocks) {
-  if (e->cfg.slab_storage == LT_SLAB_F32) launch_vturb_t<float>(e, P, blocks);
-  else launch_vturb_t<double>(e, P, blocks);
 }
 // k_rk is instantiated per slab type and per Vtransform (the s-level formula is then straight-line code in
 // the hot loop), in lt_rk_kernel.hip

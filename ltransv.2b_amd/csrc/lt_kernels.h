@@ -63,8 +63,8 @@ template <> struct SlabTraits<double> { using zeta4 = double4; };
 
 #include "lt_grid.h"
 #include "lt_rk.h"
+#include "lt_vturb.h"   // (its kernels are split between the two translation units: LT_VT_DEFINE_A / _B)
 #ifndef LT_KERNELS_RK_ONLY  // (lt_rk_kernel.hip: the kernels below are not templates and belong to lt_engine.hip)
-#include "lt_vturb.h"
 #include "lt_post.h"
 #include "lt_io.h"
 #include "lt_init.h"

@@ -1,7 +1,8 @@
-// lt_rk_kernel.hip -- k_rk (lt_rk.h) in a translation unit of its own, because it is compiled with
-// `-mllvm -disable-machine-licm` and the rest of the library is not.
+// lt_rk_kernel.hip -- k_rk (lt_rk.h) and three of the VTurb kernels (lt_vturb.h: k_vt_table, k_vt_norm,
+// k_vt_walk_fast) in a translation unit of their own, because it is compiled with `-mllvm -disable-machine-licm` and
+// the rest of the library is not.
 //
-// Pass B of k_rk (the Newton iterations of SIGS, lt_math.h: sigs_newton_k, exp_core, hval_interval_s) works with
+// Pass B of k_rk (the Newton iterations of SIGS, lt_math.h: sigs_newton_w, exp_core, hval_interval_s) works with
 // some twenty double-precision constants -- polynomial coefficients, the constants of libm's exp.  A double that
 // is not an inline constant occupies a pair of scalar registers, and the machine-level loop-invariant code
 // motion of the compiler moves their `s_mov`s out of every loop of the kernel: ~45 scalar registers held from
@@ -10,12 +11,15 @@
 // v_readlane -- a vector-ALU issue slot each, inside the slot loop the kernel spends its time in.  With the
 // constants materialised where they are used (scalar-ALU instructions, which issue beside the other wave's
 // vector instructions) k_rk issues 24.2k instead of 25.1k vector instructions per wave and step at 212
-// instead of 256 vector registers, and takes 0.946 instead of 0.971 ms.  The VTurb
-// kernels lose with the same option (k_vt_sigs, k_vt_norm), hence the separate unit.
+// instead of 256 vector registers, and takes 0.946 instead of 0.971 ms.
+// The option was then measured on every kernel of the library: k_vt_walk_fast 526 -> 491 us (96 -> 80 registers, a
+// sixth wave per SIMD), k_vt_norm 444 -> 437 (85 -> 38), k_vt_table -0.5 %: these three are defined here
+// (LT_VT_DEFINE_A); k_vt_sigs +3 %, k_vt_walk +2.5 %, k_post 106 -> 128 us, k_pre slower: they stay in lt_engine.hip.
 #include <hip/hip_runtime.h>
 
 #include "../../include/ltrans_hip.h"
 #define LT_KERNELS_RK_ONLY
+#define LT_VT_DEFINE_A
 #include "lt_kernels.h"
 #include "lt_rk_launch.h"
 
@@ -33,6 +37,31 @@ static void launch_k_rk_t(int Vtransform, unsigned grid, unsigned dynlds, hipStr
 void launch_k_rk(bool f32, int Vtransform, unsigned grid, unsigned dynlds, hipStream_t stream, const StepParams& P) {
   if (f32) launch_k_rk_t<float>(Vtransform, grid, dynlds, stream, P);
   else launch_k_rk_t<double>(Vtransform, grid, dynlds, stream, P);
+}
+
+template <typename SlabT>
+static void launch_k_vt_table_t(int Vtransform, bool fastdiv, unsigned blocks, hipStream_t st, const StepParams& P) {
+#define LT_LAUNCH_VT_TABLE(VT)                                                                         \
+  do {                                                                                                \
+    if (fastdiv) hipLaunchKernelGGL((k_vt_table<SlabT, VT, true>), dim3(blocks), dim3(256), 0, st, P); \
+    else hipLaunchKernelGGL((k_vt_table<SlabT, VT, false>), dim3(blocks), dim3(256), 0, st, P);          \
+  } while (0)
+  switch (Vtransform) {
+    case 1: LT_LAUNCH_VT_TABLE(1); break;
+    case 2: LT_LAUNCH_VT_TABLE(2); break;
+    default: LT_LAUNCH_VT_TABLE(3); break;
+  }
+#undef LT_LAUNCH_VT_TABLE
+}
+void launch_k_vt_table(bool f32, int Vtransform, bool fastdiv, unsigned blocks, hipStream_t stream, const StepParams& P) {
+  if (f32) launch_k_vt_table_t<float>(Vtransform, fastdiv, blocks, stream, P);
+  else launch_k_vt_table_t<double>(Vtransform, fastdiv, blocks, stream, P);
+}
+void launch_k_vt_norm(unsigned blocks, hipStream_t stream, const StepParams& P) {
+  hipLaunchKernelGGL(k_vt_norm, dim3(blocks), dim3(256), 0, stream, P);
+}
+void launch_k_vt_walk_fast(unsigned blocks, hipStream_t stream, const StepParams& P) {
+  hipLaunchKernelGGL(k_vt_walk_fast, dim3(blocks * (256 / LT_VT_WALKFAST_BLOCK)), dim3(LT_VT_WALKFAST_BLOCK), 0, stream, P);
 }
 
 #ifdef LT_RK_TIMING

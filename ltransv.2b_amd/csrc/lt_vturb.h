@@ -1,5 +1,8 @@
-// lt_vturb.h -- HTurb / VTurb helpers and the three VTurb kernels (table, SIGS, walk).
+// lt_vturb.h -- HTurb / VTurb helpers and the VTurb kernels (table, SIGS, deviates, the two walks).
 // Part of lt_kernels.h (included inside namespace ltd); see the notes there.
+// The kernels are not all in one translation unit: LT_VT_DEFINE_A (k_vt_table, k_vt_norm, k_vt_walk_fast) is set by
+// lt_rk_kernel.hip, which is compiled without the machine-level loop-invariant code motion (these three gain from
+// that: fewer registers held by hoisted constants), LT_VT_DEFINE_B (k_vt_sigs, k_vt_walk) by lt_engine.hip (these lose).
 #pragma once
 
 // ---------------------------------------------------------------- turbulence
@@ -242,6 +245,7 @@ LT_DEV void linint_interval(const VtInterval& c, double x, double& y, double& m)
 // tensions, computing all of them here changes nothing.
 // FD: the per-step divisors (4*ws, 6, the ex differences) have usable reciprocals (div_by);
 // a template parameter so that the ~20 quotients per knot carry no branch
+#ifdef LT_VT_DEFINE_A
 template <typename SlabT, int VT, bool FD>
 __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
   __shared__ double lev[6 * LT_LEV_STRIDE];
@@ -516,10 +520,12 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
     if (f2 != fl) P.ws_i[n] = f2;
   }
 }
+#endif  // LT_VT_DEFINE_A
 
 // The SIGS iterations (tension_module.f90:531-760) of the listed intervals, one wave per list, 64 at a
 // time; the tension factor goes into the knot's record, a failed convexity iteration (SigErr) into the
 // particle's flag word.
+#ifdef LT_VT_DEFINE_B
 __global__ __launch_bounds__(256) void k_vt_sigs(const StepParams P) {
   exp_table_load();
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -552,12 +558,13 @@ __global__ __launch_bounds__(256) void k_vt_sigs(const StepParams P) {
   }
   if (lane == 0 && rounds) atomicAdd(&P.counters[CNT_VT_ROUNDS], (unsigned long long)rounds);
 }
+#endif  // LT_VT_DEFINE_B
 
-struct __attribute__((packed, aligned(4))) RawWords4 { uint32_t a, b, c, d; };
 // rows of deviates per group of 64 particles: two for HTurb's X and Y (hor_turb_module.f90:29-50; formed here when
 // both kinds of turbulence are on, read by k_post), then the idt/2 of the walk
 #define VT_DEV_HROWS 2
 #define VT_DEV_BASE(P, n, loop) ((P).vt_dev + (size_t)((n) >> 6) * (size_t)((loop) + VT_DEV_HROWS) * 64 + (size_t)((n) & 63))
+struct __attribute__((packed, aligned(4))) RawWords4 { uint32_t a, b, c, d; };
 // ---- the normal deviates of the walk
 // norm() (norm_module.f90:25-39) of a sub-step is a function of the particle's two words of the stream alone, not
 // of where the walk has got to: the idt/2 deviates of every tracked particle are formed here, ahead of the walk and
@@ -566,6 +573,7 @@ struct __attribute__((packed, aligned(4))) RawWords4 { uint32_t a, b, c, d; };
 // depend on nothing in it).  One lane per particle, a line of raw words (8 sub-steps) at a time as the walk took
 // them; the deviates go to vt_dev[group of 64 particles][sub-step][lane], so that a wave of the walk reads one
 // 512-byte row per sub-step.  Same functions, same operands, same product: the walk's sums are unchanged.
+#ifdef LT_VT_DEFINE_A
 __global__ __launch_bounds__(256) void k_vt_norm(const StepParams P) {
   __shared__ uint2 rbuf[8][256];
   libm_tables_load<LM_LOG | LM_SINCOS>();
@@ -613,6 +621,7 @@ __global__ __launch_bounds__(256) void k_vt_norm(const StepParams P) {
     }
   }
 }
+#endif  // LT_VT_DEFINE_A
 
 // ---- the walk, in two kernels
 // 80 % of the walks never leave the zero-tension intervals (~9 % of the intervals carry a tension factor and
@@ -674,6 +683,7 @@ LT_DEV void vt_seek_lite(VtLite& c, double T, int n, const double4* tab) {
 #ifndef LT_VT_WALK_BLOCK
 #define LT_VT_WALK_BLOCK 256
 #endif
+#ifdef LT_VT_DEFINE_A
 __global__ __launch_bounds__(LT_VT_WALKFAST_BLOCK) void k_vt_walk_fast(const StepParams P) {
   libm_tables_load<LM_EXP | LM_POW>();  // (pow takes the exp table too)
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -744,8 +754,10 @@ __global__ __launch_bounds__(LT_VT_WALKFAST_BLOCK) void k_vt_walk_fast(const Ste
     if (stopped) P.vt_wl_list[base + __popcll(m & ((1ull << lane) - 1ull))] = n;
   }
 }
+#endif  // LT_VT_DEFINE_A
 
 // :282-335 random displacement model, idt/2 sub-steps of 2 s: the listed walks, every form of HVAL / HPVAL
+#ifdef LT_VT_DEFINE_B
 __global__ __launch_bounds__(LT_VT_WALK_BLOCK) void k_vt_walk(const StepParams P) {
   const int nlisted = *P.vt_wl_count;
   if ((int)(blockIdx.x * blockDim.x) >= nlisted) return;   // (the whole workgroup: launched for the worst case)
@@ -852,3 +864,4 @@ __global__ __launch_bounds__(LT_VT_WALK_BLOCK) void k_vt_walk(const StepParams P
   wsd[(size_t)WS_TURBV * N] = P_zc - ParZc;  // :342
   if (sigerr != 0) atomicAdd(&P.counters[CNT_SIGERR], 1ull);
 }
+#endif  // LT_VT_DEFINE_B
