@@ -63,6 +63,8 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--prewarm-ms", type=float, default=200.0,
+                    help="busy the GPU this long before the warm-up steps so that the clocks are up (0: off)")
     ap.add_argument("--workload", choices=["auto"] + sorted(WORKLOADS), default="auto",
                     help="auto = config2 (the configuration the metric is quoted on) per GPU: on several GPUs weak scaling, "
                          "with configs[3] strong-scaled timed beside it (config.configs3_strong)")
@@ -192,6 +194,24 @@ def selftest_launch(args, world, rank):
 
 
 # ----------------------------------------------------------------------------- helpers
+def prewarm_clocks(ms):
+    """Keep the GPU busy for `ms` milliseconds (fp32 matrix products, nothing of the workload) right before the warm-up
+    steps.  Power management drops the clocks while the host prepares the case; they come back over the first ~15
+    steps of 1 ms (k_rk 0.89 -> 0.81 ms, tools/dev/step_trend.py), which a warm-up of 5 steps does not cover and a
+    run of thousands of steps does not see.  `config.clock_prewarm_ms` says what was done; --prewarm-ms 0 turns it off."""
+    if ms <= 0:
+        return
+    import torch
+    a = torch.randn(2048, 2048, device="cuda")
+    b = torch.randn(2048, 2048, device="cuda")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        for _ in range(8):
+            a @ b
+        torch.cuda.synchronize()
+
+
 def source_hash_of_profile(tag):
     p = os.path.join(ROOT, "profiles", tag, "pmc.json")
     try:
@@ -644,6 +664,7 @@ def main():
                 torch.cuda.synchronize()
 
         setup_s = time.perf_counter() - t_begin
+        prewarm_clocks(args.prewarm_ms)
         for _ in range(args.warmup):
             if st.needs_rotation():
                 st.rotate()
@@ -714,6 +735,7 @@ def main():
                        "sigerr_last_step": stats["sigerr"], "slab_rotation_s_excluded": upload_s,
                        # the device-side re-sort of the particle order (every `resort_every` = 32 steps inside lt_step):
                        # how many fell into the timed region -- they are part of `value` -- and what one costs
+                       "clock_prewarm_ms": args.prewarm_ms,
                        "resorts_in_timed_region": resorts_in, "resort_every_steps": 32, "resort_ms_each": resort_ms,
                        # the re-sorts a run of `steps` steps has on average (steps / 32) that did not fall into the
                        # timed region, in seconds: add it to the region's wall time for the steady-state figure
@@ -746,6 +768,7 @@ def main():
             step_t()                  # the first step carries the start-up of the random stream (generator states, ring)
             fence_t()
             first_step_s = time.perf_counter() - t_create
+            prewarm_clocks(args.prewarm_ms)
             for _ in range(max(args.warmup - 1, 0)):
                 if st_t.needs_rotation():
                     st_t.rotate()
