@@ -180,3 +180,32 @@ def test_allgather_layout_three_ragged_shards():
                 o += c
         assert np.array_equal(got, np.concatenate(parts, axis=0)), (rank, counts)
         e.close()
+
+
+def test_downloads_through_the_staging_buffer(oracle):
+    """lt_get_particles through the library's pinned staging buffer: a download of one array (small buffer), then of
+    everything (the buffer grows), then into the arrays of the earlier call, with few and with many host threads --
+    always the oracle's values"""
+    import os
+    case = cases.build_case("tiny_sink")
+    outs = {}
+    for which in ("hip", "oracle"):
+        e = cases.make_engine(case, ltrans_amd.Engine, {} if which == "hip" else dict(lib=oracle, prefix="lto_"))
+        from ltrans_amd.driver import LtransRun
+        run = LtransRun(e, case["cfg"].dt, case["cfg"].idt, case["record"])
+        run.init_hydro()
+        run.run(1, max_internal=3)
+        first = e.get_particles(fields=("par",))
+        full = e.get_particles()
+        assert np.array_equal(first["par"], full["par"])
+        os.environ["LT_GET_THREADS"] = "3"
+        try:
+            again = e.get_particles(out=full)
+        finally:
+            del os.environ["LT_GET_THREADS"]
+        for k in full:
+            assert np.shares_memory(again[k], full[k])
+        outs[which] = {k: v.copy() for k, v in again.items()}
+        e.close()
+    for k in outs["oracle"]:
+        assert np.array_equal(outs["hip"][k], outs["oracle"][k]), k
