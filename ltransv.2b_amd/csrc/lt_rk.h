@@ -917,8 +917,6 @@ __global__ __launch_bounds__(LT_RK_BLOCK) __attribute__((amdgpu_waves_per_eu(WAV
 void k_rk(const StepParams P) {
   __shared__ double lev[6 * LT_LEV_STRIDE];
   __shared__ WaveScratch wsc[LT_RK_BLOCK / 64];
-  for (int i = threadIdx.x; i < 6 * LT_LEV_STRIDE; i += blockDim.x) lev[i] = P.lev[i];
-  exp_table_load();
   // XCD-aware order: workgroups go round-robin to the 8 XCDs (each with its own L2), so workgroup b takes
   // the chunk  (b mod 8) * (grid / 8) + b / 8  of the particles: every XCD works through ONE contiguous
   // eighth of the (element-sorted) particles, and the waves in flight on it share the node columns of
@@ -933,14 +931,24 @@ void k_rk(const StepParams P) {
 #endif
   const int n = (int)(vb * blockDim.x + threadIdx.x);
   const size_t N = (size_t)P.numpar;
-  const bool act = (n < P.numpar) && ((P.ws_i[n] & FL_ACT) != 0);
-  const double* wsd = P.ws_d + (act ? n : 0);
+  // The particle's state is asked for before the tables are staged and without waiting for its flag word (a lane
+  // beyond the particles, or one that is not tracked, reads particle 0's / its own stale values and selects them
+  // away): one round trip for flag, position, depth and elements beside the tables' instead of three in a row.
+  const int nn = (n < P.numpar) ? n : 0;
+  const int fl0 = P.ws_i[nn];
+  const double* wsd = P.ws_d + nn;
+  const double h0 = wsd[(size_t)WS_PDEPTH * N], X0 = P.par[(size_t)pX * N + nn], Y0 = P.par[(size_t)pY * N + nn];
+  const double Z0 = wsd[(size_t)WS_ZPAR * N];
+  const int er0 = P.P_r_element[nn], eu0 = P.P_u_element[nn], ev0 = P.P_v_element[nn];
+  for (int i = threadIdx.x; i < 6 * LT_LEV_STRIDE; i += blockDim.x) lev[i] = P.lev[i];
+  exp_table_load();
+  const bool act = (n < P.numpar) && ((fl0 & FL_ACT) != 0);
   double h = 1.0, Xs = 0.0, Ys = 0.0, Zs = 0.0;
   if (act) {
-    h = -1.0 * wsd[(size_t)WS_PDEPTH * N];
-    Xs = P.par[(size_t)pX * N + n];
-    Ys = P.par[(size_t)pY * N + n];
-    Zs = wsd[(size_t)WS_ZPAR * N];
+    h = -1.0 * h0;
+    Xs = X0;
+    Ys = Y0;
+    Zs = Z0;
   }
   // RK4 :990-1053, executed by the whole wave
   double sumU = 0.0, sumV = 0.0, sumW = 0.0;
@@ -953,7 +961,7 @@ void k_rk(const StepParams P) {
   const Divisor dv = prep_div((VT == 2) ? P.hc + h : h);  // every level depth divides by it
   // the RK stages keep the elements of the start position (LTRANS.f90:990-1053)
   int er = 1, eu = 1, ev_ = 1;
-  if (act) { er = P.P_r_element[n]; eu = P.P_u_element[n]; ev_ = P.P_v_element[n]; }
+  if (act) { er = er0; eu = eu0; ev_ = ev0; }
   // free slip: an element with a land node has its values substituted before every interpolation
   // (:1934-1994, 2329-2520); those few particles take the straight transcription of k_rk_slow
   bool act_fast = act;
