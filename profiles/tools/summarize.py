@@ -27,8 +27,14 @@ def main(out):
         with open(os.path.join(sm, "kernel_stats.csv"), "w", newline="") as f:
             csv.writer(f).writerows(rows)
         lines.append("kernel durations (rocprofv3 --kernel-trace --stats)")
-        for r in rows[1:12]:
+        # (rocBLAS' Cijk_* products are bench.py's clock pre-warm -- 200 ms of fp32 matrix products before the warm-up
+        # steps of each timed series, outside the timed region: kept in kernel_stats.csv, not listed here)
+        warm = [r for r in rows[1:] if r[0].startswith("Cijk_")]
+        for r in [r for r in rows[1:] if not r[0].startswith("Cijk_")][:11]:
             lines.append("  %-58s calls %4s  avg %10.1f us  %5s %%" % (r[0][:58], r[1], float(r[3]) / 1e3, r[4][:5]))
+        if warm:
+            lines.append("  (percentages of all GPU time, of which %.1f %% is bench.py's clock pre-warm: %d rocBLAS products, not listed)"
+                         % (sum(float(r[4]) for r in warm), sum(int(r[1]) for r in warm)))
     for name in ("stats", "pmc_sq", "pmc_fetch", "pmc_write"):
         p = os.path.join(out, name + ".bench.json")
         if os.path.exists(p) and os.path.getsize(p) and name == "stats":
