@@ -1005,7 +1005,7 @@ void k_rk(const StepParams P) {
       if (Zs < ST.maxpd) Zs = ST.maxpd + (double)0.000001f;
     }
   }
-#ifdef LT_RK_TIMING
+#if defined(LT_RK_TIMING) && !defined(LT_VT_EXCURSION)
   if ((threadIdx.x & 63) < 16) atomicAdd(&g_tim[threadIdx.x & 63], ws.tim[threadIdx.x & 63]);
 #endif
   if (act) {

@@ -504,8 +504,10 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
 #pragma unroll 1
   for (int k = p2 - 4; k <= p2; k++) knot(k, std::false_type{});
 #ifdef LT_RK_TIMING
+#ifndef LT_VT_EXCURSION
   if (lane == 0)
     for (int q = 0; q < 6; q++) atomicAdd(&g_tim[8 + q], vt_acc[q]);
+#endif
 #endif
 #ifdef LT_VT_ADV_STATS
   if (lane == 0) { atomicAdd(&g_tim[6], (unsigned long long)adv_exec); atomicAdd(&g_tim[7], (unsigned long long)adv_lanes); atomicAdd(&g_tim[5], 1ull); }
@@ -631,6 +633,11 @@ __global__ __launch_bounds__(256) void k_vt_norm(const StepParams P) {
 // only: a walk that enters an interval with a tension factor (or whose table is not a proper spline: SigErr,
 // YPC1's failure) stops at the beginning of that sub-step and is listed; k_vt_walk takes the listed walks,
 // one lane each, from the sub-step they stopped at, with every form.  Same operations per walk either way.
+#ifdef LT_VT_EXCURSION
+#define EX_NOTE() do { if (ci.I < ex_lo) ex_lo = ci.I; if (ci.I > ex_hi) ex_hi = ci.I; } while (0)
+#else
+#define EX_NOTE() do { } while (0)
+#endif
 struct VtLite {          // the cached interval without the tension-dependent parts
   int I;
   double X1, X2, Y1, Y2, P1, P2, SG, SGhi;
@@ -707,6 +714,9 @@ __global__ __launch_bounds__(LT_VT_WALKFAST_BLOCK) void k_vt_walk_fast(const Ste
   // (a table that is not a proper spline is walked by k_vt_walk from the first sub-step)
   bool stopped = (fl & (FL_VT_YPCFAIL | FL_VT_SIGERR)) != 0;
   int stop_i = 1;
+#ifdef LT_VT_EXCURSION
+  int ex_lo = 1 << 30, ex_hi = 0;   // development aid (tools/dev/vt_excursion.py): the intervals this walk visits
+#endif
 #pragma unroll 1
   for (int i = 1; i <= loop; i++) {
     if (stopped) break;
@@ -715,6 +725,7 @@ __global__ __launch_bounds__(LT_VT_WALKFAST_BLOCK) void k_vt_walk_fast(const Ste
     bool tens = false;
     if (!(ParZc < P_depth || ParZc > P_zetac)) {
       vt_seek_lite(ci, ParZc, p2, tab);
+      EX_NOTE();
       tens = !(fabs(ci.SG) < 1.e-9);
       const double B1 = div_prep(ci.X2 - ParZc, ci.dx), B2 = 1.0 - B1;  // HPVAL's cubic form, :1222
       Kprimec = ci.P1 + B2 * (ci.D1 + ci.D2 - 3.0 * B1 * (ci.D2 - ci.D1));
@@ -724,6 +735,7 @@ __global__ __launch_bounds__(LT_VT_WALKFAST_BLOCK) void k_vt_walk_fast(const Ste
     double KH3rdc = background;
     if (!tens && !(Z3rdc < P_depth || Z3rdc > P_zetac)) {
       vt_seek_lite(ci, Z3rdc, p2, tab);
+      EX_NOTE();
       tens = !(fabs(ci.SG) < 1.e-9);
       const double U = Z3rdc - ci.X1;                                   // HVAL's cubic form, :1083
       const double B2 = div_prep(U, ci.dx), B1 = 1.0 - B2;
@@ -744,6 +756,18 @@ __global__ __launch_bounds__(LT_VT_WALKFAST_BLOCK) void k_vt_walk_fast(const Ste
     wsd[(size_t)WS_TURBV * N] = ParZc;         // the depth at the beginning of sub-step stop_i
     P.vt_wl_resume[n] = stop_i;
   }
+#ifdef LT_VT_EXCURSION
+  if (ex_hi >= ex_lo) {
+    // how far from the interval of its start depth (estimated as vt_seek_lite's first use does) the walk went
+    const double xa = tab[0].x, xb = tab[(size_t)(p2 - 1) * VT_TS].x;
+    int k0 = (int)((P_zc - xa) / (xb - xa) * (double)(p2 - 1)) + 1;
+    if (k0 < 1) k0 = 1;
+    if (k0 > p2 - 1) k0 = p2 - 1;
+    int ex = max(ex_hi - k0, k0 - ex_lo);
+    if (ex < 0) ex = 0;
+    atomicAdd(&g_tim[ex < 15 ? ex : 15], 1ull);
+  }
+#endif
   // the list of the stopped walks (one atomic per wave)
   const unsigned long long m = __ballot(stopped);
   if (m) {
@@ -785,6 +809,9 @@ __global__ __launch_bounds__(LT_VT_WALK_BLOCK) void k_vt_walk(const StepParams P
   ci.I = 0; ci.X1 = ci.X2 = ci.Y1 = ci.Y2 = ci.P1 = ci.P2 = ci.SG = ci.SGhi = 0.0;
   ci.S = ci.D1 = ci.D2 = ci.SM = ci.CM = ci.CMM = 0.0; ci.dx.b = 1.0; ci.dx.y = 1.0;
   const bool cached = (sigerr == 0) && !ypc_fail;
+#ifdef LT_VT_EXCURSION
+  int ex_lo = 1 << 30, ex_hi = 0;
+#endif
 #ifdef LT_RK_TIMING
   // development aid (tools/dev/vt_walk_stats.py): what the waves of this kernel spend their sub-steps on
   unsigned long long st_t0 = __builtin_readcyclecounter();
@@ -803,6 +830,7 @@ __global__ __launch_bounds__(LT_VT_WALK_BLOCK) void k_vt_walk(const StepParams P
     if (!(ParZc < P_depth || ParZc > P_zetac)) {
       if (cached) {
         vt_seek(ci, ParZc, p2, tab);
+        EX_NOTE();
         ST_NOTE();
         Kprimec = hpval_prepared(ParZc, ci);
       } else if (sigerr == 0) {
@@ -821,6 +849,7 @@ __global__ __launch_bounds__(LT_VT_WALK_BLOCK) void k_vt_walk(const StepParams P
     } else {
       if (cached) {
         vt_seek(ci, Z3rdc, p2, tab);
+        EX_NOTE();
         ST_NOTE();
         KH3rdc = hval_prepared(Z3rdc, ci);
       } else if (sigerr == 0) {
@@ -849,6 +878,7 @@ __global__ __launch_bounds__(LT_VT_WALK_BLOCK) void k_vt_walk(const StepParams P
       s_li += __shfl_xor(s_li, o, 64); s_lt += __shfl_xor(s_lt, o, 64);
       aT = max(aT, __shfl_xor(aT, o, 64)); aR = max(aR, __shfl_xor(aR, o, 64)); aE = max(aE, __shfl_xor(aE, o, 64));
     }
+#ifndef LT_VT_EXCURSION
     if ((threadIdx.x & 63) == (__ffsll((long long)__ballot(1)) - 1)) {
       atomicAdd(&g_tim[0], 1ull); atomicAdd(&g_tim[1], (unsigned long long)mx_iter);
       atomicAdd(&g_tim[2], (unsigned long long)s_li); atomicAdd(&g_tim[3], (unsigned long long)s_lt);
@@ -859,6 +889,18 @@ __global__ __launch_bounds__(LT_VT_WALK_BLOCK) void k_vt_walk(const StepParams P
       atomicAdd(&g_tim[14], __builtin_readcyclecounter() - st_t0);
       atomicMax(&g_tim[15], __builtin_readcyclecounter() - st_t0);
     }
+#endif
+  }
+#endif
+#ifdef LT_VT_EXCURSION
+  if (ex_hi >= ex_lo) {
+    const double xa = tab[0].x, xb = tab[(size_t)(p2 - 1) * VT_TS].x;
+    int k0 = (int)((P_zc - xa) / (xb - xa) * (double)(p2 - 1)) + 1;
+    if (k0 < 1) k0 = 1;
+    if (k0 > p2 - 1) k0 = p2 - 1;
+    int ex = max(ex_hi - k0, k0 - ex_lo);
+    if (ex < 0) ex = 0;
+    atomicAdd(&g_tim[ex < 15 ? ex : 15], 1ull);
   }
 #endif
   wsd[(size_t)WS_TURBV * N] = P_zc - ParZc;  // :342
