@@ -537,13 +537,24 @@ __global__ __launch_bounds__(256) void k_vt_sigs(const StepParams P) {
   const int count = Q.count[wave], p2 = 4 * P.ws;
   const size_t qb = (size_t)wave * (size_t)Q.cap;
   unsigned rounds = 0;
+  // (the next round's task is requested before the current one is iterated: a round is a load's round trip and then
+  // a chain of dependent operations, and with one after the other the wave sat through both)
+  double nS = 0.0, nS1 = 0.0, nS2 = 0.0;
+  unsigned nwl = 0;
+  {
+    const size_t ti = qb + ((lane < count) ? lane : 0);
+    nS = Q.S[ti]; nS1 = Q.S1[ti]; nS2 = Q.S2[ti]; nwl = Q.wl[ti];
+  }
 #pragma unroll 1
   for (int t = lane; t - lane < count; t += 64) {
     rounds += 1;
     const bool have = t < count;
-    const size_t ti = qb + (have ? t : 0);
-    const double S = Q.S[ti], S1 = Q.S1[ti], S2 = Q.S2[ti];
-    const unsigned wl = Q.wl[ti];
+    const double S = nS, S1 = nS1, S2 = nS2;
+    const unsigned wl = nwl;
+    if (t - lane + 64 < count) {
+      const size_t tn = qb + ((t + 64 < count) ? t + 64 : 0);
+      nS = Q.S[tn]; nS1 = Q.S1[tn]; nS2 = Q.S2[tn]; nwl = Q.wl[tn];
+    }
     double sg = 0.0;
     double T = 0.0, sgn;
     const int kind = have ? sigs_classify(S, S1, S2, sg, T) : SIGK_DONE;
