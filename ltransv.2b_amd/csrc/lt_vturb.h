@@ -104,6 +104,13 @@ LT_DEV void polintd3x3(const StepParams& P, double ya1, double ya2, double ya3,
 // Beside the knot data it holds what HVAL / HPVAL compute from the interval alone (chord
 // slope, second differences, the prepared divisor DX and, for 1e-9 <= sigma <= .5, SNHCSH of
 // sigma), formed once when the interval is entered: the same operations, hoisted.
+// the chord slope of an interval through the reciprocal prepared for its width (a difference of diffusivities over a
+// knot spacing > 0: the same value as `/`, lt_math.h) -- LT_VT_SLOPE_DIV: with `/`, for comparison
+#ifdef LT_VT_SLOPE_DIV
+#define LT_VT_SLOPE(num, den, dv) ((num) / (den))
+#else
+#define LT_VT_SLOPE(num, den, dv) div_prep((num), (dv))
+#endif
 struct VtInterval {
   int I;
   double X1, X2, Y1, Y2, P1, P2, SG;
@@ -114,7 +121,7 @@ struct VtInterval {
 LT_DEV void vt_prepare(VtInterval& c) {
   const double DX = c.X2 - c.X1;
   c.dx = prep_div(DX);
-  c.S = (c.Y2 - c.Y1) / DX;
+  c.S = LT_VT_SLOPE(c.Y2 - c.Y1, DX, c.dx);
   c.D1 = c.S - c.P1;
   c.D2 = c.P2 - c.S;
   const double SIG = fabs(c.SG);
@@ -690,7 +697,7 @@ LT_DEV void vt_seek_lite(VtLite& c, double T, int n, const double4* tab) {
   if (moved) {  // vt_prepare without SNHCSH
     const double DX = c.X2 - c.X1;
     c.dx = prep_div(DX);
-    c.S = (c.Y2 - c.Y1) / DX;
+    c.S = LT_VT_SLOPE(c.Y2 - c.Y1, DX, c.dx);
     c.D1 = c.S - c.P1;
     c.D2 = c.P2 - c.S;
   }
