@@ -478,7 +478,10 @@ int put_field(lt_engine* e, DevBuf& buf, const T* src, int cols) {
 // LTRANS.f90:632-658): each array is put into the reference's order ON THE DEVICE (k_unpermute through `orig`)
 // into its part of one staging buffer and copied to the caller's memory from there; nothing waits until
 // get_fields_end.  (Round 3 copied each array to a pageable temporary, waited, and scattered it on the host:
-// 100 ms for the 240 MB of a million particles.)
+// 100 ms for the 240 MB of a million particles.)  The copies land in a pinned buffer of the library, kept between
+// calls, and up to eight host threads move each array on to the caller's memory while the next arrives.
+// Environment, for measurements: LT_GET_THREADS=n (host threads), LT_GET_NOPIN=1 (copy straight to the caller's
+// pageable memory), LT_GET_TIMING=1 (one line on stderr per download).
 int get_fields_begin(lt_engine* e, size_t total_bytes) {
   TRY(dev_alloc(e, e->get_stage, total_bytes + 256));
   e->get_stage_used = 0;
