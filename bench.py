@@ -63,7 +63,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--prewarm-ms", type=float, default=200.0,
+    ap.add_argument("--prewarm-ms", type=float, default=40.0,
                     help="busy the GPU this long before the warm-up steps so that the clocks are up (0: off)")
     ap.add_argument("--workload", choices=["auto"] + sorted(WORKLOADS), default="auto",
                     help="auto = config2 (the configuration the metric is quoted on) per GPU: on several GPUs weak scaling, "
@@ -197,13 +197,15 @@ def selftest_launch(args, world, rank):
 def prewarm_clocks(ms):
     """Keep the GPU busy for `ms` milliseconds (fp32 matrix products, nothing of the workload) right before the warm-up
     steps.  Power management drops the clocks while the host prepares the case; they come back over the first ~15
-    steps of 1 ms (k_rk 0.89 -> 0.81 ms, tools/dev/step_trend.py), which a warm-up of 5 steps does not cover and a
-    run of thousands of steps does not see.  `config.clock_prewarm_ms` says what was done; --prewarm-ms 0 turns it off."""
+    steps of 1 ms (k_rk 0.89 -> 0.80 ms, tools/dev/step_trend.py), which a warm-up of 5 steps does not cover and a
+    run of thousands of steps does not see; 20 ms of products bring them back as well (a memory-bound load of the same
+    length does not).  `config.clock_prewarm_ms` says what was done; --prewarm-ms 0 turns it off."""
     if ms <= 0:
         return
     import torch
     a = torch.randn(2048, 2048, device="cuda")
     b = torch.randn(2048, 2048, device="cuda")
+    a @ b                       # (the first product loads the BLAS library: not counted)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     while (time.perf_counter() - t0) * 1e3 < ms:

@@ -27,7 +27,7 @@ def main(out):
         with open(os.path.join(sm, "kernel_stats.csv"), "w", newline="") as f:
             csv.writer(f).writerows(rows)
         lines.append("kernel durations (rocprofv3 --kernel-trace --stats)")
-        # (rocBLAS' Cijk_* products are bench.py's clock pre-warm -- 200 ms of fp32 matrix products before the warm-up
+        # (rocBLAS' Cijk_* products are bench.py's clock pre-warm -- some tens of milliseconds of fp32 matrix products before the warm-up
         # steps of each timed series, outside the timed region: kept in kernel_stats.csv, not listed here)
         warm = [r for r in rows[1:] if r[0].startswith("Cijk_")]
         for r in [r for r in rows[1:] if not r[0].startswith("Cijk_")][:11]:

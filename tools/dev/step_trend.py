@@ -23,12 +23,19 @@ NS = 28
 e.sync()
 if len(sys.argv) > 1:
     ms = float(sys.argv[1])
-    a = torch.randn(4096, 4096, device="cuda"); b = torch.randn(4096, 4096, device="cuda")
+    kind = sys.argv[2] if len(sys.argv) > 2 else "matmul"
+    if kind == "matmul":
+        a = torch.randn(4096, 4096, device="cuda"); b = torch.randn(4096, 4096, device="cuda")
+    else:
+        a = torch.ones(1 << 26, device="cuda")
+    if kind == "matmul": c = a @ b      # (the first product loads the library: not counted)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     while (time.perf_counter() - t0) * 1e3 < ms:
-        for _ in range(10): c = a @ b
+        for _ in range(10):
+            if kind == "matmul": c = a @ b
+            else: a.mul_(1.0000001)
         torch.cuda.synchronize()
-    print("pre-warmed the clocks for %.0f ms with fp32 matrix products" % ((time.perf_counter() - t0) * 1e3))
+    print("pre-warmed the clocks for %.0f ms with %s" % ((time.perf_counter() - t0) * 1e3, kind))
 walls = []; ks = []
 for it in range(1, NS + 1):
     e.profile_begin(1)
