@@ -923,7 +923,12 @@ void launch_vturb(lt_engine* e, const StepParams& P, unsigned blocks) {
 // the hot loop), in lt_rk_kernel.hip
 void launch_rk(lt_engine* e, const StepParams& P, unsigned blocks) {
   // (a multiple of 8 workgroups: k_rk maps them to particle chunks per XCD)
+#if defined(LT_RK_XCD_CHUNK) && LT_RK_XCD_CHUNK > 0
+  const unsigned rkunit = 8u * LT_RK_XCD_CHUNK;
+  const unsigned rkblocks = (((unsigned)(((size_t)blocks * 256 + LT_RK_BLOCK - 1) / LT_RK_BLOCK) + rkunit - 1u) / rkunit) * rkunit;
+#else
   const unsigned rkblocks = ((unsigned)(((size_t)blocks * 256 + LT_RK_BLOCK - 1) / LT_RK_BLOCK) + 7u) & ~7u;
+#endif
   static const unsigned dynlds = getenv("LT_RK_DYNLDS") ? (unsigned)atoi(getenv("LT_RK_DYNLDS")) : 0u;  // occupancy experiments
   launch_k_rk(e->cfg.slab_storage == LT_SLAB_F32, e->cfg.Vtransform, rkblocks, dynlds, e->stream, P);
 }

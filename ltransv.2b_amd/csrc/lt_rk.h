@@ -921,7 +921,13 @@ void k_rk(const StepParams P) {
   // the chunk  (b mod 8) * (grid / 8) + b / 8  of the particles: every XCD works through ONE contiguous
   // eighth of the (element-sorted) particles, and the waves in flight on it share the node columns of
   // a few neighbouring rows of elements in its L2.  (The grid is a multiple of 8 workgroups.)
-#ifndef LT_RK_NO_XCD_MAP
+#if defined(LT_RK_XCD_CHUNK) && LT_RK_XCD_CHUNK > 0
+  // (the same, in chunks: XCD x takes the chunks x, x+8, x+16 ... of LT_RK_XCD_CHUNK workgroups each, so that a
+  // region of the domain whose particles are more work than the others' is shared by all eight; the grid is a
+  // multiple of 8 * LT_RK_XCD_CHUNK workgroups, the ones beyond the particles leave at once)
+  const unsigned xs_ = blockIdx.x >> 3;
+  const unsigned vb = ((xs_ / LT_RK_XCD_CHUNK) * 8u + (blockIdx.x & 7u)) * LT_RK_XCD_CHUNK + (xs_ % LT_RK_XCD_CHUNK);
+#elif !defined(LT_RK_NO_XCD_MAP)
   const unsigned vb = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
 #else
   const unsigned vb = blockIdx.x;
@@ -943,6 +949,7 @@ void k_rk(const StepParams P) {
   for (int i = threadIdx.x; i < 6 * LT_LEV_STRIDE; i += blockDim.x) lev[i] = P.lev[i];
   exp_table_load();
   const bool act = (n < P.numpar) && ((fl0 & FL_ACT) != 0);
+  if (LT_RK_BLOCK == 64 && !__ballot(act)) return;   // (a wave beyond the particles, or of 64 that are not tracked)
   double h = 1.0, Xs = 0.0, Ys = 0.0, Zs = 0.0;
   if (act) {
     h = -1.0 * h0;

@@ -18,10 +18,10 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/ltrans_hip.h"
+#include "lt_rk_launch.h"    // (first: LT_RK_BLOCK, LT_RK_XCD_CHUNK are used by the kernels)
 #define LT_KERNELS_RK_ONLY
 #define LT_VT_DEFINE_A
 #include "lt_kernels.h"
-#include "lt_rk_launch.h"
 
 namespace ltd {
 

@@ -9,6 +9,15 @@
 #define LT_RK_BLOCK 64   // one wave per block: a finished wave frees its slot at once (256-lane blocks: +3 % kernel time)
 #endif
 
+#ifndef LT_RK_XCD_CHUNK
+// k_rk's workgroups go round-robin to the 8 XCDs; XCD x works through the chunks x, x+8, x+16, ... of this many
+// workgroups of the (tile-sorted) particle order.  One contiguous eighth per XCD (0) fetches least (0.94 GB per
+// launch against 1.11 with 64 and 1.26 with 32), but a region of the domain whose particles are more work than the
+// others' then keeps one XCD busy after the rest have finished: 400 steps into the synthetic run the kernel was
+// 2-3 % faster with chunks of 64 (3 % with 32), at equal time in the first steps.
+#define LT_RK_XCD_CHUNK 64
+#endif
+
 namespace ltd {
 struct StepParams;
 // k_rk<float|double, Vtransform, LT_RK_WAVES> on `grid` workgroups of LT_RK_BLOCK lanes

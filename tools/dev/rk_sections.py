@@ -21,12 +21,18 @@ run.init_hydro()
 ex = run.external_times(2)
 lib = e.lib
 out = (C.c_ulonglong * 16)()
+LATE = int(sys.argv[1]) if len(sys.argv) > 1 else 0     # external steps to run first (30 internal steps each)
+p = 2
+for _ in range(LATE):
+    run.run_external_timestep(p); p += 1
+if LATE:
+    run.p = p; run.update_hydro(); ex = run.external_times(p)
 for it in range(1, 6):
-    e.update_particles(ex, run.internal_times(ex, it), 2, it)
+    e.update_particles(ex, run.internal_times(ex, it), p, it)
 e.sync(); lib.lt_diag(out)
 K = 10
 for it in range(6, 6 + K):
-    e.update_particles(ex, run.internal_times(ex, it), 2, it)
+    e.update_particles(ex, run.internal_times(ex, it), p, it)
 e.sync(); lib.lt_diag(out)
 v = [int(x) for x in out]
 names = ["0 regime+windows", "1 var setup (weights, nodes)", "2 X,Y,YPC1,select", "3 screen+queue+hval", "4 pass B", "5 pass C + stage tail"]
