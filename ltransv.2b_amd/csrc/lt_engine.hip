@@ -591,24 +591,12 @@ int sync_perm(lt_engine* e) {
   return LT_OK;
 }
 
-template <typename T>
-int permute_buf(lt_engine* e, DevBuf& b, int cols) {
-  if (!b.p) return LT_OK;
-  const int n = e->cfg.numpar;
-  const size_t bytes = (size_t)n * cols * sizeof(T);
-  hipLaunchKernelGGL((ltd::k_permute<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, (const T*)b.p,
-                     (T*)e->permute_tmp.p, (const int*)e->sort_idx_out.p, n, cols);
-  HIPCHK(e, hipMemcpyAsync(b.p, e->permute_tmp.p, bytes, hipMemcpyDeviceToDevice, e->stream));
-  return LT_OK;
-}
-
 int resort(lt_engine* e) {
   const int n = e->cfg.numpar;
   if (n <= 1 || !e->pr.p) return LT_OK;
   TRY(dev_alloc(e, e->sort_keys, (size_t)n * 4));
   TRY(dev_alloc(e, e->sort_idx_in, (size_t)n * 4));
   TRY(dev_alloc(e, e->sort_idx_out, (size_t)n * 4));
-  TRY(dev_alloc(e, e->permute_tmp, (size_t)n * 13 * 8));
   TRY(dev_alloc(e, e->sort_keys_in, (size_t)n * 4));
   const int bits = e->tile_key_bits;
   if (!e->resort_ev[0]) {
@@ -627,14 +615,35 @@ int resort(lt_engine* e) {
   HIPCHK(e, hipcub::DeviceRadixSort::SortPairs(e->sort_tmp.p, tmp_bytes, (const int*)e->sort_keys_in.p, (int*)e->sort_keys.p,
                                                (const int*)e->sort_idx_in.p, (int*)e->sort_idx_out.p, n, 0, bits,
                                                e->stream));
-  TRY(permute_buf<double>(e, e->par, 13));
-  for (DevBuf* b : {&e->pr, &e->pu, &e->pv, &e->P_behave, &e->dead, &e->oob, &e->settle, &e->endpoly, &e->hitBottom,
-                    &e->hitLand, &e->err_code, &e->bottom, &e->orig})
-    TRY(permute_buf<int32_t>(e, *b, 1));
-  TRY(permute_buf<double>(e, e->P_swim, 3));
-  for (DevBuf* b : {&e->P_pediage, &e->P_deadage, &e->settletime, &e->timer, &e->P_Sprev, &e->P_zprev, &e->P_Salt,
-                    &e->P_Temp})
-    TRY(permute_buf<double>(e, *b, 1));
+  {
+    // every per-particle array through the sorted index, in one launch into one staging buffer, and back in another
+    ltd::PermList L;
+    L.nd = 0;
+    size_t total = 0;
+    auto add = [&](DevBuf& b, int elem, int cols) {
+      if (!b.p || L.nd >= LT_PERM_MAX) return;
+      L.d[L.nd].src = b.p; L.d[L.nd].dst = nullptr; L.d[L.nd].elem = elem; L.d[L.nd].cols = cols;
+      total += (((size_t)n * elem * cols) + 255) & ~(size_t)255;
+      L.nd++;
+    };
+    add(e->par, 8, 13);
+    for (DevBuf* b : {&e->pr, &e->pu, &e->pv, &e->P_behave, &e->dead, &e->oob, &e->settle, &e->endpoly, &e->hitBottom,
+                      &e->hitLand, &e->err_code, &e->bottom, &e->orig})
+      add(*b, 4, 1);
+    add(e->P_swim, 8, 3);
+    for (DevBuf* b : {&e->P_pediage, &e->P_deadage, &e->settletime, &e->timer, &e->P_Sprev, &e->P_zprev, &e->P_Salt,
+                      &e->P_Temp})
+      add(*b, 8, 1);
+    TRY(dev_alloc(e, e->permute_tmp, total + 256));
+    size_t off = 0;
+    for (int k = 0; k < L.nd; k++) {
+      L.d[k].dst = (char*)e->permute_tmp.p + off;
+      off += (((size_t)n * L.d[k].elem * L.d[k].cols) + 255) & ~(size_t)255;
+    }
+    const unsigned pb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(ltd::k_permute_multi, dim3(pb), dim3(256), 0, e->stream, L, (const int*)e->sort_idx_out.p, n);
+    hipLaunchKernelGGL(ltd::k_copy_back_multi, dim3(pb), dim3(256), 0, e->stream, L, n);
+  }
   // "this particle's stored elements are verified" is per slot: verify again
   if (e->ele_ok.p) HIPCHK(e, hipMemsetAsync(e->ele_ok.p, 0, e->ele_ok.bytes, e->stream));
   HIPCHK(e, hipGetLastError());

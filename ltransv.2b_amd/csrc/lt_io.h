@@ -167,6 +167,41 @@ __global__ void k_permute(const T* __restrict__ src, T* __restrict__ dst, const 
 }
 // the inverse, for handing an array out in the reference's particle order: dst[c*n + orig[i]] = src[c*n + i]
 // (orig[i] = reference index of internal slot i)
+// every per-particle array of the engine through the same index in ONE launch (the re-sort: 23 arrays were 23
+// launches of k_permute and 23 copies back), into one staging buffer; k_copy_back_multi returns them.
+#define LT_PERM_MAX 32
+struct PermDesc { const void* src; void* dst; int elem, cols; };   // elem: 4 or 8 bytes
+struct PermList { int nd; PermDesc d[LT_PERM_MAX]; };
+__global__ __launch_bounds__(256) void k_permute_multi(const PermList L, const int* __restrict__ idx, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int j = idx[i];
+  for (int k = 0; k < L.nd; k++) {
+    const PermDesc D = L.d[k];
+    if (D.elem == 8) {
+      const double* s = (const double*)D.src; double* t = (double*)D.dst;
+      for (int c = 0; c < D.cols; c++) t[(size_t)c * n + i] = s[(size_t)c * n + j];
+    } else {
+      const int* s = (const int*)D.src; int* t = (int*)D.dst;
+      for (int c = 0; c < D.cols; c++) t[(size_t)c * n + i] = s[(size_t)c * n + j];
+    }
+  }
+}
+// (dst of the list -> src of the list, element for element)
+__global__ __launch_bounds__(256) void k_copy_back_multi(const PermList L, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int k = 0; k < L.nd; k++) {
+    const PermDesc D = L.d[k];
+    if (D.elem == 8) {
+      double* s = (double*)D.src; const double* t = (const double*)D.dst;
+      for (int c = 0; c < D.cols; c++) s[(size_t)c * n + i] = t[(size_t)c * n + i];
+    } else {
+      int* s = (int*)D.src; const int* t = (const int*)D.dst;
+      for (int c = 0; c < D.cols; c++) s[(size_t)c * n + i] = t[(size_t)c * n + i];
+    }
+  }
+}
 template <typename T>
 __global__ void k_unpermute(const T* __restrict__ src, T* __restrict__ dst, const int* __restrict__ orig, int n,
                             int cols) {
