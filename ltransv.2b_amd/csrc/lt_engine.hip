@@ -620,8 +620,10 @@ int resort(lt_engine* e) {
     ltd::PermList L;
     L.nd = 0;
     size_t total = 0;
+    bool overflow = false;
     auto add = [&](DevBuf& b, int elem, int cols) {
-      if (!b.p || L.nd >= LT_PERM_MAX) return;
+      if (!b.p) return;
+      if (L.nd >= LT_PERM_MAX) { overflow = true; return; }
       L.d[L.nd].src = b.p; L.d[L.nd].dst = nullptr; L.d[L.nd].elem = elem; L.d[L.nd].cols = cols;
       total += (((size_t)n * elem * cols) + 255) & ~(size_t)255;
       L.nd++;
@@ -634,6 +636,7 @@ int resort(lt_engine* e) {
     for (DevBuf* b : {&e->P_pediage, &e->P_deadage, &e->settletime, &e->timer, &e->P_Sprev, &e->P_zprev, &e->P_Salt,
                       &e->P_Temp})
       add(*b, 8, 1);
+    if (overflow) return fail(e, LT_ERR_STATE, "resort: more per-particle arrays than LT_PERM_MAX");
     TRY(dev_alloc(e, e->permute_tmp, total + 256));
     size_t off = 0;
     for (int k = 0; k < L.nd; k++) {
