@@ -333,6 +333,17 @@ int lt_set_rng_window_static(lt_engine *e, int64_t active_before, int64_t active
 int lt_count_draws(lt_engine *e, const double *ex3, const double *ix3, int32_t p, int32_t it,
                    int64_t *n_draws);
 int lt_set_rng_window_draws(lt_engine *e, int64_t draws_before, int64_t draws_total);
+/* The per-step exchange itself ("one tiny all-gather of per-GPU counts per step before the turbulence
+ * stage when any particle can be inactive"; the skip rule is LTRANS.f90:790-816, the one serial stream
+ * random_module.f90:166-197), for a host with no other communication library: runs the first part of the coming
+ * step on the device as lt_count_draws does, all-gathers the shards' draw totals -- one int64 per rank,
+ * ncclAllGather on the communicator of lt_comm_init, device to device -- and places this shard behind the draws of
+ * the lower ranks; the following lt_step with the SAME arguments continues from there.  Works for every
+ * configuration that draws (turbulence, behaviours 1-5, settlement / mortality / open boundary / late releases),
+ * ends a static window, and without a communicator is the single engine's own window.  Every rank of the
+ * communicator must make the call for every step.  One host read per call (the G counts: the host places the
+ * generators of the step's random words with them); under lt_set_rng_window_static there is none and no call. */
+int lt_exchange_rng_window(lt_engine *e, const double *ex3, const double *ix3, int32_t p, int32_t it);
 
 /* the hot path ---------------------------------------------------------- */
 /* = update_particles() with main's ex(3), ix(3), p, it (LTRANS.f90:568-571,

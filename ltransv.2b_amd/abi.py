@@ -182,4 +182,5 @@ ENTRY_POINTS = [
 ]
 HIP_ONLY_ENTRY_POINTS = ["last_error", "abi_version", "source_hash", "set_rng_window_static", "pack_positions", "stream",
                          "phase_timing", "get_phase_times", "create_bounds", "comm_unique_id", "comm_init", "comm_init_file", "allgather_positions", "comm_destroy",
+                         "exchange_rng_window",
                          "profile_begin", "profile_end", "get_counters"]

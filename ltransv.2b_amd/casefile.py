@@ -7,17 +7,21 @@ updateHydro) are handed to the Fortran harness in one stream file, in the fixed
 order the harness reads them (all little-endian, Fortran column-major)."""
 import numpy as np
 
-MAGIC = 1280590641  # 'LTC1'
+MAGIC = 1280590641   # 'LTC1'
+MAGIC2 = 1280590642  # 'LTC2': + the habitat polygons of initSettlement (settlement_module.f90:98-240)
 
 
 def _f(a, dtype):
     return np.ascontiguousarray(np.asarray(a, dtype=dtype).ravel(order="F")).tobytes()
 
 
-def write_case(path, g, geo, bounds, parts, records, numpar):
-    """records: list of dicts(zeta, Uvel, Vvel, Wvel, Kh) -- history records 0..n-1."""
+def write_case(path, g, geo, bounds, parts, records, numpar, habitat=None):
+    """records: list of dicts(zeta, Uvel, Vvel, Wvel, Kh) -- history records 0..n-1.
+    habitat: the edge-point tables of the settlement polygons (polys(pedges,5), holes(hedges,6), the id ranges,
+    maxbdis, maxhdis: what initSettlement reads from the habitat files); the harness builds the lists itself
+    (lt_create_polyspecs = createPolySpecs)."""
     us, ws = g["us"], g["ws"]
-    hdr = np.array([MAGIC, g["vi"], g["uj"], us, ws, geo["rho_nodes"], geo["u_nodes"], geo["v_nodes"],
+    hdr = np.array([MAGIC if habitat is None else MAGIC2, g["vi"], g["uj"], us, ws, geo["rho_nodes"], geo["u_nodes"], geo["v_nodes"],
                     geo["rho_elements"], geo["u_elements"], geo["v_elements"], bounds["nbounds"],
                     bounds["maxbound"], bounds["maxisland"], bounds["numislands"], numpar,
                     len(records)], dtype=np.int32)
@@ -41,6 +45,18 @@ def write_case(path, g, geo, bounds, parts, records, numpar):
         fh.write(_f(parts["par"], np.float64))
         for k in ("P_r_element", "P_u_element", "P_v_element"):
             fh.write(_f(parts[k], np.int32))
+        if habitat is not None:
+            h = habitat
+            npoly = h["maxpolyid"] - h["minpolyid"] + 1
+            nhole = (h["maxholeid"] - h["minholeid"] + 1) if h["hedges"] > 0 else 0
+            fh.write(np.array([h["pedges"], h["hedges"], h["minpolyid"], h["maxpolyid"], h["minholeid"], h["maxholeid"]],
+                              dtype=np.int32).tobytes())
+            fh.write(_f(np.asarray(h["polys"]).reshape(h["pedges"], 5, order="F"), np.float64))
+            if h["hedges"] > 0:
+                fh.write(_f(np.asarray(h["holes"]).reshape(h["hedges"], 6, order="F"), np.float64))
+            fh.write(_f(np.asarray(h["maxbdis"])[:npoly], np.float64))
+            if nhole > 0:
+                fh.write(_f(np.asarray(h["maxhdis"])[:nhole], np.float64))
         for r in records:
             kh = r.get("Kh")
             if kh is None:
@@ -73,8 +89,9 @@ def _l(v):
     return ".TRUE." if v else ".FALSE."
 
 
-def write_ltrans_data(path, cfg, days=1.0, tdim=8, iprint=None, model_timing=False):
+def write_ltrans_data(path, cfg, days=1.0, tdim=8, iprint=None, model_timing=False, habitat=None):
     """A run file in the LTRANS.data syntax with the groups the path reads."""
+    hb = habitat or dict(minpolyid=101001, maxpolyid=101004, minholeid=100201, maxholeid=100401, pedges=1, hedges=1)
     txt = f"""! written by ltrans_amd.casefile.write_ltrans_data (LTRANS.data syntax)
 $numparticles
   numpar = {cfg.numpar}          ! Number of particles
@@ -139,12 +156,12 @@ $end
 $settleparam
  settlementon = {_l(cfg.settlementon)}
  holesExist = {_l(cfg.holesExist)}
- minpolyid  = 101001
- maxpolyid  = 101004
- minholeid  = 100201
- maxholeid  = 100401
- pedges     = 1
- hedges     = 1
+ minpolyid  = {hb["minpolyid"]}
+ maxpolyid  = {hb["maxpolyid"]}
+ minholeid  = {hb["minholeid"]}
+ maxholeid  = {hb["maxholeid"]}
+ pedges     = {hb["pedges"]}
+ hedges     = {hb["hedges"]}
 $end
 $convparam
   PI = {cfg.PI!r}

@@ -82,6 +82,7 @@ struct lt_engine {
   // a few host threads move each array on to the caller's (pageable) memory while the next one arrives
   void* get_pin = nullptr;
   size_t get_pin_bytes = 0;
+  bool get_use_pin = false;   // this download goes through get_pin (decided by get_fields_begin)
   struct GetItem { const void* src; void* dst; size_t bytes; };
   std::vector<GetItem> get_items;
   std::vector<hipEvent_t> get_ev;
@@ -116,6 +117,12 @@ struct lt_engine {
   hipStream_t comm_stream = nullptr;   // the collective runs beside the next step
   hipEvent_t comm_packed = nullptr, comm_done = nullptr;
   bool comm_busy = false;              // comm_done has been recorded
+  // lt_exchange_rng_window: the shards' draw counts of the coming step, all-gathered on the communicator's stream
+  DevBuf cnt_dev;                      // [0] this shard's draws (int64), [8 ..] the G gathered counts
+  long long* h_cnt = nullptr;          // pinned: the gathered counts as the host reads them (one read for all ranks)
+  int h_cnt_cap = 0;
+  hipEvent_t cnt_ready = nullptr;      // the prefix sum of the coming step has run (engine's stream)
+  bool pre_defer_read = false;         // step_prepare leaves the shard's draw total on the device (the exchange reads it)
   bool rng_static = false;  // lt_set_rng_window_static: the window holds until it is set again
   int64_t rng_static_before = 0, rng_static_total = -1;
   int64_t rng_static_own = -1;     // the shard's draws per step under the static window, read back ONCE (the first
@@ -149,6 +156,7 @@ struct lt_engine {
   unsigned long long* h_miss = nullptr;
   hipEvent_t miss_ev = nullptr;
   bool miss_inflight = false;
+  bool miss_reported = false;      // a broken static window has been reported to the caller (by any call)
   bool quiet_window_switch = false;
   // optional HIP-event timing of the step kernel (lt_profile_*)
   bool prof_on = false;
@@ -486,7 +494,8 @@ int get_fields_begin(lt_engine* e, size_t total_bytes) {
   TRY(dev_alloc(e, e->get_stage, total_bytes + 256));
   e->get_stage_used = 0;
   e->get_items.clear();
-  if (e->get_pin_bytes < total_bytes + 256 && !getenv("LT_GET_NOPIN")) {
+  const bool nopin = getenv("LT_GET_NOPIN") != nullptr;
+  if (e->get_pin_bytes < total_bytes + 256 && !nopin) {
     if (e->get_pin) (void)hipHostFree(e->get_pin);
     e->get_pin = nullptr; e->get_pin_bytes = 0;
     // (kept for the next download; without it -- no pinned memory to be had -- the copies go to the caller's
@@ -494,6 +503,9 @@ int get_fields_begin(lt_engine* e, size_t total_bytes) {
     if (hipHostMalloc(&e->get_pin, total_bytes + 256, hipHostMallocDefault) == hipSuccess) e->get_pin_bytes = total_bytes + 256;
     else { e->get_pin = nullptr; (void)hipGetLastError(); }
   }
+  // decided once per download: the pinned path only with a buffer that holds ALL of it (a buffer left by a smaller
+  // download stays where it is when LT_GET_NOPIN is set afterwards -- and is not written to)
+  e->get_use_pin = !nopin && e->get_pin && e->get_pin_bytes >= total_bytes + 256;
   return LT_OK;
 }
 template <typename T>
@@ -508,7 +520,7 @@ int get_field(lt_engine* e, const DevBuf& buf, T* dst, int cols) {
   e->get_stage_used += (bytes + 255) & ~(size_t)255;
   hipLaunchKernelGGL((ltd::k_unpermute<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, (const T*)buf.p, stage,
                      (const int*)e->orig.p, (int)n, cols);
-  if (!e->get_pin) {
+  if (!e->get_use_pin) {
     HIPCHK(e, hipMemcpyAsync(dst, stage, bytes, hipMemcpyDeviceToHost, e->stream));
     return LT_OK;
   }
@@ -535,7 +547,10 @@ int get_fields_end(lt_engine* e) {
     // worker t copies the t-th slice of every array, as soon as the array has arrived
     unsigned hw = std::thread::hardware_concurrency();
     int nt = (int)std::max(1u, std::min(8u, hw ? hw : 1u));
-    if (getenv("LT_GET_THREADS")) nt = std::max(1, atoi(getenv("LT_GET_THREADS")));
+    if (getenv("LT_GET_THREADS")) nt = std::min(32, std::max(1, atoi(getenv("LT_GET_THREADS"))));
+    size_t total = 0;
+    for (const auto& it : e->get_items) total += it.bytes;
+    if (total < ((size_t)8 << 20)) nt = 1;   // (a small download -- the salinity / temperature columns -- is not worth a thread)
     std::atomic<size_t> ready{0};
     std::atomic<bool> abort_{false};
     auto work = [&](int t) {
@@ -550,8 +565,14 @@ int get_fields_end(lt_engine* e) {
         if (b > a) memcpy((char*)it.dst + a, (const char*)it.src + a, b - a);
       }
     };
+    // (no exception may cross the C ABI: a thread that cannot be started -- EAGAIN under a process / thread limit --
+    // leaves its slices, and those of the ones after it, to this thread; the workers started so far keep theirs)
     std::vector<std::thread> th;
-    for (int t = 1; t < nt; t++) th.emplace_back(work, t);
+    int started = 1;
+    try {
+      th.reserve((size_t)nt);
+      for (int t = 1; t < nt; t++) { th.emplace_back(work, t); started = t + 1; }
+    } catch (...) { }
     hipError_t err = hipSuccess;
     for (size_t k = 0; k < ni && err == hipSuccess; k++) {
       const double t0 = now();
@@ -562,6 +583,8 @@ int get_fields_end(lt_engine* e) {
         const lt_engine::GetItem& it = e->get_items[k];   // (this thread takes slice 0 of the array that has just arrived)
         const size_t per = ((it.bytes + nt - 1) / nt + 63) & ~(size_t)63;
         memcpy(it.dst, it.src, std::min(it.bytes, per));
+        const size_t a = std::min(it.bytes, per * (size_t)started);   // the slices of workers that could not be started
+        if (it.bytes > a) memcpy((char*)it.dst + a, (const char*)it.src + a, it.bytes - a);
       }
       t_wait += t1 - t0; t_copy += now() - t1;
     }
@@ -1096,8 +1119,10 @@ int lt_destroy(lt_engine* e) {
     if (e->pin_free[i]) (void)hipEventDestroy(e->pin_free[i]);
   }
   if (e->comm) (void)lt_comm_destroy(e);
-  for (DevBuf* b : {&e->comm_send, &e->comm_recv, &e->comm_out, &e->comm_counts})
+  for (DevBuf* b : {&e->comm_send, &e->comm_recv, &e->comm_out, &e->comm_counts, &e->cnt_dev})
     if (b->p) (void)hipFree(b->p);
+  if (e->h_cnt) (void)hipHostFree(e->h_cnt);
+  if (e->cnt_ready) (void)hipEventDestroy(e->cnt_ready);
   if (e->prefetch_done) (void)hipEventDestroy(e->prefetch_done);
   if (e->compute_mark) (void)hipEventDestroy(e->compute_mark);
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
@@ -1543,6 +1568,18 @@ int lt_set_particles(lt_engine* e, const lt_particles* p) {
       TRY(dev_alloc(e, e->rank, (n + 1) * 4));
     }
     if (e->cfg.VTurbOn) {
+      {
+        // VTurb's working set per particle: 4*ws knots x (32-byte record + 26 bytes of SIGS task slots) + the
+        // idt/2 (+2) deviates + 8 bytes of walk list -- 7.7 KB at ws = 31, 12.3 KB at ws = 51.  Said
+        // here, with the figures, rather than by whichever hipMalloc happens to fail.
+        const size_t per = (size_t)4 * e->cfg.ws * (32 + 26) + (size_t)(std::max(e->cfg.idt / 2, 1) + VT_DEV_HROWS) * 8 + 8;
+        const size_t want = per * ((n + 63) / 64 * 64);
+        size_t mfree = 0, mtotal = 0;
+        if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess && want > mfree)
+          return fail(e, LT_ERR_NOMEM, "lt_set_particles: vertical turbulence needs %.1f GB for %zu particles at ws = %d "
+                      "(%zu bytes each: spline table, SIGS task lists, deviates) and %.1f GB are free on device %d: shard the "
+                      "particles over more engines", want / 1e9, n, (int)e->cfg.ws, per, mfree / 1e9, e->device);
+      }
       // p2 = 4*ws knots per particle, [wave][knot][lane] records {x, y, yp, sigma}
       TRY(dev_alloc(e, e->vt_tab, (size_t)4 * e->cfg.ws * ((n + 63) / 64 * 64) * 32));
       // task lists of the SIGS iterations
@@ -1606,12 +1643,23 @@ static int fetch_counters(lt_engine* e);
 static int check_static_miss_async(lt_engine* e) {
   if (!e->rng_static) return LT_OK;
   if (!e->h_miss) {
-    if (hipHostMalloc((void**)&e->h_miss, sizeof(unsigned long long)) != hipSuccess) return LT_ERR_NOMEM;
-    *e->h_miss = 0ull;
-    if (hipEventCreateWithFlags(&e->miss_ev, hipEventDisableTiming) != hipSuccess) return LT_ERR_DEVICE;
+    // (the event first: h_miss is only published together with an event that can be recorded)
+    if (!e->miss_ev && hipEventCreateWithFlags(&e->miss_ev, hipEventDisableTiming) != hipSuccess) {
+      e->miss_ev = nullptr;
+      return fail(e, LT_ERR_DEVICE, "hipEventCreate failed (static-window check)");
+    }
+    unsigned long long* hm = nullptr;
+    if (hipHostMalloc((void**)&hm, sizeof(unsigned long long)) != hipSuccess) return fail(e, LT_ERR_NOMEM, "pinned word (static-window check)");
+    *hm = 0ull;
+    e->h_miss = hm;
   }
   if (e->miss_inflight && hipEventQuery(e->miss_ev) == hipSuccess) {
     e->miss_inflight = false;
+    if (*e->h_miss) {
+      // said here: the lt_set_rng_window that ends the window does not say it a second time
+      if (e->h_counters) e->h_counters[CNT_STATIC_MISS] = *e->h_miss;
+      e->miss_reported = true;
+    }
     if (*e->h_miss)
       return fail(e, LT_ERR_STATE, "static random-stream window: the shard's draws changed (%llu step(s)); a particle "
                                    "stopped or started drawing -- set the window before each step instead", *e->h_miss);
@@ -2257,19 +2305,25 @@ int lt_count_active(lt_engine* e, const double* ix3, int64_t* n_active) {
   return LT_OK;
 }
 
+static int end_static_window(lt_engine* e);
 int lt_set_rng_window(lt_engine* e, int64_t active_before, int64_t active_total) {
   if (!e || active_before < 0 || active_total < active_before) return LT_ERR_ARG;
   if (e->cfg.Behavior >= 1 && e->cfg.Behavior <= 5)
     return fail(e, LT_ERR_ARG, "behaviours 1-5 draw a data-dependent number of deviates: use "
                                "lt_count_draws / lt_set_rng_window_draws");
+  HIPCHK(e, hipSetDevice(e->device));
   const int64_t D = (e->cfg.HTurbOn ? 4 : 0) + (e->cfg.VTurbOn ? 2 * (e->cfg.idt / 2) : 0);
   e->rng_before = active_before * D;
   e->rng_total = active_total * D;
-  // A static window ends here.  Whether it held is read from the device NOW (nobody may have asked yet), the word
-  // is cleared -- a window set anew: the report is spent -- and the switch is made; a window that did not hold is
-  // this call's error, once.
+  return end_static_window(e);
+}
+
+// A static window ends (a window is set anew, or the per-step exchange takes over).  Whether it held is read from the
+// device NOW (nobody may have asked yet), the word is cleared -- a window set anew: the report is spent -- and the
+// switch is made; a window that did not hold is this call's error, once.
+static int end_static_window(lt_engine* e) {
   unsigned long long missed = 0;
-  const bool reported = e->h_counters && e->h_counters[CNT_STATIC_MISS] != 0;  // (an earlier call has said so already)
+  const bool reported = e->miss_reported || (e->h_counters && e->h_counters[CNT_STATIC_MISS] != 0);  // (an earlier call has said so already)
   if (e->rng_static && !reported) {
     HIPCHK(e, hipMemcpyAsync(e->h_counters + CNT_STATIC_MISS, (unsigned long long*)e->counters.p + CNT_STATIC_MISS,
                              sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
@@ -2278,6 +2332,7 @@ int lt_set_rng_window(lt_engine* e, int64_t active_before, int64_t active_total)
   e->rng_static = false;
   e->rng_static_own = -1;
   e->miss_inflight = false;
+  e->miss_reported = false;
   if (e->h_counters && e->h_counters[CNT_STATIC_MISS]) {
     missed = e->h_counters[CNT_STATIC_MISS];
     e->h_counters[CNT_STATIC_MISS] = 0;
@@ -2407,6 +2462,10 @@ static int step_prepare(lt_engine* e, const double* ex3, const double* ix3, int3
         e->pre_own = e->rng_static_own;
         P.expect_own = (long long)e->rng_static_own;
         e->pre_synced = false;
+      } else if (e->pre_defer_read) {
+        // lt_exchange_rng_window: the total travels to the host together with the other shards' (one read)
+        e->pre_own = -1;
+        e->pre_synced = false;
       } else {
         int own = 0;
         HIPCHK(e, hipMemcpyAsync(&own, (int*)e->rank.p + n, 4, hipMemcpyDeviceToHost, e->stream));
@@ -2460,6 +2519,7 @@ int lt_step(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32
     const bool f32 = e->cfg.slab_storage == LT_SLAB_F32;
     if (draws) {
       const int64_t own = e->pre_own;
+      if (own < 0) return fail(e, LT_ERR_STATE, "lt_step: the preceding lt_exchange_rng_window did not complete");
       const int64_t before = (e->rng_total >= 0) ? e->rng_before : 0;
       const int64_t total = (e->rng_total >= 0) ? e->rng_total : own;
       if (before + own > total) return fail(e, LT_ERR_ARG, "lt_set_rng_window: window smaller than the shard's draws");
@@ -2523,6 +2583,7 @@ static int fetch_counters(lt_engine* e) {
     HIPCHK(e, hipStreamSynchronize(e->stream));
     e->counters_fetched = true;
   }
+  if (e->h_counters[CNT_STATIC_MISS]) e->miss_reported = true;
   if (e->h_counters[CNT_STATIC_MISS])   // (reported by every call until a window is set again)
     return fail(e, LT_ERR_STATE, "static random-stream window: the shard's draws changed (%llu step(s)); a particle "
                                  "stopped or started drawing -- set the window before each step instead",
@@ -2786,6 +2847,15 @@ namespace {
 // wait for it, so the next lt_step runs beside the transfer, and only the next pack (which overwrites the send
 // buffer) waits for the previous collective.
 struct AgPlan { int G = 0; long long nmax = 0, total = 0; double* out = nullptr; };
+// every collective of the engine's communicator runs on ONE stream of its own, ordered against the engine's by events
+int ensure_comm_stream(lt_engine* e) {
+  if (!e->comm_stream) {
+    HIPCHK(e, hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
+    HIPCHK(e, hipEventCreateWithFlags(&e->comm_packed, hipEventDisableTiming));
+    HIPCHK(e, hipEventCreateWithFlags(&e->comm_done, hipEventDisableTiming));
+  }
+  return LT_OK;
+}
 int ag_pack(lt_engine* e, int G, int rank, const int32_t* counts, void* xyz_device, AgPlan& A) {
   if (counts[rank] != e->cfg.numpar) return fail(e, LT_ERR_ARG, "lt_allgather_positions: counts(rank+1) /= numpar of this engine");
   A.G = G;
@@ -2797,11 +2867,7 @@ int ag_pack(lt_engine* e, int G, int rank, const int32_t* counts, void* xyz_devi
   }
   A.total = offs[G];
   if (A.total == 0) return LT_OK;
-  if (!e->comm_stream) {
-    HIPCHK(e, hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
-    HIPCHK(e, hipEventCreateWithFlags(&e->comm_packed, hipEventDisableTiming));
-    HIPCHK(e, hipEventCreateWithFlags(&e->comm_done, hipEventDisableTiming));
-  }
+  TRY(ensure_comm_stream(e));
   // the buffers of the collective before this one are free once it has finished (also before they are re-allocated)
   if (e->comm_busy) HIPCHK(e, hipStreamWaitEvent(e->stream, e->comm_done, 0));
   const size_t blk = (size_t)3 * (size_t)A.nmax * 8;
@@ -2863,6 +2929,97 @@ int lt_allgather_wait(lt_engine* e) {
   }
   return LT_OK;
 }
+
+/* ---- the per-step exchange of the shards' draw counts (SURVEY 8e's second collective) -------------------------
+ * LTRANS draws from ONE serial stream in particle order (random_module.f90:166-197) and a particle that is not
+ * tracked in a step draws nothing (LTRANS.f90:790-816), so a shard's place in the step's part of the stream is the
+ * number of draws of the lower-ranked shards -- which changes whenever a particle anywhere settles, dies, leaves
+ * or is released.  exchange_window: the first part of the coming step on the device (the gates, the element
+ * search, the behaviour pre-pass, the prefix sum of draws: what lt_count_draws runs), the shard's total as one
+ * int64 into the send word ON THE DEVICE, ncclAllGather of one int64 per rank on the communicator's stream behind
+ * an event, and ONE read of the G counts by the host -- which needs them to plan the generators of the step
+ * (rng_ensure) and which a non-static window costs a single engine as well (step_prepare's read of its own total:
+ * folded into this one).  `injected` (test build): what the collective would deliver for the other ranks. */
+namespace {
+__global__ void k_own_draws_i64(const int* __restrict__ scan_total, long long* __restrict__ cnt) { cnt[0] = (long long)scan_total[0]; }
+
+int exchange_window(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32_t it, int G, int rank,
+                    bool collective, const int64_t* injected) {
+  TRY(ready_to_step(e));
+  HIPCHK(e, hipSetDevice(e->device));
+  if (e->pre_valid && !pre_matches(e, ex3, ix3, p, it))
+    return fail(e, LT_ERR_STATE, "lt_exchange_rng_window: arguments differ from the preceding lt_count_draws");
+  if (e->rng_static) TRY(end_static_window(e));   // (the exchange takes over from a static window; a miss is reported here, once)
+  const bool draws = e->cfg.HTurbOn || e->cfg.VTurbOn || (e->cfg.Behavior >= 1 && e->cfg.Behavior <= 5);
+  if (!e->pre_valid) {
+    e->pre_defer_read = draws && e->cfg.numpar > 0;
+    const int rc = step_prepare(e, ex3, ix3, p, it);
+    e->pre_defer_read = false;
+    if (rc) return rc;
+  }
+  if (!draws) return LT_OK;                       // (nothing draws: there is no stream to place the shard in)
+  TRY(ensure_comm_stream(e));
+  if (!e->cnt_ready) HIPCHK(e, hipEventCreateWithFlags(&e->cnt_ready, hipEventDisableTiming));
+  if (e->cnt_dev.bytes < (size_t)(G + 1) * 8) {
+    if (e->comm_busy) HIPCHK(e, hipEventSynchronize(e->comm_done));
+    TRY(dev_alloc(e, e->cnt_dev, (size_t)(G + 1) * 8));
+  }
+  if (e->h_cnt_cap < G) {
+    if (e->h_cnt) (void)hipHostFree(e->h_cnt);
+    e->h_cnt = nullptr; e->h_cnt_cap = 0;
+    HIPCHK(e, hipHostMalloc((void**)&e->h_cnt, (size_t)G * 8, hipHostMallocDefault));
+    e->h_cnt_cap = G;
+  }
+  long long* cnt = (long long*)e->cnt_dev.p;
+  const int n = e->cfg.numpar;
+  if (n > 0) hipLaunchKernelGGL(k_own_draws_i64, dim3(1), dim3(1), 0, e->stream, (const int*)e->rank.p + n, cnt);
+  else HIPCHK(e, hipMemsetAsync(cnt, 0, 8, e->stream));          // (an empty shard draws nothing)
+  HIPCHK(e, hipGetLastError());
+  HIPCHK(e, hipEventRecord(e->cnt_ready, e->stream));
+  HIPCHK(e, hipStreamWaitEvent(e->comm_stream, e->cnt_ready, 0));
+  if (collective) {
+    RcclApi* R = rccl();
+    if (!R) return fail(e, LT_ERR_UNSUPPORTED, "librccl.so could not be opened");
+    const ncclResult_t rc = R->AllGather(cnt, cnt + 1, 1, ncclInt64, e->comm, e->comm_stream);
+    if (rc != ncclSuccess) return fail(e, LT_ERR_DEVICE, "ncclAllGather (draw counts): %s", R->GetErrorString ? R->GetErrorString(rc) : "error");
+  } else {
+    // one rank, or the test build standing in for the collective: the other ranks' counts as given, this rank's own
+    // from the device
+    if (injected && G > 1) HIPCHK(e, hipMemcpyAsync(cnt + 1, injected, (size_t)G * 8, hipMemcpyHostToDevice, e->comm_stream));
+    HIPCHK(e, hipMemcpyAsync(cnt + 1 + rank, cnt, 8, hipMemcpyDeviceToDevice, e->comm_stream));
+  }
+  HIPCHK(e, hipMemcpyAsync(e->h_cnt, cnt + 1, (size_t)G * 8, hipMemcpyDeviceToHost, e->comm_stream));
+  HIPCHK(e, hipStreamSynchronize(e->comm_stream));   // the one host read of the step (the scan has run: cnt_ready)
+  long long before = 0, total = 0;
+  for (int r = 0; r < G; r++) {
+    if (e->h_cnt[r] < 0) return fail(e, LT_ERR_STATE, "lt_exchange_rng_window: rank %d reports %lld draws", r, e->h_cnt[r]);
+    if (r < rank) before += e->h_cnt[r];
+    total += e->h_cnt[r];
+  }
+  e->pre_own = (int64_t)e->h_cnt[rank];
+  // (cnt_ready lies behind everything step_prepare enqueued, and behind the step before on the same stream)
+  e->pre_synced = true;
+  e->rng_before = before;
+  e->rng_total = total;
+  return LT_OK;
+}
+}  // namespace
+
+int lt_exchange_rng_window(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32_t it) {
+  if (!e || !ex3 || !ix3) return LT_ERR_ARG;
+  if (!e->comm) return exchange_window(e, ex3, ix3, p, it, 1, 0, false, nullptr);   // one engine: its own count
+  return exchange_window(e, ex3, ix3, p, it, e->comm_nranks, e->comm_rank, true, nullptr);
+}
+
+#ifdef LT_TEST_HOOKS
+/* Test aid: lt_exchange_rng_window as rank `rank` of `nranks` on ONE GPU -- counts(nranks) is what the collective
+ * would deliver (the entry of this rank is ignored: its count comes from the device, as in the real call). */
+int lt_test_exchange_rng_window(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32_t it, int32_t nranks,
+                                int32_t rank, const int64_t* counts) {
+  if (!e || !ex3 || !ix3 || !counts || nranks < 1 || rank < 0 || rank >= nranks) return LT_ERR_ARG;
+  return exchange_window(e, ex3, ix3, p, it, nranks, rank, false, counts);
+}
+#endif
 
 #ifdef LT_TEST_HOOKS
 /* Test aid (libltrans_hip_test.so only): the N-rank form of lt_allgather_positions on ONE GPU.  This engine is

@@ -390,6 +390,16 @@ class Engine:
         self._check(self._fn["set_rng_window_draws"](self._h, C.c_int64(int(draws_before)),
                                                      C.c_int64(int(draws_total))), "set_rng_window_draws")
 
+    def exchange_rng_window(self, ex, ix, p, it):
+        """lt_exchange_rng_window: the first part of the coming step, the all-gather of the shards' draw counts on
+        the engine's communicator (comm_init_file) and this shard's window; update_particles with the same
+        arguments continues from there."""
+        ex = _f8(ex, 3, "ex")
+        ix = _f8(ix, 3, "ix")
+        f = self.lib.lt_exchange_rng_window
+        f.restype = C.c_int
+        self._check(f(self._h, _dp(ex), _dp(ix), int(p), int(it)), "exchange_rng_window")
+
     def source_hash(self):
         f = self.lib.lt_source_hash
         f.restype = C.c_char_p

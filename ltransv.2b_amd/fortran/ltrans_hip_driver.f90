@@ -26,10 +26,12 @@
 ! serial random stream is one offset), the fields are replicated, and the only exchange is the all-gather of the
 ! new (x,y,z) that the reference needs as one array at print steps (LTRANS.f90:604-612): lt_comm_init_file /
 ! lt_allgather_positions, RCCL inside the library.  With turbulence the shards take static windows of the stream
-! (lt_set_rng_window_static), which holds while no particle can stop drawing; a run with settlement, mortality or
-! an open boundary needs the shards' counts exchanged before every step (lt_count_active + the host's own
-! collective), which this harness does not carry.  Every rank writes <out.bin>.rank<g> (its shard, then the
-! gathered xyz(N,3)); ErrorLog.txt / Timing.csv get the same suffix on ranks > 0.
+! (lt_set_rng_window_static) while no particle can stop or start drawing; a run with settlement, mortality, an
+! open boundary, behaviours 1-5 or particles released after the start exchanges the shards' draw counts before every
+! step instead (lt_exchange_rng_window: one int64 per rank over the same communicator, inside the library; the skip
+! rule is LTRANS.f90:790-816, the one serial stream random_module.f90:166-197).  Every rank writes
+! <out.bin>.rank<g> (its shard, then the gathered xyz(N,3)); ErrorLog.txt / Timing.csv get the same suffix on
+! ranks > 0.  A case file with habitat polygons (settlementon): createPolySpecs through lt_create_polyspecs.
 program ltrans_hip_driver
   use iso_c_binding
   use ltrans_hip
@@ -45,7 +47,11 @@ program ltrans_hip_driver
   double precision :: z0, constZeta, constSalt, constTemp, constU, constV, constW, constAks, constDens
   logical :: readZeta, readSalt, readTemp, readU, readV, readW, readAks, readDens
   logical :: HTurbOn, VTurbOn
-  logical :: late_release
+  logical :: late_release, dynamic_window
+  integer(c_int32_t) :: hab_hdr(6)
+  real(c_double), allocatable, target :: polys(:,:), holes(:,:), maxbdis(:), maxhdis(:)
+  type(lt_habitat) :: hab
+  integer :: npoly, nhole
   double precision :: ConstantHTurb
   integer :: Behavior
   logical :: OpenOceanBoundary, mortality
@@ -187,7 +193,7 @@ program ltrans_hip_driver
   open(2, file=trim(casefile), access='stream', form='unformatted', status='old', action='read')
   read(2) magic, vi, uj, c_us, c_ws, rho_nodes, u_nodes, v_nodes, rho_elements, u_elements, &
           v_elements, nbounds, maxbound, maxisland, numislands, c_numpar, nrec
-  if (magic /= 1280590641) stop 'not an LTC1 case file'
+  if (magic /= 1280590641 .and. magic /= 1280590642) stop 'not an LTC1 / LTC2 case file'
   if (c_us /= us .or. c_ws /= ws .or. c_numpar /= numpar) then
     write(*,*) 'case file does not match the namelists: us,ws,numpar =', c_us, c_ws, c_numpar
     stop 2
@@ -206,6 +212,22 @@ program ltrans_hip_driver
   read(2) bnd_x, bnd_y, land, bx, by
   if (maxisland > 0) read(2) hx(1:maxisland), hy(1:maxisland), hid(1:maxisland)
   read(2) par, P_r_element, P_u_element, P_v_element
+  if (magic == 1280590642) then
+    ! initSettlement's tables (settlement_module.f90:98-240): the polygons' and holes' edge points
+    read(2) hab_hdr
+    if (hab_hdr(1) /= pedges .or. hab_hdr(2) /= hedges .or. hab_hdr(3) /= minpolyid .or. hab_hdr(4) /= maxpolyid) &
+      stop 'case file habitat does not match $settleparam'
+    npoly = maxpolyid - minpolyid + 1
+    nhole = 0
+    if (hedges > 0) nhole = maxholeid - minholeid + 1
+    allocate(polys(pedges,5), holes(max(hedges,1),6), maxbdis(npoly), maxhdis(max(nhole,1)))
+    read(2) polys
+    if (hedges > 0) read(2) holes
+    read(2) maxbdis
+    if (nhole > 0) read(2) maxhdis(1:nhole)
+  else if (settlementon) then
+    stop 'settlementon needs a case file with habitat polygons (LTC2)'
+  endif
   allocate(zeta(rho_nodes), Uvel(u_nodes,us), Vvel(v_nodes,us), Wvel(rho_nodes,ws), Kh(rho_nodes,ws))
   ! (a particle of ANY rank that is released later -- LTRANS.f90:790: ix(3) <= par(n,pDOB) -> cycle, before any
   ! draw -- does not draw until then: the draw counts of the job change during the run)
@@ -228,12 +250,10 @@ program ltrans_hip_driver
     deallocate(par_g, er_g, eu_g, ev_g)
   endif
   ! A sharded run with turbulence sets each shard's window of the serial random stream ONCE (below:
-  ! lt_set_rng_window_static); that holds only while no particle of the job can start or stop drawing.  Checked
-  ! here, before anything is created: every rank reads the same case file and stops with the same message.
-  if (nranks > 1 .and. (HTurbOn .or. VTurbOn)) then
-    if (settlementon .or. mortality .or. OpenOceanBoundary .or. (Behavior >= 1 .and. Behavior <= 5) .or. late_release) &
-      error stop 'sharded run: the shards'' draw counts can change; exchange them before each step (lt_count_active)'
-  endif
+  ! lt_set_rng_window_static) while no particle of the job can start or stop drawing; otherwise the shards' draw counts
+  ! are exchanged before every step (lt_exchange_rng_window).  Decided here from the case file, which every rank reads.
+  dynamic_window = len_trim(commfile) > 0 .and. (HTurbOn .or. VTurbOn .or. (Behavior >= 1 .and. Behavior <= 5)) .and. &
+                   (settlementon .or. mortality .or. OpenOceanBoundary .or. (Behavior >= 1 .and. Behavior <= 5) .or. late_release)
 
   ! ---- initBehave (behavior_module.f90:94-160) / initSettlement state
   allocate(P_behave(numpar), dead(numpar), oob(numpar), settle(numpar), endpoly(numpar))
@@ -276,7 +296,7 @@ program ltrans_hip_driver
     call lt_check(lt_comm_init_file(eng, trim(commfile)//c_null_char, int(nranks, c_int32_t), &
                                     int(myrank, c_int32_t), 120_c_int32_t), eng, 'lt_comm_init_file')
   endif
-  if (nranks > 1 .and. (HTurbOn .or. VTurbOn)) then
+  if (nranks > 1 .and. (HTurbOn .or. VTurbOn) .and. .not. dynamic_window) then
     ! the shard's window of the serial stream: the tracked particles of the lower ranks come first
     call lt_check(lt_set_rng_window_static(eng, int(n0, c_int64_t), int(numpar_global, c_int64_t)), eng, &
                   'lt_set_rng_window_static')
@@ -296,6 +316,16 @@ program ltrans_hip_driver
   b%bnd_x = c_loc(bnd_x); b%bnd_y = c_loc(bnd_y); b%land = c_loc(land)
   b%bx = c_loc(bx); b%by = c_loc(by); b%hx = c_loc(hx); b%hy = c_loc(hy); b%hid = c_loc(hid)
   call lt_check(lt_set_bounds(eng, b), eng, 'lt_set_bounds')
+
+  if (settlementon) then
+    ! initSettlement -> createPolySpecs (settlement_module.f90:245-480) on the device
+    hab%pedges = pedges; hab%hedges = hedges; hab%minpolyid = minpolyid; hab%maxpolyid = maxpolyid
+    hab%minholeid = minholeid; hab%maxholeid = maxholeid
+    hab%polys = c_loc(polys); hab%holes = c_loc(holes); hab%maxbdis = c_loc(maxbdis); hab%maxhdis = c_loc(maxhdis)
+    hab%polyspecs = c_null_ptr; hab%holespecs = c_null_ptr; hab%elepolys_ptr = c_null_ptr; hab%elepolys_ids = c_null_ptr
+    hab%polyholes_ptr = c_null_ptr; hab%polyholes_ids = c_null_ptr
+    call lt_check(lt_create_polyspecs(eng, hab), eng, 'lt_create_polyspecs')
+  endif
 
   ! setEle_all (LTRANS.f90:410, hydrodynamic_module.f90:1536-1676) on the device; the case file's
   ! elements (located by the test's host code) are kept only to report the comparison
@@ -400,6 +430,9 @@ program ltrans_hip_driver
       ix(1) = ex(2) + DBLE((it-2)*idt)
       ix(2) = ex(2) + DBLE((it-1)*idt)
       ix(3) = ex(2) + DBLE(it*idt)
+      ! the shards' draw counts of this step, exchanged inside the library (a particle that settled, died, left or
+      ! has not been released draws nothing: LTRANS.f90:790-816), then the step itself
+      if (dynamic_window) call lt_check(lt_exchange_rng_window(eng, ex, ix, p, it), eng, 'lt_exchange_rng_window')
       call lt_check(lt_step(eng, ex, ix, p, it), eng, 'lt_step')   ! = call update_particles()
       call lt_check(lt_get_stats(eng, st), eng, 'lt_get_stats')
       total_errors = total_errors + st%errors

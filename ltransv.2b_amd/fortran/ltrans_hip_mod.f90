@@ -215,6 +215,15 @@ module ltrans_hip
       integer(c_int64_t), value :: draws_before, draws_total
       integer(c_int) :: rc
     end function
+    ! the per-step exchange of the shards' draw counts (one int64 per rank over the communicator of lt_comm_init_file)
+    ! and this shard's window of the serial random stream; the lt_step that follows takes the same ex, ix, p, it
+    function lt_exchange_rng_window(engine, ex, ix, p, it) bind(C, name="lt_exchange_rng_window") result(rc)
+      import :: c_int, c_int32_t, c_double, c_ptr
+      type(c_ptr), value :: engine
+      real(c_double), intent(in) :: ex(3), ix(3)
+      integer(c_int32_t), value :: p, it
+      integer(c_int) :: rc
+    end function
     function lt_set_rng_window(engine, active_before, active_total) &
         bind(C, name="lt_set_rng_window") result(rc)
       import :: c_int, c_int64_t, c_ptr

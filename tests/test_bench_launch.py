@@ -21,6 +21,15 @@ def _run(args, env_extra=None, timeout=600):
     return subprocess.run([sys.executable, BENCH] + args, env=env, capture_output=True, text=True, timeout=timeout)
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
 def _json_line(stdout):
     """the WHOLE standard output is one JSON line (library banners of any rank go to stderr: bench.claim_stdout)"""
     assert stdout.endswith("\n") and stdout.count("\n") == 1, stdout[:2000]
@@ -39,7 +48,7 @@ def test_under_torchrun_the_whole_stdout_is_one_json_line():
     launcher's stdout; gloo's "[Gloo] Rank r is connected ..." banner of every rank must not land in it."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29613", BENCH, "--gpus", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), BENCH, "--gpus", "2",
                         "--selftest-launch", "ok"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _json_line(r.stdout)
