@@ -47,7 +47,7 @@ sys.path.insert(0, ROOT)
 A_ADV_F32 = 96 + 256 + 48 + 576          # = 976 B
 A_ADV_F64 = 96 + 256 + 96 + 1152         # = 1600 B
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_ADV, PROFILE_TURB = "r04_adv", "r04_turb"   # profiles/<tag>/pmc.json of the default workloads
+PROFILE_ADV, PROFILE_TURB = "r05_adv", "r05_turb"   # profiles/<tag>/pmc.json of the default workloads
 
 WORKLOADS = {
     # name: (grid, total particles, turbulence, reflect/behaviour-6/settlement)
@@ -92,6 +92,9 @@ def parse(argv=None):
                     help="N > 1, strong scaling: skip rank 0's run of the WHOLE workload on one GPU afterwards")
     ap.add_argument("--single-ref-budget", type=float, default=150.0,
                     help="seconds after which rank 0's single-GPU reference run is skipped (keeps --gpus 8 within minutes)")
+    ap.add_argument("--sustained-steps", type=int, default=320,
+                    help="N = 1 main line: after the timed window, this many further steps of the SAME engine timed as one "
+                         "series with its re-sorts and slab rotations (through the pipeline) inside: config.sustained_* (0: off)")
     ap.add_argument("--cpu-sample", type=int, default=40000, help="particles of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-steps", type=int, default=30)
     ap.add_argument("--selftest-launch", choices=["ok", "fail"], default=None,
@@ -381,6 +384,36 @@ def timed_steps(st, nsteps, one_step, fence):
     fence()
     wall += time.perf_counter() - t0
     return wall, upload
+
+
+def sustained_series(e, run, st, one_step, fence, nsteps, make_rom, dims):
+    """`nsteps` steps of the engine as a host runs it for hours: nothing excluded.  The re-sorts of the particle order
+    (one in 32 steps, inside lt_step) and the slab rotations are inside the timed series, the rotations through the
+    pipeline (lt_slab_prefetch of the next record right after each lt_slab_commit, float32 host arrays as NetCDF
+    delivers a ROMS history file); only the synthesis of the records -- the stand-in for reading the file -- is done
+    before the clock starts.  -> (wall seconds, rotations, re-sorts)"""
+    stepIT = st.stepIT
+    n_rot = (st.it + nsteps - 1) // stepIT if st.it + nsteps > stepIT else 0
+    first = run.stepf                              # 0-based history record the next rotation installs
+    roms = {r: make_rom(r) for r in range(first, first + n_rot)}
+    run.rom_fn, run.dims, run._prefetched = (lambda r: roms[r]), dims, None
+    fence()
+    resorts0 = e.counters()["resorts"]
+    left_rot = n_rot
+    t0 = time.perf_counter()
+    if left_rot:
+        run.prefetch_next()
+    for _ in range(nsteps):
+        if st.needs_rotation():
+            st.rotate()                            # lt_slab_commit: the prefetched record becomes slot t_f
+            left_rot -= 1
+            if left_rot > 0:
+                run.prefetch_next()                # the next record's upload runs beside this external step's steps
+        one_step()
+    fence()
+    wall = time.perf_counter() - t0
+    run.rom_fn, run.dims, run._prefetched = None, None, None
+    return wall, n_rot - left_rot, e.counters()["resorts"] - resorts0
 
 
 def hydro_update_costs(e, run, rs, g, geo, turb, st, one_step, fence):
@@ -750,6 +783,29 @@ def main():
                                        valu),
         }
 
+        # flat copies of the figures a reader of the record needs (a record that keeps only scalar keys keeps these)
+        rf = out["roofline"]
+        out["config"].update({
+            "kernel_ms_avg": rf["kernel_ms_avg"], "roofline_frac": rf["frac"], "whole_step_frac": rf["whole_step"]["frac"],
+            "valu_issue_frac": (rf["valu_issue"] or {}).get("frac"),
+            "traffic_over_algorithmic": rf["traffic_over_algorithmic"],
+            # k_rk's workgroups go to the XCDs in chunks of this many (lt_rk_launch.h): an XCD's L2 then serves eight
+            # patches of the domain instead of one contiguous eighth -- +0.17 GB of HBM reads per launch (1.17x the
+            # algorithmic bytes instead of 0.95x) for an even load late in a run
+            "rk_xcd_chunk": 64})
+
+        if main_line and world == 1 and args.sustained_steps > 0 and not args.emulate_rank:
+            dims = (g["vi"], g["uj"], g["ui"], g["vj"])
+            w_s, rot_s, res_s = sustained_series(
+                e, run, st, one_step, fence, args.sustained_steps,
+                lambda r: rs.make_record(g, geo, r, with_kh=bool(spec["turb"]), drift=drift, with_st=needs_st, raw=np.float32), dims)
+            out["config"].update({
+                "sustained_steps": args.sustained_steps, "sustained_value": n * args.sustained_steps / w_s,
+                "sustained_ms_per_step": w_s / args.sustained_steps * 1e3,
+                "sustained_resorts_inside": res_s, "sustained_slab_rotations_inside": rot_s,
+                "sustained_note": "the same engine, right after the timed window: re-sorts and slab rotations (lt_slab_prefetch / "
+                                  "lt_slab_commit, float32 host arrays) inside the series; no clock pre-warm of its own"})
+
         if main_line and world == 1 and spec["name"] == "config2" and not args.no_turbulence_line:
             # BASELINE configs[2] in the same line: the same particles with HTurb + VTurb, same number of steps
             cfg_t = config_for(n, True)
@@ -791,6 +847,22 @@ def main():
                 "resorts_in_timed_region": cnt_t["resorts"] - rs0,
                 "create_to_first_step_s": first_step_s,
                 "roofline": roofline_block(args.slab, True, us + 1, n, kt_avg, wall_tb / args.steps, tr_t, src_t, valu_t)}
+            rft = out["config"]["turbulence"]["roofline"]
+            out["config"].update({
+                "turb_value": n * args.steps / wall_tb, "turb_ms_per_step": wall_tb / args.steps * 1e3,
+                "turb_vt_kernels_ms": rft["kernel_ms_avg"], "turb_roofline_frac": rft["frac"],
+                "turb_whole_step_frac": rft["whole_step"]["frac"],
+                "turb_valu_issue_frac": (rft["valu_issue"] or {}).get("frac"),
+                "turb_traffic_over_algorithmic": rft["traffic_over_algorithmic"]})
+            if args.sustained_steps > 0:
+                dims_t = (g["vi"], g["uj"], g["ui"], g["vj"])
+                ns_t = max(args.sustained_steps // 4, 1)         # (a turbulence step is 4-5x an advection step)
+                w_t, rot_t, res_t = sustained_series(
+                    e_t, run_t, st_t, step_t, fence_t, ns_t,
+                    lambda r: rs.make_record(g, geo, r, with_kh=True, drift=drift, with_st=needs_st, raw=np.float32), dims_t)
+                out["config"].update({"turb_sustained_steps": ns_t, "turb_sustained_value": n * ns_t / w_t,
+                                      "turb_sustained_ms_per_step": w_t / ns_t * 1e3,
+                                      "turb_sustained_resorts_inside": res_t, "turb_sustained_slab_rotations_inside": rot_t})
             e_t.close()
 
         if main_line and world == 1 and not args.no_hydro_timing:

@@ -457,6 +457,11 @@ int lt_get_counters(lt_engine *e, uint64_t *out8);
 /* device-side re-sorts of the particle order so far (one every resort_every steps inside lt_step) and the GPU
  * milliseconds of the last one (-1: none yet) */
 int lt_get_resort_stats(lt_engine *e, int64_t *resorts, double *last_ms);
+/* (host only, no device) the double-double 1/b = hl2[0] + hl2[1] the kernels multiply by instead of dividing by a
+ * divisor every particle shares (4*ws, 6, differences of the external times); returns 1, or 0 when b is not of the
+ * form for which that is exact for every numerator (the kernels then divide).  Exported so that the claim can be
+ * checked in exact arithmetic without a GPU (tests/test_host.py). */
+int lt_div_const(double b, double *hl2);
 
 #ifdef __cplusplus
 }

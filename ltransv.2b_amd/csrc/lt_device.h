@@ -103,9 +103,9 @@ struct StepParams {
   // ---- time
   double ex0, ex1, ex2, ix0, ix1, ix2;
   int p, it, idt;
-  // reciprocals of the divisors shared by all particles (div_by in lt_math.h):
+  // reciprocals (as double-doubles) of the divisors shared by all particles (div_by in lt_math.h):
   // ex(2)-ex(3), ex(1)-ex(2), ex(1)-ex(3), 4*ws, 6; fastdiv = 0 falls back to '/'
-  double r_d23, r_d12, r_d13, r_p2, r_6;
+  double c_d23[2], c_d12[2], c_d13[2], c_p2[2], c_6[2];
   int fastdiv;
   int pns0, pns1, pns2;  // polintd's closest time node (1..3) for ix(1), ix(2), ix(3)
   // ---- options
@@ -156,6 +156,10 @@ struct StepParams {
   // the walks that met an interval with a tension factor and are finished by k_vt_walk (lt_vturb.h):
   // their number, the particle slots, the sub-step each resumes at
   int *vt_wl_count, *vt_wl_list, *vt_wl_resume;
+  // k_vt_norm / k_vt_walk_fast may be launched piece by piece (particles [part_lo, part_hi), part_lo a multiple of
+  // 256) so that the deviates of one piece are formed beside the walks of the piece before; k_vt_walk takes
+  // vt_walk_lanes listed walks per wave (64, or fewer: the wave then executes fewer of the forms its walks need)
+  int part_lo, part_hi, vt_walk_lanes;
   // ---- per-step workspace exchanged between k_pre / k_rk / k_post
   unsigned char* ele_ok;  // [numpar] 1: the stored elements were found for the CURRENT position
                           //     by the setEle at the end of the previous step (LTRANS.f90:1317)

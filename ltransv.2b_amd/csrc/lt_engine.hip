@@ -123,6 +123,16 @@ struct lt_engine {
   int h_cnt_cap = 0;
   hipEvent_t cnt_ready = nullptr;      // the prefix sum of the coming step has run (engine's stream)
   bool pre_defer_read = false;         // step_prepare leaves the shard's draw total on the device (the exchange reads it)
+  // The host needs a step's draw totals to place the generators of the step's random words.  They travel to the host
+  // asynchronously (the shard's own: own_ev behind the prefix sum; the job's: cnt_arrived behind the all-gather) and
+  // whoever needs them first waits for them ONCE (resolve_own): lt_step before it enqueues the generators, lt_count_draws
+  // at once.
+  int* h_own = nullptr;                // pinned: the shard's draw total (rank[n]) of the coming step
+  hipEvent_t own_ev = nullptr;
+  bool own_pending = false;            // the copy into h_own has been enqueued, nobody has waited for it
+  hipEvent_t cnt_arrived = nullptr;    // comm_stream: the gathered counts are in h_cnt
+  bool xchg_pending = false;
+  int xchg_G = 1, xchg_rank = 0;
   bool rng_static = false;  // lt_set_rng_window_static: the window holds until it is set again
   int64_t rng_static_before = 0, rng_static_total = -1;
   int64_t rng_static_own = -1;     // the shard's draws per step under the static window, read back ONCE (the first
@@ -179,6 +189,12 @@ struct lt_engine {
   int64_t pre_own = 0;
   bool pre_synced = true;   // step_prepare waited for the device (everything earlier on `stream` has completed)
   double pre_sig[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // VTurb's kernels after the table (lt_vturb.h): k_vt_sigs on a stream of its own beside k_vt_norm / k_vt_walk_fast
+  // (vt_aside), and those two in vt_pieces pieces of the particles -- the deviates of piece k+1 beside the walks of
+  // piece k; k_vt_walk, behind all of them, takes vt_walk_lanes listed walks per wave
+  hipStream_t vt_stream[2] = {nullptr, nullptr};
+  hipEvent_t vt_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int vt_aside = 1, vt_pieces = 1, vt_walk_lanes = 64;
   hipStream_t rng_stream = nullptr;  // the MT19937 blocks of a step are generated beside k_rk
   hipEvent_t rng_done = nullptr;
   bool rng_pending = false, step_done_valid = false;
@@ -338,7 +354,8 @@ void fill_params(lt_engine* e, StepParams& P) {
   P.vt_q.wl = (unsigned short*)e->vt_qwl.p; P.vt_q.count = (int*)e->vt_qcount.p; P.vt_q.cap = e->vt_qcap;
   P.vt_wl_count = (int*)e->vt_wl.p;
   P.vt_wl_list = e->vt_wl.p ? (int*)e->vt_wl.p + 4 : nullptr;
-  P.vt_wl_resume = e->vt_wl.p ? (int*)e->vt_wl.p + 4 + e->cfg.numpar : nullptr;
+  P.vt_wl_resume = e->vt_wl.p ? (int*)e->vt_wl.p + 4 + 2 * (size_t)e->cfg.numpar : nullptr;
+  P.part_lo = 0; P.part_hi = c.numpar; P.vt_walk_lanes = e->vt_walk_lanes;
   P.ele_ok = (unsigned char*)e->ele_ok.p;
   P.FreeSlip = c.FreeSlip ? 1 : 0;
   P.fsR = (const unsigned char*)e->fsR.p; P.fsU = (const unsigned char*)e->fsU.p;
@@ -943,16 +960,65 @@ void wait_rng(lt_engine* e) {
   if (e->rng_pending) (void)hipStreamWaitEvent(e->stream, e->rng_done, 0);
   e->rng_pending = false;
 }
-void launch_vturb(lt_engine* e, const StepParams& P, unsigned blocks) {
+// VTurb after k_rk.  What depends on what: k_vt_sigs on the table; k_vt_norm on the step's random words only;
+// k_vt_walk_fast on the table and the deviates of ITS particles -- not on k_vt_sigs: a listed interval carries a
+// non-zero mark from the table kernel on (VT_SIG_PENDING) and a walk stops there --; k_vt_walk on all of them.
+// k_vt_sigs and the walks wait for their own chains of dependent operations and k_vt_norm is bound by its instruction
+// stream, so they are worth running beside each other; each is small in registers (38 .. 96), unlike k_rk and
+// k_vt_table, which fill the register file with two waves per SIMD and share it with nobody.
+// (in two parts: the head needs none of the step's random words and not the shard's place in the stream, so lt_step
+// can enqueue it before the host knows the step's draw totals)
+int launch_vturb_head(lt_engine* e, const StepParams& P, unsigned blocks) {
   // (k_vt_table, k_vt_norm and k_vt_walk_fast live in lt_rk_kernel.hip: lt_rk_launch.h)
   launch_k_vt_table(e->cfg.slab_storage == LT_SLAB_F32, e->cfg.Vtransform, P.fastdiv != 0, blocks, e->stream, P);
-  hipLaunchKernelGGL(k_vt_sigs, dim3(blocks), dim3(256), 0, e->stream, P);
+  const int pieces = std::max(1, std::min(e->vt_pieces, 4));
+  const bool forked = e->vt_aside || pieces > 1;
+  if (forked && !e->vt_stream[0]) {
+    for (auto& s : e->vt_stream) HIPCHK(e, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    for (auto& ev : e->vt_ev) HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  }
+  hipStream_t s_sigs = e->vt_aside ? e->vt_stream[0] : e->stream;
+  if (forked) HIPCHK(e, hipEventRecord(e->vt_ev[0], e->stream));            // the table is there
+  if (e->vt_aside) HIPCHK(e, hipStreamWaitEvent(s_sigs, e->vt_ev[0], 0));
+  hipLaunchKernelGGL(k_vt_sigs, dim3(blocks), dim3(256), 0, s_sigs, P);
+  if (e->vt_aside) HIPCHK(e, hipEventRecord(e->vt_ev[1], s_sigs));
+  return LT_OK;
+}
+int launch_vturb_tail(lt_engine* e, const StepParams& P, unsigned blocks) {
+  const int pieces = std::max(1, std::min(e->vt_pieces, 4));
   wait_rng(e);
-  launch_k_vt_norm(blocks, e->stream, P);
-  // the walks on zero-tension intervals; then, for the ones that met a tension factor, the rest of the walk
-  // (as many workgroups as could be needed: the ones beyond the list's end leave at once)
-  launch_k_vt_walk_fast(blocks, e->stream, P);
-  hipLaunchKernelGGL(k_vt_walk, dim3(blocks * (256 / LT_VT_WALK_BLOCK)), dim3(LT_VT_WALK_BLOCK), 0, e->stream, P);
+  if (pieces == 1) {
+    launch_k_vt_norm(blocks, e->stream, P);
+    launch_k_vt_walk_fast(blocks, e->stream, P);
+  } else {
+    // piece k: deviates, then walks, pieces alternating between the engine's stream and a second one; the deviates of
+    // piece k+1 start when those of piece k are done, i.e. beside piece k's walks
+    hipStream_t s2 = e->vt_stream[1];
+    HIPCHK(e, hipEventRecord(e->vt_ev[2], e->stream));                       // table + random words: what s2 waits for
+    HIPCHK(e, hipStreamWaitEvent(s2, e->vt_ev[2], 0));
+    const unsigned per = (blocks + (unsigned)pieces - 1) / (unsigned)pieces;
+    for (int k = 0; k < pieces; k++) {
+      const unsigned b0 = std::min(blocks, per * (unsigned)k), b1 = std::min(blocks, b0 + per);
+      if (b1 <= b0) break;
+      StepParams Q = P;
+      Q.part_lo = (int)(b0 * 256u);
+      Q.part_hi = std::min(P.numpar, (int)(b1 * 256u));
+      hipStream_t sk = (k & 1) ? s2 : e->stream;
+      if (k > 0) HIPCHK(e, hipStreamWaitEvent(sk, e->vt_ev[3], 0));          // the deviates of the piece before are done
+      launch_k_vt_norm(b1 - b0, sk, Q);
+      HIPCHK(e, hipEventRecord(e->vt_ev[3], sk));
+      launch_k_vt_walk_fast(b1 - b0, sk, Q);
+    }
+    HIPCHK(e, hipEventRecord(e->vt_ev[4], s2));
+    HIPCHK(e, hipStreamWaitEvent(e->stream, e->vt_ev[4], 0));
+  }
+  if (e->vt_aside) HIPCHK(e, hipStreamWaitEvent(e->stream, e->vt_ev[1], 0));
+  // the walks that met a tension factor (or a SigErr), the rest of the walk with every form: as many workgroups as
+  // could be needed (a stop and a SigErr entry per particle), the ones beyond the list's end leave at once
+  const unsigned per_wg = (unsigned)(LT_VT_WALK_BLOCK / 64) * (unsigned)P.vt_walk_lanes;
+  const unsigned walk_blocks = (unsigned)((2 * (size_t)P.numpar + per_wg - 1) / per_wg);
+  hipLaunchKernelGGL(k_vt_walk, dim3(walk_blocks), dim3(LT_VT_WALK_BLOCK), 0, e->stream, P);
+  return LT_OK;
 }
 // k_rk is instantiated per slab type and per Vtransform (the s-level formula is then straight-line code in
 // the hot loop), in lt_rk_kernel.hip
@@ -1079,6 +1145,13 @@ int lt_create(const lt_config* cfg, lt_engine** out) {
   // (tests: a small pool of generator states makes short runs go round it many times)
   const char* envp = getenv("LT_RNG_STATES");
   if (envp && atoi(envp) >= 2 && atoi(envp) <= 1024) e->rng_P = atoi(envp);
+  // (measurements: how VTurb's kernels behind the table are launched, launch_vturb)
+  if (getenv("LT_VT_ASIDE")) e->vt_aside = atoi(getenv("LT_VT_ASIDE")) != 0;
+  if (getenv("LT_VT_PIECES")) e->vt_pieces = std::max(1, std::min(4, atoi(getenv("LT_VT_PIECES"))));
+  if (getenv("LT_VT_WALK_LANES")) {
+    const int L = atoi(getenv("LT_VT_WALK_LANES"));
+    if (L == 8 || L == 16 || L == 32 || L == 64) e->vt_walk_lanes = L;
+  }
   const char* env = getenv("LT_BRUTE_BOUNDS");
   if (env && atoi(env) != 0) { e->use_seg_index = 0; e->use_pip_index = 0; }
   // init_genrand(seed), random_module.f90:108-119 / LTRANS.f90:241
@@ -1123,6 +1196,9 @@ int lt_destroy(lt_engine* e) {
     if (b->p) (void)hipFree(b->p);
   if (e->h_cnt) (void)hipHostFree(e->h_cnt);
   if (e->cnt_ready) (void)hipEventDestroy(e->cnt_ready);
+  if (e->cnt_arrived) (void)hipEventDestroy(e->cnt_arrived);
+  if (e->h_own) (void)hipHostFree(e->h_own);
+  if (e->own_ev) (void)hipEventDestroy(e->own_ev);
   if (e->prefetch_done) (void)hipEventDestroy(e->prefetch_done);
   if (e->compute_mark) (void)hipEventDestroy(e->compute_mark);
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
@@ -1135,6 +1211,8 @@ int lt_destroy(lt_engine* e) {
   for (hipEvent_t ev : e->rng_job_ev) if (ev) (void)hipEventDestroy(ev);
   if (e->rng_jobs) (void)hipHostFree(e->rng_jobs);
   if (e->rng_stream) (void)hipStreamDestroy(e->rng_stream);
+  for (hipEvent_t ev : e->vt_ev) if (ev) (void)hipEventDestroy(ev);
+  for (hipStream_t st : e->vt_stream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
   if (e->get_pin) (void)hipHostFree(e->get_pin);
   for (auto ev : e->get_ev) (void)hipEventDestroy(ev);
   if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -1591,7 +1669,7 @@ int lt_set_particles(lt_engine* e, const lt_particles* p) {
       TRY(dev_alloc(e, e->vt_qS, waves * e->vt_qcap * 8)); TRY(dev_alloc(e, e->vt_qS1, waves * e->vt_qcap * 8));
       TRY(dev_alloc(e, e->vt_qS2, waves * e->vt_qcap * 8)); TRY(dev_alloc(e, e->vt_qwl, waves * e->vt_qcap * 2));
       TRY(dev_alloc(e, e->vt_qcount, waves * 4 + 4));
-      TRY(dev_alloc(e, e->vt_wl, (2 * n + 4) * 4));
+      TRY(dev_alloc(e, e->vt_wl, (3 * n + 4) * 4));   // count | list (a stop per particle + a SigErr entry per particle) | resume
       TRY(dev_alloc(e, e->vt_dev, waves * 64 * (size_t)(std::max(e->cfg.idt / 2, 1) + VT_DEV_HROWS) * 8));
     }
   }
@@ -1973,6 +2051,29 @@ __global__ void k_test_div(const double* a, const double* b, double* qf, double*
   const ltd::Divisor d = ltd::prep_div(b[i]);
   qf[i] = ltd::div_prep(a[i], d);
   qr[i] = a[i] / b[i];
+}
+__global__ void k_test_div_by(const double* a, double b, double ch, double cl, double* qf, double* qr, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  qf[i] = ltd::div_by(a[i], b, ltd::DivConst{ch, cl}, true);
+  qr[i] = a[i] / b;
+}
+/* test aid (device): div_by (lt_math.h) with the constants of lt_div_const against `/`, n numerators over one divisor;
+ * LT_ERR_UNSUPPORTED when the divisor gets no constants */
+int lt_test_div_by(const double* a, double b, double* q_fast, double* q_ref, int32_t n) {
+  if (!a || !q_fast || !q_ref || n < 0) return LT_ERR_ARG;
+  double hl[2];
+  if (!lt_div_const(b, hl)) return LT_ERR_UNSUPPORTED;
+  double *da = nullptr, *df = nullptr, *dr = nullptr;
+  const size_t bytes = (size_t)n * 8;
+  if (hipMalloc(&da, bytes) != hipSuccess || hipMalloc(&df, bytes) != hipSuccess || hipMalloc(&dr, bytes) != hipSuccess) return LT_ERR_NOMEM;
+  (void)hipMemcpy(da, a, bytes, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(k_test_div_by, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, da, b, hl[0], hl[1], df, dr, (int)n);
+  const hipError_t rc = hipDeviceSynchronize();
+  (void)hipMemcpy(q_fast, df, bytes, hipMemcpyDeviceToHost);
+  (void)hipMemcpy(q_ref, dr, bytes, hipMemcpyDeviceToHost);
+  (void)hipFree(da); (void)hipFree(df); (void)hipFree(dr);
+  return rc == hipSuccess ? LT_OK : LT_ERR_DEVICE;
 }
 int lt_test_div(const double* a, const double* b, double* q_fast, double* q_ref, int32_t n) {
   if (!a || !b || !q_fast || !q_ref || n < 0) return LT_ERR_ARG;
@@ -2365,6 +2466,29 @@ int lt_set_rng_window_draws(lt_engine* e, int64_t draws_before, int64_t draws_to
   return LT_OK;
 }
 
+// 1/b as the double-double div_by (lt_math.h) multiplies by: hl[0] + hl[1] = 1/b to 2^-105, both of b's sign.  Offered
+// only for b = B * 2^e with an odd integer B < 2^30 and an exponent well inside the range -- the divisors of the path
+// (4*ws, 6, differences of whole seconds) are such; anything else makes the kernels divide (fastdiv = 0).
+int lt_div_const(double b, double* hl) {
+  if (!hl) return 0;
+  hl[0] = hl[1] = 0.0;
+  if (!(std::fabs(b) > 0x1p-500 && std::fabs(b) < 0x1p500)) return 0;
+  int ex;
+  const double m = std::fabs(std::frexp(b, &ex));              // [0.5, 1)
+  unsigned long long M = (unsigned long long)std::ldexp(m, 53);  // the 53-bit significand as an integer
+  while (M && !(M & 1ull)) M >>= 1;
+  if (M >= (1ull << 30)) return 0;
+  double h = 1.0 / b;
+  double l = std::fma(-b, h, 1.0) / b;                          // (1 - b h is exact: 1/b - h, divided)
+  if (l != 0.0 && std::signbit(l) != std::signbit(h)) {        // h overshoots: one ulp towards zero, the rest is of h's sign
+    h = std::nextafter(h, 0.0);
+    l = std::fma(-b, h, 1.0) / b;
+  }
+  if (l == 0.0) l = std::copysign(0.0, h);
+  hl[0] = h; hl[1] = l;
+  return 1;
+}
+
 static int phase_flush(lt_engine* e) {
   if (!e->phase_used) return LT_OK;
   HIPCHK(e, hipEventSynchronize(e->phase_ev[e->phase_used - 1]));
@@ -2397,15 +2521,9 @@ static int step_prepare(lt_engine* e, const double* ex3, const double* ix3, int3
   P.ex0 = ex3[0]; P.ex1 = ex3[1]; P.ex2 = ex3[2];
   {
     const double dv[5] = {ex3[1] - ex3[2], ex3[0] - ex3[1], ex3[0] - ex3[2], (double)(4 * e->cfg.ws), 6.0};
-    double rc[5];
+    double* dst[5] = {P.c_d23, P.c_d12, P.c_d13, P.c_p2, P.c_6};
     int ok = 1;
-    for (int i = 0; i < 5; i++) {
-      int ex;
-      const double mant = std::fabs(std::frexp(dv[i], &ex));  // [0.5, 1)
-      if (!(std::fabs(dv[i]) > 1e-290 && std::fabs(dv[i]) < 1e290) || mant == 1.0 - 0x1p-53) ok = 0;
-      rc[i] = 1.0 / dv[i];
-    }
-    P.r_d23 = rc[0]; P.r_d12 = rc[1]; P.r_d13 = rc[2]; P.r_p2 = rc[3]; P.r_6 = rc[4];
+    for (int i = 0; i < 5; i++) ok &= lt_div_const(dv[i], dst[i]) ? 1 : 0;
     P.fastdiv = (ok && !getenv("LT_NO_FASTDIV")) ? 1 : 0;
   }
   P.ix0 = ix3[0]; P.ix1 = ix3[1]; P.ix2 = ix3[2];
@@ -2467,12 +2585,17 @@ static int step_prepare(lt_engine* e, const double* ex3, const double* ix3, int3
         e->pre_own = -1;
         e->pre_synced = false;
       } else {
-        int own = 0;
-        HIPCHK(e, hipMemcpyAsync(&own, (int*)e->rank.p + n, 4, hipMemcpyDeviceToHost, e->stream));
-        HIPCHK(e, hipStreamSynchronize(e->stream));
-        e->pre_own = own;
-        e->pre_synced = true;
-        if (e->rng_static) e->rng_static_own = own;
+        // on its way to the host; whoever needs it first waits for it (resolve_own: lt_step after it has enqueued
+        // k_rk, lt_count_draws at once)
+        if (!e->h_own) {
+          HIPCHK(e, hipHostMalloc((void**)&e->h_own, 64, hipHostMallocDefault));
+          HIPCHK(e, hipEventCreateWithFlags(&e->own_ev, hipEventDisableTiming));
+        }
+        HIPCHK(e, hipMemcpyAsync(e->h_own, (int*)e->rank.p + n, 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipEventRecord(e->own_ev, e->stream));
+        e->own_pending = true;
+        e->pre_own = -1;
+        e->pre_synced = false;
       }
     }
   }
@@ -2482,6 +2605,33 @@ static int step_prepare(lt_engine* e, const double* ex3, const double* ix3, int3
   e->pre_sig[0] = ex3[0]; e->pre_sig[1] = ex3[1]; e->pre_sig[2] = ex3[2];
   e->pre_sig[3] = ix3[0]; e->pre_sig[4] = ix3[1]; e->pre_sig[5] = ix3[2];
   e->pre_sig[6] = (double)p; e->pre_sig[7] = (double)it;
+  return LT_OK;
+}
+
+// The step's draw totals on the host: waits for whichever copy is on its way (the shard's own total, or the job's
+// gathered counts of lt_exchange_rng_window).  Both events lie behind the prefix sum of THIS step on the engine's
+// stream, so the step before has completed once they have (pre_synced).
+static int resolve_own(lt_engine* e) {
+  if (e->xchg_pending) {
+    HIPCHK(e, hipEventSynchronize(e->cnt_arrived));
+    e->xchg_pending = false;
+    long long before = 0, total = 0;
+    for (int r = 0; r < e->xchg_G; r++) {
+      if (e->h_cnt[r] < 0) return fail(e, LT_ERR_STATE, "lt_exchange_rng_window: rank %d reports %lld draws", r, e->h_cnt[r]);
+      if (r < e->xchg_rank) before += e->h_cnt[r];
+      total += e->h_cnt[r];
+    }
+    e->pre_own = (int64_t)e->h_cnt[e->xchg_rank];
+    e->rng_before = before;
+    e->rng_total = total;
+    e->pre_synced = true;
+  } else if (e->own_pending) {
+    HIPCHK(e, hipEventSynchronize(e->own_ev));
+    e->own_pending = false;
+    e->pre_own = (int64_t)*e->h_own;
+    e->pre_synced = true;
+    if (e->rng_static) e->rng_static_own = e->pre_own;
+  }
   return LT_OK;
 }
 
@@ -2497,6 +2647,7 @@ int lt_count_draws(lt_engine* e, const double* ex3, const double* ix3, int32_t p
   HIPCHK(e, hipSetDevice(e->device));
   if (e->pre_valid) return fail(e, LT_ERR_STATE, "lt_count_draws: the step counted before has not been run");
   TRY(step_prepare(e, ex3, ix3, p, it));
+  TRY(resolve_own(e));
   HIPCHK(e, hipStreamSynchronize(e->stream));
   *n_draws = e->pre_own;
   return LT_OK;
@@ -2517,9 +2668,11 @@ int lt_step(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32
   if (blocks) {
     const bool prof = e->prof_on && e->prof_used + 2 <= e->prof_ev.size();
     const bool f32 = e->cfg.slab_storage == LT_SLAB_F32;
-    if (draws) {
+    // the step's random words: where the shard's draws lie in the stream, and the generators of the blocks they touch
+    // (on a stream of their own, beside k_rk)
+    auto place_generators = [&]() -> int {
       const int64_t own = e->pre_own;
-      if (own < 0) return fail(e, LT_ERR_STATE, "lt_step: the preceding lt_exchange_rng_window did not complete");
+      if (own < 0) return fail(e, LT_ERR_STATE, "lt_step: the shard's draw total is not known");
       const int64_t before = (e->rng_total >= 0) ? e->rng_before : 0;
       const int64_t total = (e->rng_total >= 0) ? e->rng_total : own;
       if (before + own > total) return fail(e, LT_ERR_ARG, "lt_set_rng_window: window smaller than the shard's draws");
@@ -2527,8 +2680,8 @@ int lt_step(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32
       const uint64_t base = e->rng_cur + (uint64_t)before;
       if (own > 0) {
         // the generators may overwrite old ring blocks while k_rk runs on the main stream: everything earlier on
-        // e->stream has completed (step_prepare synchronised), or -- static window, nobody waited -- the
-        // generator stream waits for the end of the step before
+        // e->stream has completed (somebody waited for this step's prefix sum), or -- static window, nobody waited --
+        // the generator stream waits for the end of the step before
         if (!e->pre_synced && e->step_done_valid) HIPCHK(e, hipStreamWaitEvent(e->rng_stream, e->step_done, 0));
         TRY(rng_ensure(e, base, base + (uint64_t)own, e->rng_stream));
         HIPCHK(e, hipEventRecord(e->rng_done, e->rng_stream));
@@ -2541,8 +2694,20 @@ int lt_step(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32
       e->rng_total = e->rng_static ? e->rng_static_total : -1;
       e->rng_before = e->rng_static ? e->rng_static_before : 0;
       e->stats.rng_draws = own;
+      return LT_OK;
+    };
+    // The generators go first: their few large workgroups (four generator states each, a compute unit's worth of wave
+    // slots) are placed while the device is still empty and then run beside k_rk.  Enqueued AFTER k_rk they wait until
+    // its queue of single-wave workgroups has drained -- a slot k_rk frees is refilled by k_rk -- and the step's random
+    // words arrive a kernel late (measured: behaviour 4 on 1M particles 1.45 -> 2.15 ms per step, configs[4]'s shape
+    // 4.77 -> 4.85 ms).  So a step whose draw totals are still on their way to the host (no static window: the
+    // shard's own total behind the prefix sum, or the job's counts behind lt_exchange_rng_window's all-gather) waits
+    // for them here, before anything else of the step is enqueued: the one host wait of such a step.
+    if (draws) {
+      TRY(resolve_own(e));
+      TRY(place_generators());
     }
-    // lt_profile_* times the dominant kernel(s) of the configuration: the three VTurb kernels when
+    // lt_profile_* times the dominant kernel(s) of the configuration: the VTurb kernels when
     // vertical turbulence is on, k_rk otherwise
     const bool prof_rk = prof && !e->cfg.VTurbOn, prof_vt = prof && e->cfg.VTurbOn;
     if (prof_rk) HIPCHK(e, hipEventRecord(e->prof_ev[e->prof_used], e->stream));
@@ -2556,7 +2721,10 @@ int lt_step(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32
     else hipLaunchKernelGGL((k_rk_slow<double>), dim3(slow_blocks), dim3(256), 0, e->stream, P);
     TRY(phase_mark(e, 2));
     if (prof_vt) HIPCHK(e, hipEventRecord(e->prof_ev[e->prof_used], e->stream));
-    if (e->cfg.VTurbOn) launch_vturb(e, P, blocks);
+    if (e->cfg.VTurbOn) {
+      TRY(launch_vturb_head(e, P, blocks));
+      TRY(launch_vturb_tail(e, P, blocks));
+    }
     if (prof_vt) {
       HIPCHK(e, hipEventRecord(e->prof_ev[e->prof_used + 1], e->stream));
       e->prof_used += 2;
@@ -2568,8 +2736,20 @@ int lt_step(lt_engine* e, const double* ex3, const double* ix3, int32_t p, int32
     HIPCHK(e, hipEventRecord(e->step_done, e->stream));
     e->step_done_valid = true;
     TRY(phase_mark(e, 4));
-  } else if (e->phase_on) {
-    for (int k = 2; k <= 4; k++) TRY(phase_mark(e, k));
+  } else {
+    // an empty shard draws nothing, but the job's stream moves on by the step's total: the shard hands back the same
+    // generator state as the others (lt_get_rng)
+    if (draws) TRY(resolve_own(e));
+    if (draws && e->rng_total > 0) {
+      if (!e->rng_ready) TRY(rng_init_device(e));
+      e->rng_cur += (uint64_t)e->rng_total;
+    }
+    if (draws) {
+      e->rng_total = e->rng_static ? e->rng_static_total : -1;
+      e->rng_before = e->rng_static ? e->rng_static_before : 0;
+    }
+    if (e->phase_on)
+      for (int k = 2; k <= 4; k++) TRY(phase_mark(e, k));
   }
   e->stats_valid = false;  // the step's counters stay on the device until somebody asks (fetch_counters)
   e->counters_fetched = false;
@@ -2983,24 +3163,25 @@ int exchange_window(lt_engine* e, const double* ex3, const double* ix3, int32_t 
     const ncclResult_t rc = R->AllGather(cnt, cnt + 1, 1, ncclInt64, e->comm, e->comm_stream);
     if (rc != ncclSuccess) return fail(e, LT_ERR_DEVICE, "ncclAllGather (draw counts): %s", R->GetErrorString ? R->GetErrorString(rc) : "error");
   } else {
-    // one rank, or the test build standing in for the collective: the other ranks' counts as given, this rank's own
-    // from the device
-    if (injected && G > 1) HIPCHK(e, hipMemcpyAsync(cnt + 1, injected, (size_t)G * 8, hipMemcpyHostToDevice, e->comm_stream));
+    // one rank, or the test build standing in for the collective: the other ranks' counts as given (through the pinned
+    // words the result comes back to), this rank's own from the device
+    if (injected && G > 1) {
+      for (int r = 0; r < G; r++) e->h_cnt[r] = (long long)injected[r];
+      HIPCHK(e, hipMemcpyAsync(cnt + 1, e->h_cnt, (size_t)G * 8, hipMemcpyHostToDevice, e->comm_stream));
+    }
     HIPCHK(e, hipMemcpyAsync(cnt + 1 + rank, cnt, 8, hipMemcpyDeviceToDevice, e->comm_stream));
   }
+  // The counts travel to the host behind the collective; nobody waits here: the lt_step that follows waits for them
+  // (resolve_own) before it places the generators of the step's random words -- one host wait for the exchange and the
+  // shard's own total together.
+  if (!e->cnt_arrived) HIPCHK(e, hipEventCreateWithFlags(&e->cnt_arrived, hipEventDisableTiming));
   HIPCHK(e, hipMemcpyAsync(e->h_cnt, cnt + 1, (size_t)G * 8, hipMemcpyDeviceToHost, e->comm_stream));
-  HIPCHK(e, hipStreamSynchronize(e->comm_stream));   // the one host read of the step (the scan has run: cnt_ready)
-  long long before = 0, total = 0;
-  for (int r = 0; r < G; r++) {
-    if (e->h_cnt[r] < 0) return fail(e, LT_ERR_STATE, "lt_exchange_rng_window: rank %d reports %lld draws", r, e->h_cnt[r]);
-    if (r < rank) before += e->h_cnt[r];
-    total += e->h_cnt[r];
-  }
-  e->pre_own = (int64_t)e->h_cnt[rank];
-  // (cnt_ready lies behind everything step_prepare enqueued, and behind the step before on the same stream)
-  e->pre_synced = true;
-  e->rng_before = before;
-  e->rng_total = total;
+  HIPCHK(e, hipEventRecord(e->cnt_arrived, e->comm_stream));
+  e->xchg_pending = true;
+  e->own_pending = false;     // (the shard's total comes with the others')
+  e->xchg_G = G;
+  e->xchg_rank = rank;
+  e->pre_own = -1;
   return LT_OK;
 }
 }  // namespace

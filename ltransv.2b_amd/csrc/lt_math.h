@@ -40,19 +40,22 @@ namespace ltd {
 LT_DEV double dmin(double a, double b) { return (a < b) ? a : b; }
 LT_DEV double dmax(double a, double b) { return (a > b) ? a : b; }
 
-// a / b for a divisor b that is the same for every particle, given y = RN(1/b)
-// from the host.  q0 = a*y is within 2 ulp; one residual correction makes it a
-// faithful quotient and the second one (Markstein's theorem, valid unless the
-// significand of b is all ones -- the host checks and then clears `ok`) makes it
-// the correctly rounded quotient, i.e. exactly the value of `a / b`.
-// 5 full-rate operations instead of the ~14-instruction v_rcp_f64 sequence.
-LT_DEV double div_by(double a, double b, double y, bool ok) {
+// a / b for a divisor b that is the same for every particle, given 1/b as a double-double from the host:
+// c.h + c.l = 1/b with |c.l| <= ulp(c.h), both of b's sign (the sign of a zero quotient then comes out right).
+//   q = RN(a * c.h + RN(a * c.l))            -- a multiplication and an FMA (Brisebarre & Muller, "Correctly rounded
+//                                               multiplication by arbitrary precision constants", IEEE TC 2008, algorithm 1)
+// The value under the final rounding differs from a/b by less than 2^-104 |a/b| = 2^-51 ulp.  The host offers the
+// constants only for a divisor b = B * 2^e with an odd integer B < 2^30 (4*ws, 6, differences of the external
+// times): a quotient A/B of a 53-bit integer A is never closer than ulp/(2B) > 2^-31 ulp to the midpoint of two
+// doubles (A * 2^j - B * (2m+1) is an odd integer), so the rounding is that of the exact quotient: q == a / b for
+// every a of ordinary magnitude (|a/b| > 2^-960), bit for bit.  2 full-rate operations in a chain of 2; the
+// reciprocal-and-two-corrections form this replaces (Markstein) was 5 in a chain of 5, the compiler's a / b ~14.
+// tests/test_host.py checks the host's constants and the algorithm in exact rational arithmetic on numerators built
+// to land next to midpoints, tests/test_gpu_div.py the device code against `/`.
+struct DivConst { double h, l; };
+LT_DEV double div_by(double a, double b, const DivConst& c, bool ok) {
   if (!ok) return a / b;
-  double q = a * y;
-  double r = __builtin_fma(-b, q, a);
-  q = __builtin_fma(r, y, q);
-  r = __builtin_fma(-b, q, a);
-  return __builtin_fma(r, y, q);
+  return __builtin_fma(a, c.h, a * c.l);
 }
 
 // Division by a divisor that is used several times.  The compiler expands a / b into

@@ -194,23 +194,42 @@ inline void host_jump(const uint32_t* h, const uint32_t* g, uint32_t* out) {
 }
 
 // ---------------------------------------------------------------- device side
-constexpr int CHUNK = 227 * 16;      // words generated per LDS pass (227 = N - M independent words)
-constexpr int JUMP_CHUNK = 112 * 32;  // coefficients of the jump polynomial handled per LDS pass (whole words, <= CHUNK)
-constexpr int GEN_THREADS = 256;      // threads that drive one generator state
-constexpr int GEN_PER_WG = 4;         // generator states per workgroup of k_mt_block
+#ifndef LT_GEN_THREADS
+#define LT_GEN_THREADS 256
+#endif
+#ifndef LT_GEN_PER_WG
+#define LT_GEN_PER_WG 4
+#endif
+#ifndef LT_GEN_ROUNDS
+#define LT_GEN_ROUNDS 16
+#endif
+constexpr int CHUNK = 227 * LT_GEN_ROUNDS;      // words generated per LDS pass (227 = N - M independent words)
+constexpr int JUMP_CHUNK = ((CHUNK / 32) < 112 ? (CHUNK / 32) : 112) * 32;  // coefficients of the jump polynomial handled per LDS pass (whole words, <= CHUNK)
+constexpr int GEN_THREADS = LT_GEN_THREADS;      // threads that drive one generator state
+constexpr int GEN_PER_WG = LT_GEN_PER_WG;        // generator states per workgroup of k_mt_block
 constexpr int GEN_LDS_WORDS = N + CHUNK;
+constexpr int GEN_NQ = (N + GEN_THREADS - 1) / GEN_THREADS;   // words of the 624-word window a thread owns
 
 // window (lds[0..N)) <- g(F) window, for the GEN_THREADS threads t of one generator.  The sequence E generated
 // from the window is produced JUMP_CHUNK words at a time behind a sliding window (N + JUMP_CHUNK words of LDS
 // instead of DEG + N): new window[j] = XOR_{i: g_i = 1} E[i + j]; thread t owns j = t, t+256, t+512.
 // Every thread of the workgroup calls it (barriers); `active` = this generator really jumps.
+// (T = the threads that drive the generator: GEN_THREADS in k_mt_block, 256 in the start-up kernels; thread t owns
+// j = t, t + T, ...)
+template <int T>
 __device__ inline void jump_in_lds(uint32_t* lds, const uint32_t* __restrict__ g, int t, bool active) {
-  uint32_t acc0 = 0, acc1 = 0, acc2 = 0;
+  constexpr int NQ = (N + T - 1) / T;
+  uint32_t acc[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) acc[q] = 0u;
   for (int c = 0; c < DEG; c += JUMP_CHUNK) {
     const int todo = (DEG - c < JUMP_CHUNK) ? (DEG - c) : JUMP_CHUNK;
     for (int base = 0; base < todo; base += (N - M)) {
-      const int i = base + t;
-      if (active && t < (N - M) && i < todo) lds[N + i] = lds[M + i] ^ twist(lds[i], lds[i + 1]);
+#pragma unroll
+      for (int r = 0; r < (N - M + T - 1) / T; r++) {
+        const int k = t + r * T, i = base + k;
+        if (active && k < (N - M) && i < todo) lds[N + i] = lds[M + i] ^ twist(lds[i], lds[i + 1]);
+      }
       __syncthreads();
     }
     if (active) {
@@ -222,32 +241,32 @@ __device__ inline void jump_in_lds(uint32_t* lds, const uint32_t* __restrict__ g
           const int b = __ffs(bits) - 1;
           bits &= bits - 1;
           const int i = i0 + b;
-          acc0 ^= lds[i + t];
-          acc1 ^= lds[i + t + 256];
-          if (t + 512 < N) acc2 ^= lds[i + t + 512];
+#pragma unroll
+          for (int q = 0; q < NQ; q++)
+            if (t + q * T < N) acc[q] ^= lds[i + t + q * T];
         }
       }
     }
     __syncthreads();
     // slide the window by todo words
-    uint32_t keep[3];
+    uint32_t keep[NQ];
 #pragma unroll
-    for (int q = 0; q < 3; q++) {
-      const int i = t + q * 256;
+    for (int q = 0; q < NQ; q++) {
+      const int i = t + q * T;
       keep[q] = (active && i < N) ? lds[todo + i] : 0u;
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 3; q++) {
-      const int i = t + q * 256;
+    for (int q = 0; q < NQ; q++) {
+      const int i = t + q * T;
       if (active && i < N) lds[i] = keep[q];
     }
     __syncthreads();
   }
   if (active) {
-    lds[t] = acc0;
-    lds[t + 256] = acc1;
-    if (t + 512 < N) lds[t + 512] = acc2;
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+      if (t + q * T < N) lds[t + q * T] = acc[q];
   }
   __syncthreads();
 }
@@ -288,7 +307,7 @@ __global__ __launch_bounds__(GEN_THREADS * GEN_PER_WG) void k_mt_block(uint32_t*
     for (int i = tid; i < N; i += GEN_THREADS) lds[i] = st[i];
   __syncthreads();
   if (__syncthreads_or(active && job.poly >= 0))
-    jump_in_lds(lds, polys + (size_t)(job.poly >= 0 ? job.poly : 0) * GW, tid, active && job.poly >= 0);
+    jump_in_lds<GEN_THREADS>(lds, polys + (size_t)(job.poly >= 0 ? job.poly : 0) * GW, tid, active && job.poly >= 0);
   int done = 0;
   if (first_copy > 0) {
     if (store)
@@ -299,24 +318,27 @@ __global__ __launch_bounds__(GEN_THREADS * GEN_PER_WG) void k_mt_block(uint32_t*
     const int todo = (count - done < CHUNK) ? (count - done) : CHUNK;
     // rounds of up to 227 independent words: E[N+i] = E[M+i] ^ twist(E[i], E[i+1])
     for (int base = 0; base < todo; base += (N - M)) {
-      const int i = base + tid;
-      if (active && tid < (N - M) && i < todo) lds[N + i] = lds[M + i] ^ twist(lds[i], lds[i + 1]);
+#pragma unroll
+      for (int r = 0; r < (N - M + GEN_THREADS - 1) / GEN_THREADS; r++) {
+        const int k = tid + r * GEN_THREADS, i = base + k;
+        if (active && k < (N - M) && i < todo) lds[N + i] = lds[M + i] ^ twist(lds[i], lds[i + 1]);
+      }
       __syncthreads();
     }
     if (store)
       for (int i = tid; i < todo; i += GEN_THREADS) out[done + i] = lds[N + i];
     __syncthreads();
     // slide the history window
-    uint32_t keep[3];
+    uint32_t keep[GEN_NQ];
 #pragma unroll
-    for (int q = 0; q < 3; q++) {
-      int i = tid + q * 256;
+    for (int q = 0; q < GEN_NQ; q++) {
+      int i = tid + q * GEN_THREADS;
       keep[q] = (active && i < N) ? lds[todo + i] : 0u;
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 3; q++) {
-      int i = tid + q * 256;
+    for (int q = 0; q < GEN_NQ; q++) {
+      int i = tid + q * GEN_THREADS;
       if (active && i < N) lds[i] = keep[q];
     }
     __syncthreads();
@@ -333,7 +355,7 @@ __global__ __launch_bounds__(256) void k_mt_jump(uint32_t* __restrict__ states, 
   const int tid = threadIdx.x;
   for (int i = tid; i < N; i += blockDim.x) lds[i] = states[(size_t)src * N + i];
   __syncthreads();
-  jump_in_lds(lds, g, tid, true);
+  jump_in_lds<256>(lds, g, tid, true);
   for (int i = tid; i < N; i += blockDim.x) states[(size_t)dst * N + i] = lds[i];
 }
 
@@ -393,7 +415,7 @@ __global__ __launch_bounds__(256) void k_mt_jump_each(uint32_t* __restrict__ sta
   uint32_t* st = states + (size_t)blockIdx.x * N;
   for (int i = tid; i < N; i += blockDim.x) lds[i] = st[i];
   __syncthreads();
-  jump_in_lds(lds, g, tid, true);
+  jump_in_lds<256>(lds, g, tid, true);
   for (int i = tid; i < N; i += blockDim.x) st[i] = lds[i];
 }
 

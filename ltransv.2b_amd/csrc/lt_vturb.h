@@ -28,6 +28,11 @@ LT_DEV double draw_norm(const StepParams& P, unsigned long long idx) {
 // (tab: the records {x, y, yp, sigma} of one particle, knot k at tab[k * VT_TS]; zero_sig: TSPSI failed
 // before SIGS ran)
 #define VT_TS 64  // table layout [wave][knot][lane]: a wave's records of one knot are 2 KB contiguous
+// what k_vt_table stores as the tension factor of an interval it LISTS for k_vt_sigs (which overwrites it): not zero,
+// so that k_vt_walk_fast -- which may run beside k_vt_sigs -- stops at such an interval whether or not its factor has
+// been written yet.  (A listed interval's factor comes out zero only when T rounds to <= 2 in sigs_classify; such a
+// walk then goes to k_vt_walk, whose cubic form is the same expression: same sums either way.)
+#define VT_SIG_PENDING 1.0
 template <bool DERIV>
 LT_DEV double hval_table(double T, int n, const double4* tab, bool zero_sig, int& il) {
   int I;
@@ -60,7 +65,7 @@ LT_DEV double hval_table(double T, int n, const double4* tab, bool zero_sig, int
 // (ns, the node of the time axis closest to x, is the same for every particle: the host
 // finds it once per step with polintd's own comparisons, StepParams::pns)
 LT_DEV double polintd_shared(double xa1, double xa2, double xa3, double ya1, double ya2, double ya3,
-                             double q32, double q21, double r13, bool fd, double x, int ns) {
+                             double q32, double q21, const DivConst& r13, bool fd, double x, int ns) {
   double c = (xa2 - x) * q32;
   c = c - (xa2 - x) * q21;
   c = div_by(c, xa1 - xa3, r13, fd);
@@ -79,17 +84,17 @@ LT_DEV void polintd3x3_ns(const StepParams& P, double ya1, double ya2, double ya
                           double& rb, double& rc, double& rf) {
   const double xa1 = P.ex0, xa2 = P.ex1, xa3 = P.ex2;
   constexpr bool fd = FD;
-  rb = polintd_shared(xa1, xa2, xa3, ya1, ya2, ya3, q32, q21, P.r_d13, fd, P.ix0, NS > 0 ? NS : P.pns0);
-  rc = polintd_shared(xa1, xa2, xa3, ya1, ya2, ya3, q32, q21, P.r_d13, fd, P.ix1, NS > 0 ? NS : P.pns1);
-  rf = polintd_shared(xa1, xa2, xa3, ya1, ya2, ya3, q32, q21, P.r_d13, fd, P.ix2, NS > 0 ? NS : P.pns2);
+  rb = polintd_shared(xa1, xa2, xa3, ya1, ya2, ya3, q32, q21, DivConst{P.c_d13[0], P.c_d13[1]}, fd, P.ix0, NS > 0 ? NS : P.pns0);
+  rc = polintd_shared(xa1, xa2, xa3, ya1, ya2, ya3, q32, q21, DivConst{P.c_d13[0], P.c_d13[1]}, fd, P.ix1, NS > 0 ? NS : P.pns1);
+  rf = polintd_shared(xa1, xa2, xa3, ya1, ya2, ya3, q32, q21, DivConst{P.c_d13[0], P.c_d13[1]}, fd, P.ix2, NS > 0 ? NS : P.pns2);
 }
 template <bool FD>
 LT_DEV void polintd3x3(const StepParams& P, double ya1, double ya2, double ya3,
                        double& rb, double& rc, double& rf) {
   const double xa1 = P.ex0, xa2 = P.ex1, xa3 = P.ex2;
   constexpr bool fd = FD;
-  const double q32 = div_by(ya3 - ya2, xa2 - xa3, P.r_d23, fd);
-  const double q21 = div_by(ya2 - ya1, xa1 - xa2, P.r_d12, fd);
+  const double q32 = div_by(ya3 - ya2, xa2 - xa3, DivConst{P.c_d23[0], P.c_d23[1]}, fd);
+  const double q21 = div_by(ya2 - ya1, xa1 - xa2, DivConst{P.c_d12[0], P.c_d12[1]}, fd);
   const int ns = (P.pns0 == P.pns1 && P.pns1 == P.pns2) ? P.pns0 : 0;
   if (ns == 2) polintd3x3_ns<FD, 2>(P, ya1, ya2, ya3, q32, q21, rb, rc, rf);
   else if (ns == 3) polintd3x3_ns<FD, 3>(P, ya1, ya2, ya3, q32, q21, rb, rc, rf);
@@ -323,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
     rng_[s] = wzN[s] - wz1[s];
   }
   auto NEWX = [&](int s, int j) -> double {  // :121-123
-    return wz1[s] + div_by(((double)(float)(j - 4)) * rng_[s], (double)p2, P.r_p2, FD);
+    return wz1[s] + div_by(((double)(float)(j - 4)) * rng_[s], (double)p2, DivConst{P.c_p2[0], P.c_p2[1]}, FD);
   };
   // piecewise-linear profile segment per slot :126-163.  Moving up one level reuses
   // the upper end of the previous segment (same values), and the Kh of the level after
@@ -395,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
       Q.wl[qb + idx] = (unsigned short)((where << 6) | lane);
     }
     ntask += __popcll(m);
-    return 0.0;  // what the owner stores with the knot (the list's results are written later by k_vt_sigs)
+    return lm_lane(m) ? VT_SIG_PENDING : 0.0;  // what the owner stores with the knot (k_vt_sigs writes the listed ones' later)
   };
   // newx(k+7) of the knot in hand is newx(k+8) of the one before: kept (the reference recomputes each newx
   // three times: as the end of the 8-point window, as its last-but-one point, and as its start)
@@ -440,8 +445,8 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
       if (fyb < 0.0) fyb = 0.0;
       if (fyc < 0.0) fyc = 0.0;
       if (fyf < 0.0) fyf = 0.0;
-      yk = div_by(fyb + 4.0 * fyc + fyf, 6.0, P.r_6, FD);
-      xk = div_by(fxb + 4.0 * fxc + fxf, 6.0, P.r_6, FD);
+      yk = div_by(fyb + 4.0 * fyc + fyf, 6.0, DivConst{P.c_6[0], P.c_6[1]}, FD);
+      xk = div_by(fxb + 4.0 * fxc + fxf, 6.0, DivConst{P.c_6[0], P.c_6[1]}, FD);
     }
     VTICK(1);
     // TSPSI(p2) as a stream: YPC1 (tension_module.f90:852-977), SIGS (:314-781).  YPC1 stops at the
@@ -573,7 +578,15 @@ __global__ __launch_bounds__(256) void k_vt_sigs(const StepParams P) {
     else if (kind == SIGK_SECANT) sg = sigs_secant(S, S1, S2);
     if (have) {
       P.vt_tab[((size_t)wave * (size_t)p2 + (wl >> 6)) * VT_TS + (wl & 63u)].w = sg;
-      if (lm_lane(NEED & FAILED)) atomicOr(&P.ws_i[(size_t)wave * 64 + (wl & 63u)], (int)FL_VT_SIGERR);
+      if (lm_lane(NEED & FAILED)) {
+        // SigErr: every evaluation of this particle's walk is linint's (ver_turb_module.f90:296-331).  k_vt_walk_fast
+        // may be running beside this kernel and may not see the flag: the particle goes onto k_vt_walk's list from
+        // here (once: the first failed interval of the particle), marked as such, and is walked from the first
+        // sub-step whatever the fast kernel did with it.
+        const int pn = (int)((size_t)wave * 64 + (wl & 63u));
+        const int old = atomicOr(&P.ws_i[pn], (int)FL_VT_SIGERR);
+        if (!(old & FL_VT_SIGERR)) P.vt_wl_list[atomicAdd(P.vt_wl_count, 1)] = pn | (int)0x80000000;
+      }
     }
   }
   if (lane == 0 && rounds) atomicAdd(&P.counters[CNT_VT_ROUNDS], (unsigned long long)rounds);
@@ -597,8 +610,8 @@ struct __attribute__((packed, aligned(4))) RawWords4 { uint32_t a, b, c, d; };
 __global__ __launch_bounds__(256) void k_vt_norm(const StepParams P) {
   __shared__ uint2 rbuf[8][256];
   libm_tables_load<LM_LOG | LM_SINCOS>();
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= P.numpar) return;
+  const int n = P.part_lo + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (n >= P.part_hi) return;
   if (!(P.ws_i[n] & FL_ACT)) return;
   const int loop = P.idt / 2;
   unsigned long long di = P.rng_base + (unsigned long long)(unsigned)P.rank[P.orig[n]];
@@ -711,8 +724,8 @@ LT_DEV void vt_seek_lite(VtLite& c, double T, int n, const double4* tab) {
 #ifdef LT_VT_DEFINE_A
 __global__ __launch_bounds__(LT_VT_WALKFAST_BLOCK) void k_vt_walk_fast(const StepParams P) {
   libm_tables_load<LM_EXP | LM_POW>();  // (pow takes the exp table too)
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= P.numpar) return;
+  const int n = P.part_lo + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (n >= P.part_hi) return;
   const int fl = P.ws_i[n];
   if (!(fl & FL_ACT)) return;
   const int lane = threadIdx.x & 63;
@@ -802,15 +815,25 @@ __global__ __launch_bounds__(LT_VT_WALKFAST_BLOCK) void k_vt_walk_fast(const Ste
 #ifdef LT_VT_DEFINE_B
 __global__ __launch_bounds__(LT_VT_WALK_BLOCK) void k_vt_walk(const StepParams P) {
   const int nlisted = *P.vt_wl_count;
-  if ((int)(blockIdx.x * blockDim.x) >= nlisted) return;   // (the whole workgroup: launched for the worst case)
+  // vt_walk_lanes listed walks per wave (the other lanes leave): a wave executes every form any of its walks needs at
+  // a sub-step, and its time is its longest walk's
+  const int L = P.vt_walk_lanes;
+  const int wv0 = (int)((blockIdx.x * blockDim.x) >> 6);
+  if (wv0 * L >= nlisted) return;   // (the whole workgroup: launched for the worst case)
   libm_tables_load<LM_EXP | LM_POW>();
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nlisted) return;
-  const int n = P.vt_wl_list[t];
+  const int ln = threadIdx.x & 63;
+  const int t = (wv0 + (int)(threadIdx.x >> 6)) * L + ln;
+  if (ln >= L || t >= nlisted) return;
+  // an entry is a particle slot; bit 31: listed by k_vt_sigs (SigErr).  A SigErr particle is walked through ITS entry
+  // of k_vt_sigs, from the first sub-step; an entry k_vt_walk_fast made for it (a stop, or the flag seen at its start)
+  // is skipped.
+  const int ent = P.vt_wl_list[t];
+  const int n = ent & 0x7fffffff;
   const int fl = P.ws_i[n];
-  const int i0 = P.vt_wl_resume[n];     // the sub-step the walk stopped at (1: nothing done yet)
   const bool ypc_fail = (fl & FL_VT_YPCFAIL) != 0;
   const int sigerr = (fl & FL_VT_SIGERR) ? 1 : 0;
+  if (sigerr && ent >= 0) return;
+  const int i0 = sigerr ? 1 : P.vt_wl_resume[n];     // the sub-step the walk stopped at (1: nothing done yet)
   const size_t N = (size_t)P.numpar;
   double* wsd = P.ws_d + n;
   const int p2 = 4 * P.ws;
@@ -821,7 +844,7 @@ __global__ __launch_bounds__(LT_VT_WALK_BLOCK) void k_vt_walk(const StepParams P
   const double background = (double)1.0E-6f, deltat = 2.0;
   const int loop = P.idt / (int)deltat;
   const double* dev = VT_DEV_BASE(P, n, loop) + (size_t)VT_DEV_HROWS * 64;   // norm() per sub-step
-  double ParZc = wsd[(size_t)WS_TURBV * N];   // left there by k_vt_walk_fast
+  double ParZc = sigerr ? P_zc : wsd[(size_t)WS_TURBV * N];   // left there by k_vt_walk_fast
   int il = 1;
   VtInterval ci;
   ci.I = 0; ci.X1 = ci.X2 = ci.Y1 = ci.Y2 = ci.P1 = ci.P2 = ci.SG = ci.SGhi = 0.0;

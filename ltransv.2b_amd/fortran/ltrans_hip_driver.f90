@@ -160,7 +160,7 @@ program ltrans_hip_driver
     write(sfx, '(a,i0)') '.rank', myrank
     outfile = trim(outfile)//trim(sfx)
   else if (nranks > 1) then
-    stop 'LT_NRANKS > 1 needs LT_COMM_FILE'
+    error stop 'LT_NRANKS > 1 needs LT_COMM_FILE'
   endif
   errlog = 'ErrorLog.txt'; timingcsv = 'Timing.csv'
   if (myrank > 0) then

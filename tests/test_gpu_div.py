@@ -59,6 +59,30 @@ def test_prepared_division_near_one_and_fp32_values(hip_lib):
     assert np.array_equal(qf.view(np.uint64), qr.view(np.uint64))
 
 
+@pytest.mark.parametrize("b", [124.0, 204.0, 6.0, -3600.0, -7200.0, 84.0, 44.0])
+def test_division_by_a_shared_constant_is_the_compilers_division(hip_lib, b):
+    """div_by (lt_math.h): a multiplication and an FMA with the host's double-double 1/b (lt_div_const) against `/` on
+    the device -- the divisors k_vt_table shares among all particles (4*ws, 6, differences of the external times);
+    tests/test_host.py holds the same algorithm against exact rational arithmetic."""
+    rng = np.random.default_rng(int(abs(b)))
+    n = 3_000_000
+    a = np.concatenate([
+        np.exp(rng.uniform(np.log(1e-40), np.log(1e8), n)) * rng.choice([-1.0, 1.0], n),
+        (rng.standard_normal(n // 2).astype(np.float32)).astype(np.float64) * rng.uniform(0.0, 300.0, n // 2),
+        # quotients next to the midpoint of two doubles
+        (rng.integers(1 << 52, 1 << 53, n // 2).astype(np.float64) + 0.5) * b * np.exp2(rng.integers(-40, 40, n // 2)),
+        np.array([0.0, -0.0, 1.0, -1.0, b, -b, 3.0 * b]),
+    ])
+    qf = np.empty_like(a)
+    qr = np.empty_like(a)
+    hip_lib.lt_test_div_by.restype = C.c_int
+    rc = hip_lib.lt_test_div_by(a.ctypes.data_as(C.c_void_p), C.c_double(b), qf.ctypes.data_as(C.c_void_p),
+                                qr.ctypes.data_as(C.c_void_p), C.c_int32(a.size))
+    assert rc == 0
+    assert np.array_equal(qf.view(np.uint64), qr.view(np.uint64))
+    assert np.array_equal(qr, a / b)
+
+
 def _dev_exp(lib, x):
     x = np.ascontiguousarray(x, dtype=np.float64)
     out = np.empty((x.size, 2))

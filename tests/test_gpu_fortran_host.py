@@ -67,26 +67,23 @@ def test_fortran_driver_rank_mode(tmp_path):
     assert not (tmp_path / "comm_id").exists()
 
 
-@pytest.mark.parametrize("what", ["late_release", "mortality"])
-def test_fortran_driver_rank_mode_refuses_a_static_window_that_cannot_hold(tmp_path, what):
-    """two ranks with turbulence set their windows of the stream once; a particle that is released later (LTRANS.f90:790:
-    no draw before its release) or can die makes the job's draw counts change, so the harness stops before it creates
-    anything (rank 0 alone is enough to see it: no second process, no communicator)"""
+def test_fortran_driver_rank_mode_needs_a_communicator_for_several_ranks(tmp_path):
+    """LT_NRANKS > 1 without LT_COMM_FILE: the harness stops before it creates anything (the shards could neither
+    exchange their draw counts -- lt_exchange_rng_window, tests/test_gpu_exchange.py -- nor gather positions)"""
     if not os.path.exists(DRIVER):
         pytest.skip("Fortran harness not built (flang absent at build time)")
-    case = cases.build_case("tiny_turb", **({"mortality": 1, "deadage": 1.0e9} if what == "mortality" else {}))
-    if what == "late_release":
-        case["parts"]["par"][17, 10] = 300.0      # par(18,pDOB): ONE particle, in the other rank's half or not
+    case = cases.build_case("tiny_turb", mortality=1, deadage=1.0e9)
     casefile.write_ltrans_data(tmp_path / "LTRANS.data", case["cfg"], days=1.0)
     casefile.write_case(tmp_path / "case.bin", case["g"], case["geo"], case["bounds"], case["parts"],
                         [case["record"](r) for r in range(2)], case["cfg"].numpar)
-    env = dict(os.environ, LT_NRANKS="2", LT_RANK="1", LT_COMM_FILE=str(tmp_path / "comm_id"), LT_DEVICE="0")
+    env = {k: v for k, v in os.environ.items() if k != "LT_COMM_FILE"}
+    env.update(LT_NRANKS="2", LT_RANK="1", LT_DEVICE="0")
     r = subprocess.run([DRIVER, str(tmp_path / "LTRANS.data"), str(tmp_path / "case.bin"),
                         str(tmp_path / "out.bin"), "1", "3", "0"], capture_output=True, text=True, cwd=tmp_path, env=env,
                        timeout=120)
     assert r.returncode != 0
-    assert "draw counts can change" in r.stdout + r.stderr
-    assert not (tmp_path / "out.bin.rank1").exists()
+    assert "needs LT_COMM_FILE" in r.stdout + r.stderr
+    assert not (tmp_path / "out.bin.rank1").exists() and not (tmp_path / "out.bin").exists()
 
 
 def test_fortran_driver_writes_errorlog_and_timing(tmp_path):

@@ -3,6 +3,8 @@ init-time geometry stand-ins, sharding helpers; and whole-step sanity of the CPU
 oracle on the synthetic inputs (the checker must itself behave)."""
 import os
 
+import math
+
 import numpy as np
 import pytest
 
@@ -137,3 +139,53 @@ def test_exp_table_header_is_the_generated_one():
         h = struct.unpack("<d", struct.pack("<Q", sbits + (k << 45)))[0]
         assert h == 2.0 ** (k / 128.0) or abs(h - 2.0 ** (k / 128.0)) <= 2.3e-16 * h
         assert abs(struct.unpack("<d", struct.pack("<Q", tail))[0]) < 2.0 ** -53
+
+
+def test_division_by_a_shared_constant_is_exact_in_rational_arithmetic():
+    """div_by (csrc/lt_math.h): a / b for a divisor every particle shares as q = RN(a*h + RN(a*l)) with the host's
+    double-double h + l = 1/b (lt_div_const, no GPU needed).  Checked here in exact rational arithmetic -- Python's
+    Fraction -> float conversion rounds correctly -- against RN(a/b) on numerators built to put the quotient next to
+    the midpoint of two doubles (where a wrong last bit would show), on random ones, and on the sign of zero; and the
+    divisors lt_div_const must refuse."""
+    import ctypes as C
+    import random
+    from fractions import Fraction
+    import ltrans_amd
+    lib = ltrans_amd.load_hip_library()
+    lib.lt_div_const.restype = C.c_int
+    lib.lt_div_const.argtypes = [C.c_double, C.POINTER(C.c_double)]
+
+    def consts(b):
+        hl = (C.c_double * 2)()
+        return lib.lt_div_const(b, hl), hl[0], hl[1]
+
+    def algo(a, h, l):
+        u1 = float(Fraction(a) * Fraction(l))            # RN(a * l)
+        return float(Fraction(a) * Fraction(h) + Fraction(u1))   # RN(a * h + u1): the FMA
+
+    rnd = random.Random(5)
+    for b in (124.0, 204.0, 6.0, -3600.0, -7200.0, 3600.0, 120.0, 36.0, 84.0, 44.0, -86400.0, 3.0, 1.0, 0.5, -2.0,
+              float((1 << 30) - 1), 900.0 * 2.0 ** -40):
+        ok, h, l = consts(b)
+        assert ok == 1, b
+        assert (h < 0) == (b < 0) and (math.copysign(1.0, l) < 0) == (b < 0)
+        assert abs(Fraction(1) / Fraction(b) - Fraction(h) - Fraction(l)) <= abs(Fraction(1) / Fraction(b)) * Fraction(1, 2 ** 104)
+        nums = [rnd.uniform(-1e6, 1e6) for _ in range(300)] + [rnd.uniform(-1, 1) * 10.0 ** rnd.randint(-200, 200) for _ in range(300)]
+        # quotients next to midpoints: a = RN(b * (an odd multiple of half an ulp)), and its neighbours
+        for _ in range(400):
+            m = rnd.getrandbits(52) | (1 << 52)
+            e = rnd.randint(-60, 60)
+            mid = Fraction(2 * m + 1, 2) * Fraction(2) ** e
+            a0 = float(mid * Fraction(b))
+            nums += [a0, math.nextafter(a0, math.inf), math.nextafter(a0, -math.inf)]
+        for a in nums:
+            want = float(Fraction(a) / Fraction(b))
+            got = algo(a, h, l)
+            assert got == want and math.copysign(1.0, got) == math.copysign(1.0, want), (a, b, got, want)
+        # zero numerators: the sign of the quotient (both parts of the constant carry b's sign)
+        for a in (0.0, -0.0):
+            want = a / b
+            got = a * h + a * l
+            assert got == 0.0 and math.copysign(1.0, got) == math.copysign(1.0, want), (a, b)
+    for b in (0.0, math.inf, math.nan, 1e200, 1e-200, math.pi, float((1 << 31) + 1), 1.0 / 3.0):
+        assert consts(b)[0] == 0, b
