@@ -341,8 +341,10 @@ int lt_set_rng_window_draws(lt_engine *e, int64_t draws_before, int64_t draws_to
  * the lower ranks; the following lt_step with the SAME arguments continues from there.  Works for every
  * configuration that draws (turbulence, behaviours 1-5, settlement / mortality / open boundary / late releases),
  * ends a static window, and without a communicator is the single engine's own window.  Every rank of the
- * communicator must make the call for every step.  One host read per call (the G counts: the host places the
- * generators of the step's random words with them); under lt_set_rng_window_static there is none and no call. */
+ * communicator must make the call for every step.  The call itself does not wait: the G counts travel to the host
+ * behind the collective and the lt_step that follows waits for them once, before it places the generators of the
+ * step's random words (the one host wait a step without a static window has anyway, for the shard's own total).
+ * Under lt_set_rng_window_static there is no exchange and no wait. */
 int lt_exchange_rng_window(lt_engine *e, const double *ex3, const double *ix3, int32_t p, int32_t it);
 
 /* the hot path ---------------------------------------------------------- */

@@ -156,10 +156,6 @@ struct StepParams {
   // the walks that met an interval with a tension factor and are finished by k_vt_walk (lt_vturb.h):
   // their number, the particle slots, the sub-step each resumes at
   int *vt_wl_count, *vt_wl_list, *vt_wl_resume;
-  // k_vt_norm / k_vt_walk_fast may be launched piece by piece (particles [part_lo, part_hi), part_lo a multiple of
-  // 256) so that the deviates of one piece are formed beside the walks of the piece before; k_vt_walk takes
-  // vt_walk_lanes listed walks per wave (64, or fewer: the wave then executes fewer of the forms its walks need)
-  int part_lo, part_hi, vt_walk_lanes;
   // ---- per-step workspace exchanged between k_pre / k_rk / k_post
   unsigned char* ele_ok;  // [numpar] 1: the stored elements were found for the CURRENT position
                           //     by the setEle at the end of the previous step (LTRANS.f90:1317)

@@ -189,12 +189,11 @@ struct lt_engine {
   int64_t pre_own = 0;
   bool pre_synced = true;   // step_prepare waited for the device (everything earlier on `stream` has completed)
   double pre_sig[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  // VTurb's kernels after the table (lt_vturb.h): k_vt_sigs on a stream of its own beside k_vt_norm / k_vt_walk_fast
-  // (vt_aside), and those two in vt_pieces pieces of the particles -- the deviates of piece k+1 beside the walks of
-  // piece k; k_vt_walk, behind all of them, takes vt_walk_lanes listed walks per wave
-  hipStream_t vt_stream[2] = {nullptr, nullptr};
-  hipEvent_t vt_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  int vt_aside = 1, vt_pieces = 1, vt_walk_lanes = 64;
+  // VTurb's kernels behind the table (launch_vturb_head / _tail): k_vt_sigs on a stream of its own beside k_vt_norm and
+  // k_vt_walk_fast (vt_aside; LT_VT_ASIDE=0 puts it back into the chain, for measurements)
+  hipStream_t vt_stream = nullptr;
+  hipEvent_t vt_ev[2] = {nullptr, nullptr};
+  int vt_aside = 1;
   hipStream_t rng_stream = nullptr;  // the MT19937 blocks of a step are generated beside k_rk
   hipEvent_t rng_done = nullptr;
   bool rng_pending = false, step_done_valid = false;
@@ -355,7 +354,6 @@ void fill_params(lt_engine* e, StepParams& P) {
   P.vt_wl_count = (int*)e->vt_wl.p;
   P.vt_wl_list = e->vt_wl.p ? (int*)e->vt_wl.p + 4 : nullptr;
   P.vt_wl_resume = e->vt_wl.p ? (int*)e->vt_wl.p + 4 + 2 * (size_t)e->cfg.numpar : nullptr;
-  P.part_lo = 0; P.part_hi = c.numpar; P.vt_walk_lanes = e->vt_walk_lanes;
   P.ele_ok = (unsigned char*)e->ele_ok.p;
   P.FreeSlip = c.FreeSlip ? 1 : 0;
   P.fsR = (const unsigned char*)e->fsR.p; P.fsU = (const unsigned char*)e->fsU.p;
@@ -971,52 +969,27 @@ void wait_rng(lt_engine* e) {
 int launch_vturb_head(lt_engine* e, const StepParams& P, unsigned blocks) {
   // (k_vt_table, k_vt_norm and k_vt_walk_fast live in lt_rk_kernel.hip: lt_rk_launch.h)
   launch_k_vt_table(e->cfg.slab_storage == LT_SLAB_F32, e->cfg.Vtransform, P.fastdiv != 0, blocks, e->stream, P);
-  const int pieces = std::max(1, std::min(e->vt_pieces, 4));
-  const bool forked = e->vt_aside || pieces > 1;
-  if (forked && !e->vt_stream[0]) {
-    for (auto& s : e->vt_stream) HIPCHK(e, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  if (e->vt_aside && !e->vt_stream) {
+    HIPCHK(e, hipStreamCreateWithFlags(&e->vt_stream, hipStreamNonBlocking));
     for (auto& ev : e->vt_ev) HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   }
-  hipStream_t s_sigs = e->vt_aside ? e->vt_stream[0] : e->stream;
-  if (forked) HIPCHK(e, hipEventRecord(e->vt_ev[0], e->stream));            // the table is there
-  if (e->vt_aside) HIPCHK(e, hipStreamWaitEvent(s_sigs, e->vt_ev[0], 0));
+  hipStream_t s_sigs = e->vt_aside ? e->vt_stream : e->stream;
+  if (e->vt_aside) {
+    HIPCHK(e, hipEventRecord(e->vt_ev[0], e->stream));            // the table is there
+    HIPCHK(e, hipStreamWaitEvent(s_sigs, e->vt_ev[0], 0));
+  }
   hipLaunchKernelGGL(k_vt_sigs, dim3(blocks), dim3(256), 0, s_sigs, P);
   if (e->vt_aside) HIPCHK(e, hipEventRecord(e->vt_ev[1], s_sigs));
   return LT_OK;
 }
 int launch_vturb_tail(lt_engine* e, const StepParams& P, unsigned blocks) {
-  const int pieces = std::max(1, std::min(e->vt_pieces, 4));
   wait_rng(e);
-  if (pieces == 1) {
-    launch_k_vt_norm(blocks, e->stream, P);
-    launch_k_vt_walk_fast(blocks, e->stream, P);
-  } else {
-    // piece k: deviates, then walks, pieces alternating between the engine's stream and a second one; the deviates of
-    // piece k+1 start when those of piece k are done, i.e. beside piece k's walks
-    hipStream_t s2 = e->vt_stream[1];
-    HIPCHK(e, hipEventRecord(e->vt_ev[2], e->stream));                       // table + random words: what s2 waits for
-    HIPCHK(e, hipStreamWaitEvent(s2, e->vt_ev[2], 0));
-    const unsigned per = (blocks + (unsigned)pieces - 1) / (unsigned)pieces;
-    for (int k = 0; k < pieces; k++) {
-      const unsigned b0 = std::min(blocks, per * (unsigned)k), b1 = std::min(blocks, b0 + per);
-      if (b1 <= b0) break;
-      StepParams Q = P;
-      Q.part_lo = (int)(b0 * 256u);
-      Q.part_hi = std::min(P.numpar, (int)(b1 * 256u));
-      hipStream_t sk = (k & 1) ? s2 : e->stream;
-      if (k > 0) HIPCHK(e, hipStreamWaitEvent(sk, e->vt_ev[3], 0));          // the deviates of the piece before are done
-      launch_k_vt_norm(b1 - b0, sk, Q);
-      HIPCHK(e, hipEventRecord(e->vt_ev[3], sk));
-      launch_k_vt_walk_fast(b1 - b0, sk, Q);
-    }
-    HIPCHK(e, hipEventRecord(e->vt_ev[4], s2));
-    HIPCHK(e, hipStreamWaitEvent(e->stream, e->vt_ev[4], 0));
-  }
+  launch_k_vt_norm(blocks, e->stream, P);
+  launch_k_vt_walk_fast(blocks, e->stream, P);
   if (e->vt_aside) HIPCHK(e, hipStreamWaitEvent(e->stream, e->vt_ev[1], 0));
   // the walks that met a tension factor (or a SigErr), the rest of the walk with every form: as many workgroups as
   // could be needed (a stop and a SigErr entry per particle), the ones beyond the list's end leave at once
-  const unsigned per_wg = (unsigned)(LT_VT_WALK_BLOCK / 64) * (unsigned)P.vt_walk_lanes;
-  const unsigned walk_blocks = (unsigned)((2 * (size_t)P.numpar + per_wg - 1) / per_wg);
+  const unsigned walk_blocks = (unsigned)((2 * (size_t)P.numpar + LT_VT_WALK_BLOCK - 1) / LT_VT_WALK_BLOCK);
   hipLaunchKernelGGL(k_vt_walk, dim3(walk_blocks), dim3(LT_VT_WALK_BLOCK), 0, e->stream, P);
   return LT_OK;
 }
@@ -1145,13 +1118,7 @@ int lt_create(const lt_config* cfg, lt_engine** out) {
   // (tests: a small pool of generator states makes short runs go round it many times)
   const char* envp = getenv("LT_RNG_STATES");
   if (envp && atoi(envp) >= 2 && atoi(envp) <= 1024) e->rng_P = atoi(envp);
-  // (measurements: how VTurb's kernels behind the table are launched, launch_vturb)
-  if (getenv("LT_VT_ASIDE")) e->vt_aside = atoi(getenv("LT_VT_ASIDE")) != 0;
-  if (getenv("LT_VT_PIECES")) e->vt_pieces = std::max(1, std::min(4, atoi(getenv("LT_VT_PIECES"))));
-  if (getenv("LT_VT_WALK_LANES")) {
-    const int L = atoi(getenv("LT_VT_WALK_LANES"));
-    if (L == 8 || L == 16 || L == 32 || L == 64) e->vt_walk_lanes = L;
-  }
+  if (getenv("LT_VT_ASIDE")) e->vt_aside = atoi(getenv("LT_VT_ASIDE")) != 0;   // (measurements)
   const char* env = getenv("LT_BRUTE_BOUNDS");
   if (env && atoi(env) != 0) { e->use_seg_index = 0; e->use_pip_index = 0; }
   // init_genrand(seed), random_module.f90:108-119 / LTRANS.f90:241
@@ -1212,7 +1179,7 @@ int lt_destroy(lt_engine* e) {
   if (e->rng_jobs) (void)hipHostFree(e->rng_jobs);
   if (e->rng_stream) (void)hipStreamDestroy(e->rng_stream);
   for (hipEvent_t ev : e->vt_ev) if (ev) (void)hipEventDestroy(ev);
-  for (hipStream_t st : e->vt_stream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+  if (e->vt_stream) { (void)hipStreamSynchronize(e->vt_stream); (void)hipStreamDestroy(e->vt_stream); }
   if (e->get_pin) (void)hipHostFree(e->get_pin);
   for (auto ev : e->get_ev) (void)hipEventDestroy(ev);
   if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -2561,17 +2528,18 @@ static int step_prepare(lt_engine* e, const double* ex3, const double* ix3, int3
       // offset of every tracked particle's first draw, in REFERENCE order: the reference's
       // generator is advanced particle by particle (LTRANS.f90:778,1087,1098,1110)
       const int n = e->cfg.numpar;
-      hipLaunchKernelGGL(k_flag_scatter, dim3(blocks), dim3(256), 0, e->stream, (const int*)e->ws_i.p,
+      hipStream_t ss = e->stream;
+      hipLaunchKernelGGL(k_flag_scatter, dim3(blocks), dim3(256), 0, ss, (const int*)e->ws_i.p,
                          (const int*)e->orig.p, (int*)e->flag.p, n, P.rng_draws);
       size_t need = 0;
-      HIPCHK(e, hipcub::DeviceScan::ExclusiveSum(nullptr, need, (int*)e->flag.p, (int*)e->rank.p, n + 1, e->stream));
+      HIPCHK(e, hipcub::DeviceScan::ExclusiveSum(nullptr, need, (int*)e->flag.p, (int*)e->rank.p, n + 1, ss));
       if (need > e->scan_tmp_bytes) {
         TRY(dev_alloc(e, e->scan_tmp, need));
         e->scan_tmp_bytes = e->scan_tmp.bytes;
       }
-      HIPCHK(e, hipMemsetAsync((int*)e->flag.p + n, 0, 4, e->stream));
+      HIPCHK(e, hipMemsetAsync((int*)e->flag.p + n, 0, 4, ss));
       size_t tb = e->scan_tmp_bytes;
-      HIPCHK(e, hipcub::DeviceScan::ExclusiveSum(e->scan_tmp.p, tb, (int*)e->flag.p, (int*)e->rank.p, n + 1, e->stream));
+      HIPCHK(e, hipcub::DeviceScan::ExclusiveSum(e->scan_tmp.p, tb, (int*)e->flag.p, (int*)e->rank.p, n + 1, ss));
       // rank[n] = draws of this shard.  Under a static window (lt_set_rng_window_static: no particle can stop
       // drawing) it is read back once; afterwards the host knows it, the step is enqueued without waiting for the
       // device, and k_post compares the scan's total with it (a mismatch is reported by lt_get_stats /

@@ -610,8 +610,8 @@ struct __attribute__((packed, aligned(4))) RawWords4 { uint32_t a, b, c, d; };
 __global__ __launch_bounds__(256) void k_vt_norm(const StepParams P) {
   __shared__ uint2 rbuf[8][256];
   libm_tables_load<LM_LOG | LM_SINCOS>();
-  const int n = P.part_lo + (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (n >= P.part_hi) return;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= P.numpar) return;
   if (!(P.ws_i[n] & FL_ACT)) return;
   const int loop = P.idt / 2;
   unsigned long long di = P.rng_base + (unsigned long long)(unsigned)P.rank[P.orig[n]];
@@ -724,8 +724,8 @@ LT_DEV void vt_seek_lite(VtLite& c, double T, int n, const double4* tab) {
 #ifdef LT_VT_DEFINE_A
 __global__ __launch_bounds__(LT_VT_WALKFAST_BLOCK) void k_vt_walk_fast(const StepParams P) {
   libm_tables_load<LM_EXP | LM_POW>();  // (pow takes the exp table too)
-  const int n = P.part_lo + (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (n >= P.part_hi) return;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= P.numpar) return;
   const int fl = P.ws_i[n];
   if (!(fl & FL_ACT)) return;
   const int lane = threadIdx.x & 63;
@@ -815,15 +815,10 @@ __global__ __launch_bounds__(LT_VT_WALKFAST_BLOCK) void k_vt_walk_fast(const Ste
 #ifdef LT_VT_DEFINE_B
 __global__ __launch_bounds__(LT_VT_WALK_BLOCK) void k_vt_walk(const StepParams P) {
   const int nlisted = *P.vt_wl_count;
-  // vt_walk_lanes listed walks per wave (the other lanes leave): a wave executes every form any of its walks needs at
-  // a sub-step, and its time is its longest walk's
-  const int L = P.vt_walk_lanes;
-  const int wv0 = (int)((blockIdx.x * blockDim.x) >> 6);
-  if (wv0 * L >= nlisted) return;   // (the whole workgroup: launched for the worst case)
+  if ((int)(blockIdx.x * blockDim.x) >= nlisted) return;   // (the whole workgroup: launched for the worst case)
   libm_tables_load<LM_EXP | LM_POW>();
-  const int ln = threadIdx.x & 63;
-  const int t = (wv0 + (int)(threadIdx.x >> 6)) * L + ln;
-  if (ln >= L || t >= nlisted) return;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nlisted) return;
   // an entry is a particle slot; bit 31: listed by k_vt_sigs (SigErr).  A SigErr particle is walked through ITS entry
   // of k_vt_sigs, from the first sub-step; an entry k_vt_walk_fast made for it (a stop, or the flag seen at its start)
   // is skipped.

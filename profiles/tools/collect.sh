@@ -17,7 +17,7 @@ mkdir -p "$out/summary"
 cd /tmp && export TMPDIR=/tmp
 run() {  # <subdir> <rocprof args...> -- bench args
   local sub=$1; shift
-  timeout -k 10 400 rocprofv3 "$@" --output-format csv -d "$out/$sub" -o r -- python3 "$repo/bench.py" "${BENCH_ARGS[@]}" --no-cpu-baseline --no-hydro-timing --no-turbulence-line > "$out/$sub.log" 2>&1
+  timeout -k 10 400 rocprofv3 "$@" --output-format csv -d "$out/$sub" -o r -- python3 "$repo/bench.py" "${BENCH_ARGS[@]}" --no-cpu-baseline --no-hydro-timing --no-turbulence-line --sustained-steps 0 > "$out/$sub.log" 2>&1
   grep '^{' "$out/$sub.log" > "$out/$sub.bench.json" || true
 }
 BENCH_ARGS=("$@")

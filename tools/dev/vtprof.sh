@@ -6,7 +6,7 @@ for t in "$@"; do
   out=$repo/gpurun_out/vtprof_$t
   mkdir -p $out
   export LT_HIP_LIBRARY=$repo/build/lib_$t.so
-  (cd /tmp && TMPDIR=/tmp timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o r -- python3 $repo/bench.py --turb --steps 8 --warmup 3 --no-cpu-baseline --no-hydro-timing $BENCH_EXTRA > $out/bench.json 2> $out/bench.err) || { echo "$t: failed"; tail -3 $out/bench.err; continue; }
+  (cd /tmp && TMPDIR=/tmp timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o r -- python3 $repo/bench.py --turb --steps 8 --warmup 3 --no-cpu-baseline --no-hydro-timing --sustained-steps 0 $BENCH_EXTRA > $out/bench.json 2> $out/bench.err) || { echo "$t: failed"; tail -3 $out/bench.err; continue; }
   python3 - "$t" "$out" <<'PY'
 import csv, json, sys
 t, out = sys.argv[1], sys.argv[2]
