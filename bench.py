@@ -777,6 +777,11 @@ def main():
                        "slab_storage": args.slab, "kernel_source_hash": lib_hash,
                        "active_last_step": stats["active"], "errors_last_step": stats["errors"],
                        "sigerr_last_step": stats["sigerr"], "slab_rotation_s_excluded": upload_s,
+                       # boundary queries of the last step that left the segment index (a move across more than two of
+                       # its cells: all segments are tested) / point-in-polygon tests that needed the reference's full
+                       # algorithm (a vertex on the ray), VTurb intervals iterated, particle-steps redone by k_rk_slow
+                       "brute_bounds_last_step": stats["brute_bounds"], "pip_full_last_step": stats["pip_full"],
+                       "vt_queued_last_step": stats["vt_queued"], "rk_slow_last_step": stats["rk_slow"],
                        # the device-side re-sort of the particle order (every `resort_every` = 32 steps inside lt_step):
                        # how many fell into the timed region -- they are part of `value` -- and what one costs
                        "clock_prewarm_ms": args.prewarm_ms,

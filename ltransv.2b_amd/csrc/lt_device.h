@@ -47,13 +47,24 @@ struct SegIndex {
   int ncx, ncy;
 };
 
-// y-slab index over polygon edges for the crossings test: bin b lists (ascending)
-// every edge i -> i+1 whose closed y-range overlaps the bin.
+// Slab index over polygon edges for the crossings test (point_in_polygon_module.f90:25-167 casts a ray towards +x and
+// counts the edges that STRADDLE the point's y).  The slabs are the intervals between consecutive distinct vertex
+// ordinates ys[0] < ys[1] < ...: inside one, the edges that straddle y are exactly those that span the whole slab, so
+// slab k lists them (in polygon order) and nothing else -- two wall edges in the interior of a basin, one or two of a
+// coastline however many of its edges lie within a few metres of the point's y.  (Uniform y-bins listed every edge whose
+// y-range touched the bin: a coast running along x put hundreds of edges into the bins next to it, and every particle
+// near that coast scanned them all, every step -- profiles/r05_config5_shard.)  A point whose y EQUALS a vertex ordinate
+// goes to the reference's full algorithm (`slow`).  Lookup: a uniform grid of ncell cells over [ys[0], ys[m-1]] gives the
+// range of ys that can hold the answer (gidx[c] = number of ys whose cell is below c; the cell function is monotone and
+// evaluated identically on the host), a bisection over that range the slab.
 struct PipIndex {
-  const int* ptr;   // (nbins+1)
-  const int* ids;   // 1-based index of the edge's first point
+  const double* ys;    // (m) distinct vertex ordinates, ascending
+  const int* gidx;     // (ncell+1)
+  const int* ptr;      // (m) slab k -> its entries [ptr[k], ptr[k+1]); slab k = (ys[k], ys[k+1]), k < m-1
+  const double4* rec;  // per entry: the edge {x1, y1, x2, y2}
+  const int* pid;      // per entry: id of the edge's polygon (islands: hid), or null
   double y0, inv_h;
-  int nbins;
+  int ncell, m;
 };
 
 // Physical time slots of a slab: the three records in use (back / centre / forward) and a

@@ -43,6 +43,9 @@ struct DevBuf {
 
 struct HostIndex {
   std::vector<int> ptr, ids;
+  // point-in-polygon slab index (lt_device.h: PipIndex)
+  std::vector<double> ys, rec;   // distinct vertex ordinates; {x1, y1, x2, y2} per list entry
+  std::vector<int> gidx, pid;    // lookup grid; the polygon's id per list entry (islands)
 };
 
 }  // namespace
@@ -61,7 +64,7 @@ struct lt_engine {
   bool slab_set[4] = {false, false, false, false};
   int t_b = 1, t_c = 2, t_f = 3;
   // bounds
-  DevBuf bnd, land, bx, by, hx, hy, hid, seg_ptr, seg_ids, pm_ptr, pm_ids, pi_ptr, pi_ids;
+  DevBuf bnd, land, bx, by, hx, hy, hid, seg_ptr, seg_ids, pm_ptr, pm_ids, pi_ptr, pi_ids, pm_rec, pi_rec, pi_pid, pm_ys, pi_ys;
   int nbounds = 0, maxbound = 0, maxisland = 0, numislands = 0;
   SegIndex seg{};
   PipIndex pip_main{}, pip_isl{};
@@ -409,29 +412,59 @@ void build_seg_index(const double* bnd_x, const double* bnd_y, int nb, SegIndex&
 
 // y-slab edge index of a chain of closed polygons given as consecutive points;
 // `same_poly(i)` tells whether points i and i+1 (0-based) belong to one polygon
+// The slab index of lt_device.h (PipIndex) for the polygon(s) px, py (edge i: point i -> i+1 where same_poly(i)).
+// Returns false when the lists would be unreasonably long (the caller then leaves the index off: full algorithm).
 template <typename F>
-void build_pip_index(const double* py, int npts, F same_poly, PipIndex& I, HostIndex& H) {
-  double ymin = 1e300, ymax = -1e300;
-  for (int i = 0; i < npts; i++) { ymin = std::min(ymin, py[i]); ymax = std::max(ymax, py[i]); }
-  if (npts == 0) { ymin = 0.0; ymax = 1.0; }
-  int nb = std::min(8192, std::max(16, npts / 2));
-  double h = (ymax - ymin) / nb;
-  if (!(h > 0.0)) h = 1.0;
-  I.y0 = ymin; I.inv_h = 1.0 / h; I.nbins = nb;
-  auto bin = [&](double y) { double f = std::floor((y - I.y0) * I.inv_h); return (int)std::min<double>(std::max(f, 0.0), nb - 1); };
-  std::vector<std::vector<int>> bins(nb);
-  for (int i = 0; i + 1 < npts; i++) {
-    if (!same_poly(i)) continue;
-    int b0 = bin(std::min(py[i], py[i + 1])), b1 = bin(std::max(py[i], py[i + 1]));
-    for (int b = b0; b <= b1; b++) bins[b].push_back(i + 1);
+bool build_pip_index(const double* px, const double* py, const int32_t* polyid, int npts, F same_poly, PipIndex& I, HostIndex& H) {
+  H.ys.clear(); H.gidx.clear(); H.ptr.clear(); H.ids.clear(); H.rec.clear(); H.pid.clear();
+  std::vector<int> edges;
+  for (int i = 0; i + 1 < npts; i++)
+    if (same_poly(i)) edges.push_back(i);
+  for (int i : edges) { H.ys.push_back(py[i]); H.ys.push_back(py[i + 1]); }
+  std::sort(H.ys.begin(), H.ys.end());
+  H.ys.erase(std::unique(H.ys.begin(), H.ys.end()), H.ys.end());
+  const int m = (int)H.ys.size();
+  I.m = m; I.ncell = 1; I.y0 = m ? H.ys[0] : 0.0; I.inv_h = 1.0;
+  if (m < 2) {   // no edge with a y-extent: nothing can be crossed
+    H.ys.resize(2, 0.0); H.gidx.assign(2, 0); H.ptr.assign(2, 0);
+    I.m = 0;
+    return true;
   }
-  H.ptr.assign(nb + 1, 0);
-  H.ids.clear();
-  for (int b = 0; b < nb; b++) {
-    H.ptr[b] = (int)H.ids.size();
-    H.ids.insert(H.ids.end(), bins[b].begin(), bins[b].end());
+  // entries: edge e spans the slabs k0 .. k1-1 between its two ordinates
+  std::vector<std::vector<int>> slab((size_t)m - 1);
+  size_t total = 0;
+  for (int i : edges) {
+    const double lo = std::min(py[i], py[i + 1]), hi = std::max(py[i], py[i + 1]);
+    const int k0 = (int)(std::lower_bound(H.ys.begin(), H.ys.end(), lo) - H.ys.begin());
+    const int k1 = (int)(std::lower_bound(H.ys.begin(), H.ys.end(), hi) - H.ys.begin());
+    total += (size_t)(k1 - k0);
+    if (total > ((size_t)1 << 24)) return false;
+    for (int k = k0; k < k1; k++) slab[(size_t)k].push_back(i + 1);   // (edges visited in ascending i: polygon order)
   }
-  H.ptr[nb] = (int)H.ids.size();
+  H.ptr.assign((size_t)m, 0);
+  for (int k = 0; k + 1 < m; k++) {
+    H.ptr[(size_t)k] = (int)H.ids.size();
+    for (int i1 : slab[(size_t)k]) {   // (i1 = 1-based index of the edge's first point)
+      H.ids.push_back(i1);
+      H.rec.push_back(px[i1 - 1]); H.rec.push_back(py[i1 - 1]); H.rec.push_back(px[i1]); H.rec.push_back(py[i1]);
+      H.pid.push_back(polyid ? polyid[i1 - 1] : 0);
+    }
+  }
+  H.ptr[(size_t)m - 1] = (int)H.ids.size();
+  // the lookup grid: cell(y) = floor((y - y0) * inv_h), clamped -- monotone in y, the same expression as pip_slab's
+  const int ncell = std::min(1 << 17, std::max(16, 4 * m));
+  const double h = (H.ys[(size_t)m - 1] - H.ys[0]) / ncell;
+  I.ncell = ncell; I.y0 = H.ys[0]; I.inv_h = 1.0 / h;
+  auto cell = [&](double y) { const double f = std::floor((y - I.y0) * I.inv_h); return (f < 0.0) ? 0 : (f >= (double)ncell ? ncell - 1 : (int)f); };
+  H.gidx.assign((size_t)ncell + 1, 0);
+  {
+    int j = 0;
+    for (int c = 0; c <= ncell; c++) {   // gidx[c] = number of ys whose cell is below c
+      while (j < m && cell(H.ys[(size_t)j]) < c) j++;
+      H.gidx[(size_t)c] = j;
+    }
+  }
+  return true;
 }
 
 template <typename SlabT>
@@ -1138,7 +1171,7 @@ int lt_destroy(lt_engine* e) {
   DevBuf* bufs[] = {&e->rnode, &e->unode, &e->vnode, &e->RE, &e->UE, &e->VE, &e->rAdj, &e->uAdj,
                     &e->vAdj, &e->lev, &e->fsR, &e->fsU, &e->fsV, &e->fsVU, &e->U, &e->V, &e->W, &e->Kh, &e->zeta, &e->staging, &e->stage_rom, &e->rmask, &e->umask, &e->vmask,
                     &e->flags, &e->bnd, &e->land, &e->bx, &e->by, &e->hx, &e->hy, &e->hid,
-                    &e->seg_ptr, &e->seg_ids, &e->pm_ptr, &e->pm_ids, &e->pi_ptr, &e->pi_ids,
+                    &e->seg_ptr, &e->seg_ids, &e->pm_ptr, &e->pm_ids, &e->pi_ptr, &e->pi_ids, &e->pm_rec, &e->pi_rec, &e->pi_pid, &e->pm_ys, &e->pi_ys,
                     &e->polys, &e->holes, &e->polyspecs, &e->holespecs, &e->maxbdis, &e->maxhdis,
                     &e->ep_ptr, &e->ep_ids, &e->ph_ptr, &e->ph_ids, &e->par, &e->pr, &e->pu,
                     &e->pv, &e->P_behave, &e->dead, &e->oob, &e->settle, &e->endpoly,
@@ -1348,9 +1381,10 @@ int lt_set_bounds(lt_engine* e, const lt_bounds* b) {
   }
   HostIndex hs, hm, hi;
   build_seg_index(b->bnd_x, b->bnd_y, b->nbounds, e->seg, hs);
-  build_pip_index(b->by, b->maxbound, [](int) { return true; }, e->pip_main, hm);
   const int32_t* hid = b->hid;
-  build_pip_index(b->hy, b->maxisland, [hid](int i) { return hid[i] == hid[i + 1]; }, e->pip_isl, hi);
+  const bool pip_ok = build_pip_index(b->bx, b->by, nullptr, b->maxbound, [](int) { return true; }, e->pip_main, hm) &&
+                      build_pip_index(b->hx, b->hy, hid, b->maxisland, [hid](int i) { return hid[i] == hid[i + 1]; }, e->pip_isl, hi);
+  if (!pip_ok) e->use_pip_index = 0;   // (polygons whose slab lists would not fit: the reference's full algorithm)
   TRY(upload(e, e->bnd, seg.data(), seg.size() * 8));
   TRY(upload(e, e->land, b->land, (size_t)b->nbounds * 4));
   TRY(upload(e, e->bx, b->bx, (size_t)b->maxbound * 8));
@@ -1361,12 +1395,19 @@ int lt_set_bounds(lt_engine* e, const lt_bounds* b) {
   TRY(upload(e, e->seg_ptr, hs.ptr.data(), hs.ptr.size() * 4));
   TRY(upload(e, e->seg_ids, hs.ids.data(), hs.ids.size() * 4));
   TRY(upload(e, e->pm_ptr, hm.ptr.data(), hm.ptr.size() * 4));
-  TRY(upload(e, e->pm_ids, hm.ids.data(), hm.ids.size() * 4));
+  TRY(upload(e, e->pm_ids, hm.gidx.data(), hm.gidx.size() * 4));
   TRY(upload(e, e->pi_ptr, hi.ptr.data(), hi.ptr.size() * 4));
-  TRY(upload(e, e->pi_ids, hi.ids.data(), hi.ids.size() * 4));
+  TRY(upload(e, e->pi_ids, hi.gidx.data(), hi.gidx.size() * 4));
+  TRY(upload(e, e->pm_rec, hm.rec.data(), hm.rec.size() * 8));
+  TRY(upload(e, e->pi_rec, hi.rec.data(), hi.rec.size() * 8));
+  TRY(upload(e, e->pi_pid, hi.pid.data(), hi.pid.size() * 4));
+  TRY(upload(e, e->pm_ys, hm.ys.data(), hm.ys.size() * 8));
+  TRY(upload(e, e->pi_ys, hi.ys.data(), hi.ys.size() * 8));
   e->seg.ptr = (const int*)e->seg_ptr.p; e->seg.ids = (const int*)e->seg_ids.p;
-  e->pip_main.ptr = (const int*)e->pm_ptr.p; e->pip_main.ids = (const int*)e->pm_ids.p;
-  e->pip_isl.ptr = (const int*)e->pi_ptr.p; e->pip_isl.ids = (const int*)e->pi_ids.p;
+  e->pip_main.ptr = (const int*)e->pm_ptr.p; e->pip_main.gidx = (const int*)e->pm_ids.p;
+  e->pip_isl.ptr = (const int*)e->pi_ptr.p; e->pip_isl.gidx = (const int*)e->pi_ids.p;
+  e->pip_main.rec = (const double4*)e->pm_rec.p; e->pip_main.pid = nullptr; e->pip_main.ys = (const double*)e->pm_ys.p;
+  e->pip_isl.rec = (const double4*)e->pi_rec.p; e->pip_isl.pid = (const int*)e->pi_pid.p; e->pip_isl.ys = (const double*)e->pi_ys.p;
   e->nbounds = b->nbounds; e->maxbound = b->maxbound; e->maxisland = b->maxisland;
   e->numislands = b->numislands;
   HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -2242,29 +2283,33 @@ int lt_test_inpoly(const double* px, const double* py, int32_t npts, const doubl
                    const int32_t* onin, int32_t nq, int32_t* out_full, int32_t* out_index, int32_t* out_slow) {
   if (!px || !py || npts < 3 || !qx || !qy || !onin || nq < 0) return LT_ERR_ARG;
   PipIndex I; HostIndex H;
-  build_pip_index(py, npts, [](int) { return true; }, I, H);
-  double *dpx, *dpy, *dqx, *dqy; int *dptr, *dids, *donin, *o1, *o2, *o3;
+  if (!build_pip_index(px, py, nullptr, npts, [](int) { return true; }, I, H)) return LT_ERR_ARG;
+  double *dpx, *dpy, *dqx, *dqy, *drec = nullptr, *dys = nullptr; int *dptr, *dids, *donin, *o1, *o2, *o3;
+  if (hipMalloc(&drec, H.rec.size() * 8 + 32) != hipSuccess || hipMalloc(&dys, H.ys.size() * 8 + 32) != hipSuccess) return LT_ERR_NOMEM;
+  (void)hipMemcpy(drec, H.rec.data(), H.rec.size() * 8, hipMemcpyHostToDevice);
+  (void)hipMemcpy(dys, H.ys.data(), H.ys.size() * 8, hipMemcpyHostToDevice);
   const size_t nb = (size_t)npts * 8, qb = (size_t)nq * 8 + 8, ib = (size_t)nq * 4 + 4;
   if (hipMalloc(&dpx, nb) != hipSuccess || hipMalloc(&dpy, nb) != hipSuccess || hipMalloc(&dqx, qb) != hipSuccess ||
       hipMalloc(&dqy, qb) != hipSuccess || hipMalloc(&dptr, H.ptr.size() * 4 + 4) != hipSuccess ||
-      hipMalloc(&dids, H.ids.size() * 4 + 4) != hipSuccess || hipMalloc(&donin, ib) != hipSuccess ||
+      hipMalloc(&dids, H.gidx.size() * 4 + 4) != hipSuccess || hipMalloc(&donin, ib) != hipSuccess ||
       hipMalloc(&o1, ib) != hipSuccess || hipMalloc(&o2, ib) != hipSuccess || hipMalloc(&o3, ib) != hipSuccess)
     return LT_ERR_NOMEM;
   (void)hipMemcpy(dpx, px, nb, hipMemcpyHostToDevice); (void)hipMemcpy(dpy, py, nb, hipMemcpyHostToDevice);
   (void)hipMemcpy(dqx, qx, (size_t)nq * 8, hipMemcpyHostToDevice); (void)hipMemcpy(dqy, qy, (size_t)nq * 8, hipMemcpyHostToDevice);
   (void)hipMemcpy(donin, onin, (size_t)nq * 4, hipMemcpyHostToDevice);
   (void)hipMemcpy(dptr, H.ptr.data(), H.ptr.size() * 4, hipMemcpyHostToDevice);
-  (void)hipMemcpy(dids, H.ids.data(), H.ids.size() * 4, hipMemcpyHostToDevice);
+  (void)hipMemcpy(dids, H.gidx.data(), H.gidx.size() * 4, hipMemcpyHostToDevice);
   StepParams P;
   memset(&P, 0, sizeof(P));
   P.bx = dpx; P.by = dpy; P.maxbound = npts;
-  P.pip_main = I; P.pip_main.ptr = dptr; P.pip_main.ids = dids;
+  P.pip_main = I; P.pip_main.ptr = dptr; P.pip_main.gidx = dids; P.pip_main.rec = (const double4*)drec; P.pip_main.pid = nullptr;
+  P.pip_main.ys = dys;
   if (nq) hipLaunchKernelGGL(k_test_inpoly, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, 0, P, dqx, dqy, donin, (int)nq, o1, o2, o3);
   const hipError_t rc = hipDeviceSynchronize();
   (void)hipMemcpy(out_full, o1, (size_t)nq * 4, hipMemcpyDeviceToHost);
   (void)hipMemcpy(out_index, o2, (size_t)nq * 4, hipMemcpyDeviceToHost);
   (void)hipMemcpy(out_slow, o3, (size_t)nq * 4, hipMemcpyDeviceToHost);
-  for (void* q : {(void*)dpx, (void*)dpy, (void*)dqx, (void*)dqy, (void*)dptr, (void*)dids, (void*)donin, (void*)o1, (void*)o2, (void*)o3}) (void)hipFree(q);
+  for (void* q : {(void*)dpx, (void*)dpy, (void*)dqx, (void*)dqy, (void*)dptr, (void*)dids, (void*)donin, (void*)o1, (void*)o2, (void*)o3, (void*)drec, (void*)dys}) (void)hipFree(q);
   return rc == hipSuccess ? LT_OK : LT_ERR_DEVICE;
 }
 

@@ -314,22 +314,34 @@ LT_DEV int pip_edge(double x, double y, double x1, double y1, double x2, double 
   return (ix > x) ? 1 : 0;
 }
 
-// mbounds (boundary_module.f90:1515-1540) through the y-slab index; `slow` is
+// the slab of y in a PipIndex (lt_device.h): k with ys[k] < y < ys[k+1], or -1 when y lies outside every edge's
+// y-range (no edge can be crossed); `slow` when y equals a vertex ordinate
+LT_DEV int pip_slab(const PipIndex& ix, double y, bool& slow) {
+  if (ix.m < 2 || !(y >= ix.ys[0])) return -1;          // (below the polygon, or NaN)
+  double fc = floor((y - ix.y0) * ix.inv_h);
+  const int c = (fc < 0.0) ? 0 : (fc >= (double)ix.ncell ? ix.ncell - 1 : (int)fc);
+  // the largest k with ys[k] <= y lies in [gidx[c] - 1, gidx[c + 1] - 1]
+  int lo = ix.gidx[c] - 1, hi = ix.gidx[c + 1] - 1;
+  if (lo < 0) lo = 0;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (ix.ys[mid] <= y) lo = mid; else hi = mid - 1;
+  }
+  if (ix.ys[lo] == y) { slow = true; return -1; }
+  return (lo < ix.m - 1) ? lo : -1;                      // (above the last vertex: outside)
+}
+
+// mbounds (boundary_module.f90:1515-1540) through the slab index; `slow` is
 // set when a vertex shares the particle's y exactly (then the full algorithm
 // must decide).
 LT_DEV bool mbounds_indexed(const StepParams& P, double x, double y, bool& slow) {
   const PipIndex& ix = P.pip_main;
-  double fb = floor((y - ix.y0) * ix.inv_h);
-  int b = (fb < 0.0) ? 0 : (fb >= (double)ix.nbins ? ix.nbins - 1 : (int)fb);
+  const int k = pip_slab(ix, y, slow);
+  if (k < 0) return false;
   int crossed = 0;
-  for (int q = ix.ptr[b]; q < ix.ptr[b + 1]; q++) {
-    int i = ix.ids[q];
-    double x1 = P.bx[i - 1], y1 = P.by[i - 1], x2 = P.bx[i], y2 = P.by[i];
-    if (y1 == y || y2 == y) {
-      slow = true;
-      return false;
-    }
-    int r = pip_edge(x, y, x1, y1, x2, y2);
+  for (int q = ix.ptr[k]; q < ix.ptr[k + 1]; q++) {
+    const double4 e = ix.rec[q];
+    int r = pip_edge(x, y, e.x, e.y, e.z, e.w);
     if (r == 2) return true;
     crossed += r;
   }
@@ -339,23 +351,18 @@ LT_DEV bool mbounds_indexed(const StepParams& P, double x, double y, bool& slow)
 // ibounds (boundary_module.f90:1548-1614): inside ANY island?
 LT_DEV bool ibounds_indexed(const StepParams& P, double x, double y, bool& slow) {
   const PipIndex& ix = P.pip_isl;
-  double fb = floor((y - ix.y0) * ix.inv_h);
-  int b = (fb < 0.0) ? 0 : (fb >= (double)ix.nbins ? ix.nbins - 1 : (int)fb);
+  const int k = pip_slab(ix, y, slow);
+  if (k < 0) return false;
   int cur = -1, crossed = 0;
-  for (int q = ix.ptr[b]; q < ix.ptr[b + 1]; q++) {
-    int i = ix.ids[q];
-    int id = P.hid[i - 1];
+  for (int q = ix.ptr[k]; q < ix.ptr[k + 1]; q++) {
+    const int id = ix.pid[q];
     if (id != cur) {
       if (crossed & 1) return true;
       cur = id;
       crossed = 0;
     }
-    double x1 = P.hx[i - 1], y1 = P.hy[i - 1], x2 = P.hx[i], y2 = P.hy[i];
-    if (y1 == y || y2 == y) {
-      slow = true;
-      return false;
-    }
-    int r = pip_edge(x, y, x1, y1, x2, y2);
+    const double4 e = ix.rec[q];
+    int r = pip_edge(x, y, e.x, e.y, e.z, e.w);
     if (r == 2) return true;
     crossed += r;
   }

@@ -9,6 +9,13 @@ __global__ __launch_bounds__(256) void k_post(const StepParams P) {
 #endif
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned c_err = 0, c_brute = 0, c_pipslow = 0;
+#if defined(LT_POST_TIMING) && defined(LT_RK_TIMING)
+  // development aid (tools/dev/post_sections.py): wave cycles per part of the kernel, summed into g_tim[0..6]
+  unsigned long long pt_acc[7] = {0, 0, 0, 0, 0, 0, 0}, pt_prev = __builtin_readcyclecounter();
+#define PTICK(sec) do { const unsigned long long t_ = __builtin_readcyclecounter(); pt_acc[sec] += t_ - pt_prev; pt_prev = t_; } while (0)
+#else
+#define PTICK(sec) do { } while (0)
+#endif
   __shared__ EleScratch esc[4];
   __shared__ double s_hamp;   // HTurb's amplitude (2/r*KM*idt)**0.5 -- the same for every particle: libm's pow once per workgroup
   if (P.HTurbOn) {
@@ -155,6 +162,7 @@ __global__ __launch_bounds__(256) void k_post(const StepParams P) {
         newZpos = P_depth + (double)0.000001f;
         if (P.TrackCollisions) P.hitBottom[n] += 1;
       }
+      PTICK(0);
       // horizontal boundaries :1180-1232
       double Xpos = X, Ypos = Y, nXpos = newXpos, nYpos = newYpos;
       int skipbound = -1, reflects = 0;
@@ -179,6 +187,7 @@ __global__ __launch_bounds__(256) void k_post(const StepParams P) {
         }
         Xpos = H.fix; Ypos = H.fiy; nXpos = H.frx; nYpos = H.fry;
       }
+      PTICK(1);
       if (!done) {
         newXpos = nXpos;
         newYpos = nYpos;
@@ -194,6 +203,7 @@ __global__ __launch_bounds__(256) void k_post(const StepParams P) {
           c_pipslow += 1;
           inb = inpoly_full(newXpos, newYpos, P.maxbound, P.bx, P.by, false);
         }
+        PTICK(2);
         if (!inb) {
           err = 25;
         } else {
@@ -218,9 +228,11 @@ __global__ __launch_bounds__(256) void k_post(const StepParams P) {
       }
     }
   }
+  PTICK(3);
   // Part 2: setEle :1317
   bool okr2, oku2, okv2;
   wave_set_ele(P, esc[threadIdx.x >> 6], want_ele, eX, eY, er, eu, ev, rn0, un0, vn0, okr2, oku2, okv2);
+  PTICK(4);
   // Part 3
   if (inrange) {
     if (want_ele) {
@@ -266,6 +278,13 @@ __global__ __launch_bounds__(256) void k_post(const StepParams P) {
     if (set_lifespan) PARV(pLifespan) = lifespan;
 #undef PARV
   }
+  PTICK(5);
+#if defined(LT_POST_TIMING) && defined(LT_RK_TIMING)
+  if ((threadIdx.x & 63) == 0) {
+    for (int q = 0; q < 6; q++) atomicAdd(&g_tim[q], pt_acc[q]);
+    atomicAdd(&g_tim[7], 1ull);
+  }
+#endif
   __shared__ unsigned red[3];
   if (threadIdx.x < 3) red[threadIdx.x] = 0;
   if (blockIdx.x == 0) {  // total of k_pre's per-block counts of tracked particles
