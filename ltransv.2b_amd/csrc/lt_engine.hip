@@ -2313,6 +2313,31 @@ int lt_test_inpoly(const double* px, const double* py, int32_t npts, const doubl
   return rc == hipSuccess ? LT_OK : LT_ERR_DEVICE;
 }
 
+/* test aid (HOST only, no device): the slab index of the point-in-polygon tests (lt_device.h: PipIndex) built as
+ * lt_set_bounds builds it and queried by the very functions the kernels call (pip_slab, pip_edge: host-callable), for
+ * one polygon (polyid = NULL: mbounds' form) or several (polyid(npts): ibounds' form, "inside any").  out_in[q] = 0/1
+ * where the index decides, out_slow[q] = 1 where it hands over to the reference's full algorithm.  Returns the number
+ * of list entries, or a negative status. */
+int lt_test_pip_index_host(const double* px, const double* py, const int32_t* polyid, int32_t npts, const double* qx,
+                           const double* qy, int32_t nq, int32_t* out_in, int32_t* out_slow) {
+  if (!px || !py || npts < 2 || !qx || !qy || nq < 0 || !out_in || !out_slow) return LT_ERR_ARG;
+  PipIndex I; HostIndex H;
+  const bool ok = polyid ? build_pip_index(px, py, polyid, npts, [polyid](int i) { return polyid[i] == polyid[i + 1]; }, I, H)
+                         : build_pip_index(px, py, nullptr, npts, [](int) { return true; }, I, H);
+  if (!ok) return LT_ERR_UNSUPPORTED;
+  std::vector<double4> rec4(H.ids.size() + 1);   // (double4's own alignment)
+  for (size_t k = 0; k < H.ids.size(); k++) rec4[k] = make_double4(H.rec[4 * k], H.rec[4 * k + 1], H.rec[4 * k + 2], H.rec[4 * k + 3]);
+  H.pid.resize(H.pid.size() + 1, 0);
+  I.ys = H.ys.data(); I.gidx = H.gidx.data(); I.ptr = H.ptr.data(); I.rec = rec4.data(); I.pid = H.pid.data();
+  for (int q = 0; q < nq; q++) {
+    bool slow = false;
+    const bool in = polyid ? ltd::pip_any_polygon(I, qx[q], qy[q], slow) : ltd::pip_one_polygon(I, qx[q], qy[q], slow);
+    out_in[q] = in ? 1 : 0;
+    out_slow[q] = slow ? 1 : 0;
+  }
+  return (int)H.ids.size();
+}
+
 /* test aid (device): N-knot tension splines (N = 4*ws in VTurb) through the forms the VTurb kernels use: the
  * streaming YPC1 of k_vt_table (ypc1_end / ypc1_mid in knot order), its screening of every interval
  * (sigs_eval_zero) with the task-list iteration of k_vt_sigs (sigs_classify + sigs_newton / sigs_secant), the

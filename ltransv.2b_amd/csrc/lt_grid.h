@@ -302,7 +302,7 @@ __device__ __noinline__ bool inpoly_full(double x, double y, int n, const double
 
 // crossings test of ONE edge (point_in_polygon_module.f90:125-160).
 // returns 0 no crossing, 1 crossing, 2 point lies on the edge
-LT_DEV int pip_edge(double x, double y, double x1, double y1, double x2, double y2) {
+LT_HD int pip_edge(double x, double y, double x1, double y1, double x2, double y2) {
   if (x1 <= x && x2 <= x) return 0;
   if (y1 <= y && y2 <= y) return 0;
   if (y1 >= y && y2 >= y) return 0;
@@ -316,7 +316,7 @@ LT_DEV int pip_edge(double x, double y, double x1, double y1, double x2, double 
 
 // the slab of y in a PipIndex (lt_device.h): k with ys[k] < y < ys[k+1], or -1 when y lies outside every edge's
 // y-range (no edge can be crossed); `slow` when y equals a vertex ordinate
-LT_DEV int pip_slab(const PipIndex& ix, double y, bool& slow) {
+LT_HD int pip_slab(const PipIndex& ix, double y, bool& slow) {
   if (ix.m < 2 || !(y >= ix.ys[0])) return -1;          // (below the polygon, or NaN)
   double fc = floor((y - ix.y0) * ix.inv_h);
   const int c = (fc < 0.0) ? 0 : (fc >= (double)ix.ncell ? ix.ncell - 1 : (int)fc);
@@ -334,8 +334,7 @@ LT_DEV int pip_slab(const PipIndex& ix, double y, bool& slow) {
 // mbounds (boundary_module.f90:1515-1540) through the slab index; `slow` is
 // set when a vertex shares the particle's y exactly (then the full algorithm
 // must decide).
-LT_DEV bool mbounds_indexed(const StepParams& P, double x, double y, bool& slow) {
-  const PipIndex& ix = P.pip_main;
+LT_HD bool pip_one_polygon(const PipIndex& ix, double x, double y, bool& slow) {
   const int k = pip_slab(ix, y, slow);
   if (k < 0) return false;
   int crossed = 0;
@@ -348,9 +347,10 @@ LT_DEV bool mbounds_indexed(const StepParams& P, double x, double y, bool& slow)
   return (crossed & 1) != 0;
 }
 
+LT_DEV bool mbounds_indexed(const StepParams& P, double x, double y, bool& slow) { return pip_one_polygon(P.pip_main, x, y, slow); }
+
 // ibounds (boundary_module.f90:1548-1614): inside ANY island?
-LT_DEV bool ibounds_indexed(const StepParams& P, double x, double y, bool& slow) {
-  const PipIndex& ix = P.pip_isl;
+LT_HD bool pip_any_polygon(const PipIndex& ix, double x, double y, bool& slow) {
   const int k = pip_slab(ix, y, slow);
   if (k < 0) return false;
   int cur = -1, crossed = 0;
@@ -368,6 +368,8 @@ LT_DEV bool ibounds_indexed(const StepParams& P, double x, double y, bool& slow)
   }
   return (crossed & 1) != 0;
 }
+
+LT_DEV bool ibounds_indexed(const StepParams& P, double x, double y, bool& slow) { return pip_any_polygon(P.pip_isl, x, y, slow); }
 
 // ibounds by the reference's own island loop (slow path)
 __device__ __noinline__ bool ibounds_full(const double* hx, const double* hy, const int* hid,

@@ -28,6 +28,7 @@
 namespace ltd {
 
 #define LT_DEV __device__ __forceinline__
+#define LT_HD __host__ __device__ __forceinline__   // (also callable from the host: the test build checks such code without a GPU)
 #define LT_DEV_NOINLINE __device__ __noinline__
 
 // RTOL = 200*eps computed by the STORE loop, tension_module.f90:433-439:
