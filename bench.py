@@ -670,9 +670,28 @@ def main():
             sys.stderr.write("bench.py: --emulate-rank needs a workload with a static stream window\n")
             return 2, None
 
+        # The per-step exchange of the shards' draw counts: inside the library (lt_exchange_rng_window: ncclAllGather of
+        # one int64 per rank on the engine's own RCCL communicator, whose id travels over torch.distributed once) where
+        # every rank has a GPU of its own; through torch.distributed (sharding.rng_window: one host read per step) in
+        # the gloo rehearsals, where the ranks share a card and RCCL refuses a second rank on a device.
+        abi_exchange = False
+        if world > 1 and draws and not static_window and backend == "nccl" and not os.environ.get("LT_BENCH_TORCH_EXCHANGE"):
+            try:
+                box = [e.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                e.comm_init(box[0], world, rank)
+                abi_exchange = True
+            except Exception as ex:      # noqa: BLE001 -- the torch path below does the same job
+                sys.stderr.write(f"bench.py: rank {rank}: lt_comm_init failed ({ex}); exchanging through torch.distributed\n")
+            ok_t = torch.tensor([1 if abi_exchange else 0], dtype=torch.int64, device=coll_dev)
+            dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)      # (the choice is the job's: every rank or none)
+            abi_exchange = bool(int(ok_t.item()))
+
         def one_step():
             ix = st.next_times()
-            if world > 1 and draws and not static_window:
+            if abi_exchange:
+                e.exchange_rng_window(st.ex, ix, st.p, st.it)
+            elif world > 1 and draws and not static_window:
                 if 1 <= spec["behavior"] <= 5:   # data-dependent number of deviates: count draws
                     mine = e.count_draws(st.ex, ix, st.p, st.it)
                     before, total = sharding.rng_window(dist, torch, mine, world, rank, device=coll_dev)
@@ -790,7 +809,8 @@ def main():
                        # timed region, in seconds: add it to the region's wall time for the steady-state figure
                        "resort_s_excluded": resort_excl,
                        "rng_window": (("static (validated on the device every step)" if static_window
-                                       else "exchanged per step") if draws else None),
+                                       else ("exchanged per step by lt_exchange_rng_window (RCCL inside the library)" if abi_exchange
+                                             else "exchanged per step")) if draws else None),
                        "collective_backend": (backend if world > 1 else None), "device_index": dev_index,
                        "setup_s": setup_s},
             "roofline": roofline_block(args.slab, spec["turb"], us + 1, n, k_avg_s, wall / args.steps, traffic, traffic_src,

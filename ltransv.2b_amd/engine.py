@@ -469,6 +469,22 @@ class Engine:
         f.restype = C.c_int
         self._check(f(self._h, str(path).encode(), int(nranks), int(rank), int(timeout_s)), "comm_init_file")
 
+    def comm_unique_id(self):
+        """lt_comm_unique_id: RCCL's 128-byte id (rank 0 makes it, every rank passes it to comm_init)"""
+        buf = (C.c_ubyte * 128)()
+        f = self.lib.lt_comm_unique_id
+        f.restype = C.c_int
+        rc = f(buf)
+        if rc != 0:
+            raise LtError(rc, "lt_comm_unique_id")
+        return bytes(buf)
+
+    def comm_init(self, id128, nranks, rank):
+        f = self.lib.lt_comm_init
+        f.restype = C.c_int
+        buf = (C.c_ubyte * 128).from_buffer_copy(bytes(id128))
+        self._check(f(self._h, buf, int(nranks), int(rank)), "comm_init")
+
     def allgather_positions(self, counts):
         """-> xyz(sum(counts), 3) of all shards in rank order (host array)"""
         counts = _i4(counts)

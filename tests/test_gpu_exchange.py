@@ -125,14 +125,19 @@ def test_three_shards_through_the_exchange_reproduce_the_unsharded_run(name, bou
     assert full["settle"].sum() > 0 or name != "tiny_settle"
 
 
-def test_exchange_on_a_one_rank_communicator(tmp_path):
+@pytest.mark.parametrize("how", ["file", "id"])
+def test_exchange_on_a_one_rank_communicator(tmp_path, how):
     """the real collective (ncclAllGather of one int64 on the communicator's stream) with the one rank the box allows:
-    exchange + step, every step, equals the plain run; also after a static window, which the exchange ends."""
+    exchange + step, every step, equals the plain run.  The communicator through the id file (the Fortran harness's
+    way) and through lt_comm_unique_id / lt_comm_init (bench.py's way: the id travels over torch.distributed)."""
     steps = 9
     case = _dynamic_case()
     full = _full(case, steps)
     e = cases.make_engine(case, ltrans_amd.Engine, {})
-    e.comm_init_file(tmp_path / "id", 1, 0, timeout_s=20)
+    if how == "file":
+        e.comm_init_file(tmp_path / "id", 1, 0, timeout_s=20)
+    else:
+        e.comm_init(e.comm_unique_id(), 1, 0)
     run = LtransRun(e, 3600, 120, case["record"])
     run.init_hydro()
     ex = run.external_times(1)
