@@ -1259,12 +1259,18 @@ int lt_set_grid(lt_engine* e, const lt_grid* g) {
   TRY(upload(e, e->unode, un.data(), un.size() * sizeof(XYNode)));
   TRY(upload(e, e->vnode, vn.data(), vn.size() * sizeof(XYNode)));
   {
-    // The internal particle order is by TILES of 32 x 32 rho elements (then rows inside a tile): the waves in
+    // The internal particle order is by TILES of 32 x 32 rho elements: the waves in
     // flight on an XCD (each XCD works through a contiguous eighth of the order) then cover a few compact
     // patches whose node columns stay in its L2, where whole rows of elements (the reference's element
     // numbering) put the elements above and below a row hundreds of waves apart.  Row length from an
     // element's own corners: (i,j), (i+1,j), (i+1,j+1), (i,j+1) -> node(4) - node(1) = vi.
     const int T = getenv("LT_TILE") ? std::max(1, atoi(getenv("LT_TILE"))) : 32;   // (LT_TILE: experiments; 16 -> 1.33, 32 -> 1.30, 64 -> 1.29 GB per k_rk launch)
+    // Inside a tile the elements follow a Z curve (r05): the 64 particles of a wave then cover a compact patch (at 2.4
+    // particles per element 27 elements touch ~42 node columns instead of the 56 of a strip along a row), which is
+    // what a sparse shard's k_rk, bound by what it fetches, is sensitive to: configs[3]'s shard 7.19 -> 7.08 ms,
+    // configs[2] 4.47 -> 4.43 ms, configs[1] unchanged.  LT_TILE_ORDER=rows: rows inside the tile, as before.
+    const char* tord = getenv("LT_TILE_ORDER");
+    const bool morton = !(tord && !strcmp(tord, "rows")) && (T & (T - 1)) == 0 && T <= 256;
     const int32_t* RE = g->RE;
     const int vi_row = std::max(2, RE[3] - RE[0]);
     const int ntx = (vi_row + T - 1) / T;
@@ -1272,7 +1278,12 @@ int lt_set_grid(lt_engine* e, const lt_grid* g) {
     int32_t kmax = 0;
     for (int el = 0; el < g->rho_elements; el++) {
       const int n1 = RE[(size_t)el * 4] - 1, i = n1 % vi_row, j = n1 / vi_row;
-      const int32_t key = (((j / T) * ntx + (i / T)) * T + (j % T)) * T + (i % T);
+      int32_t key = (((j / T) * ntx + (i / T)) * T + (j % T)) * T + (i % T);
+      if (morton) {
+        int32_t z = 0;
+        for (int b = 0; b < 8; b++) z |= (((i % T) >> b) & 1) << (2 * b) | (((j % T) >> b) & 1) << (2 * b + 1);
+        key = ((j / T) * ntx + (i / T)) * T * T + z;
+      }
       e->h_tile_key[(size_t)el] = key;
       kmax = std::max(kmax, key);
     }
