@@ -265,7 +265,16 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
   for (int i = threadIdx.x; i < 6 * LT_LEV_STRIDE; i += blockDim.x) lev[i] = P.lev[i];
   exp_table_load();
   if (blockIdx.x == 0 && threadIdx.x == 0) *P.vt_wl_count = 0;  // the walk kernels' list (they run after this one)
+#ifndef LT_VT_NO_XCD_MAP
+  // workgroups go round-robin to the 8 XCDs: XCD x takes the x-th contiguous eighth of the particles (any grid size),
+  // so that the Kh columns its waves stream up are shared in ITS L2 (a shard of configs[3] 7.00 -> 6.98 ms; nothing
+  // at 7.6 particles per element)
+  const unsigned xq_ = gridDim.x >> 3, xr_ = gridDim.x & 7u, xx_ = blockIdx.x & 7u;
+  const unsigned vb_ = xx_ * xq_ + (xx_ < xr_ ? xx_ : xr_) + (blockIdx.x >> 3);
+  const int n = vb_ * blockDim.x + threadIdx.x;
+#else
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
+#endif
   const int lane = threadIdx.x & 63;
   const int wave = n >> 6;
   // (every lane of the wave stays to the end: the task list is filled with wave-wide ballots)
