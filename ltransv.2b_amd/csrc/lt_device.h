@@ -79,6 +79,12 @@ struct PipIndex {
 #define LT_LAYOUT_SLOTFAST 0
 #define LT_LAYOUT_LEVFAST 1
 
+// one knot of VTurb's spline table (lt_vturb.h): abscissa, ordinate, derivative.  The tension factor of the interval
+// that starts at the knot is zero for nine intervals in ten and lives elsewhere: a bit per knot and particle
+// (StepParams::vt_bits) says whether the interval was listed for the SIGS iteration, the factors of those are in
+// StepParams::vt_sig (same indexing as the records, touched only where a bit is set).
+struct VtRec { double x, y, yp; };
+
 // per-wave task lists of VTurb's SIGS iterations (lt_vturb.h)
 struct VtQueue {
   double *S, *S1, *S2;      // [wave][cap]
@@ -162,7 +168,9 @@ struct StepParams {
   const int* orig;                // [numpar] reference index of internal slot i
   long long expect_own;           // >= 0: the shard's draw total the host assumed (static window); k_post checks rank[numpar]
   double* vt_dev;   // the walk's normal deviates [group of 64 particles][idt/2 sub-steps][lane] (k_vt_norm)
-  double4* vt_tab;  // VTurb spline table [wave][4*ws][lane] of {x, y, yp, sigma}
+  VtRec* vt_tab;    // VTurb spline table [wave][4*ws][lane] of {x, y, yp}
+  double* vt_sig;   // [wave][4*ws][lane] tension factor of the interval that starts at the knot -- listed intervals only
+  unsigned long long* vt_bits;   // [wave][4][lane] bit k of the lane's 256: the interval that starts at knot k is listed
   VtQueue vt_q;     // per-wave task lists of the SIGS iterations (lt_vturb.h)
   // the walks that met an interval with a tension factor and are finished by k_vt_walk (lt_vturb.h):
   // their number, the particle slots, the sub-step each resumes at

@@ -157,7 +157,7 @@ struct lt_engine {
   ltmt::BlockJob* rng_jobs = nullptr;  // pinned, mapped: RNG_JOB_SLOTS launches of up to P jobs
   int rng_job_slot = 0;
   std::vector<long long> rng_ring_blk;  // the stream block each ring slot holds (-1: none)
-  DevBuf flag, rank, scan_tmp, vt_tab, vt_qS, vt_qS1, vt_qS2, vt_qwl, vt_qcount, vt_wl, vt_dev, slow_list;
+  DevBuf flag, rank, scan_tmp, vt_tab, vt_bits, vt_qS, vt_qS1, vt_qS2, vt_qwl, vt_qcount, vt_wl, vt_dev, slow_list;
   int vt_qcap = 0;
   size_t scan_tmp_bytes = 0;
   // counters
@@ -349,7 +349,9 @@ void fill_params(lt_engine* e, StepParams& P) {
   P.rng_draws = (c.HTurbOn ? 4 : 0) + (c.VTurbOn ? 2 * (c.idt / 2) : 0);
   P.rank = (const int*)e->rank.p; P.orig = (const int*)e->orig.p;
   P.expect_own = -1;
-  P.vt_tab = (double4*)e->vt_tab.p;
+  P.vt_tab = (VtRec*)e->vt_tab.p;      // records, then the plane of the listed intervals' tension factors
+  P.vt_sig = e->vt_tab.p ? (double*)((char*)e->vt_tab.p + (size_t)4 * e->cfg.ws * (((size_t)e->cfg.numpar + 63) / 64 * 64) * sizeof(VtRec)) : nullptr;
+  P.vt_bits = (unsigned long long*)e->vt_bits.p;
   P.vt_dev = (double*)e->vt_dev.p;
   P.slow_list = (int*)e->slow_list.p;
   P.vt_q.S = (double*)e->vt_qS.p; P.vt_q.S1 = (double*)e->vt_qS1.p; P.vt_q.S2 = (double*)e->vt_qS2.p;
@@ -1177,7 +1179,7 @@ int lt_destroy(lt_engine* e) {
                     &e->pv, &e->P_behave, &e->dead, &e->oob, &e->settle, &e->endpoly,
                     &e->hitBottom, &e->hitLand, &e->err_code, &e->P_swim, &e->P_pediage,
                     &e->P_deadage, &e->settletime, &e->timer, &e->P_Sprev, &e->P_zprev, &e->bottom, &e->P_Salt, &e->P_Temp, &e->S, &e->T, &e->counters, &e->ws_d, &e->ws_i, &e->orig, &e->ele_ok, &e->block_active, &e->get_stage, &e->count_slots, &e->out_cols, &e->out_hits, &e->rng_states, &e->rng_ring, &e->rng_polys, &e->flag, &e->rank, &e->scan_tmp,
-                    &e->vt_tab, &e->vt_qS, &e->vt_qS1, &e->vt_qS2, &e->vt_qwl, &e->vt_qcount, &e->vt_wl, &e->vt_dev, &e->slow_list, &e->sort_keys, &e->sort_keys_in, &e->tile_key, &e->sort_idx_in, &e->sort_idx_out,
+                    &e->vt_tab, &e->vt_bits, &e->vt_qS, &e->vt_qS1, &e->vt_qS2, &e->vt_qwl, &e->vt_qcount, &e->vt_wl, &e->vt_dev, &e->slow_list, &e->sort_keys, &e->sort_keys_in, &e->tile_key, &e->sort_idx_in, &e->sort_idx_out,
                     &e->sort_tmp, &e->permute_tmp};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
@@ -1666,10 +1668,10 @@ int lt_set_particles(lt_engine* e, const lt_particles* p) {
     }
     if (e->cfg.VTurbOn) {
       {
-        // VTurb's working set per particle: 4*ws knots x (32-byte record + 26 bytes of SIGS task slots) + the
-        // idt/2 (+2) deviates + 8 bytes of walk list -- 7.7 KB at ws = 31, 12.3 KB at ws = 51.  Said
+        // VTurb's working set per particle: 4*ws knots x (24-byte record + 8 bytes for a tension factor + 26 bytes of SIGS
+        // task slots) + the idt/2 (+2) deviates + 12 bytes of walk list + 32 bytes of flags -- 7.7 KB at ws = 31, 12.3 KB at ws = 51.  Said
         // here, with the figures, rather than by whichever hipMalloc happens to fail.
-        const size_t per = (size_t)4 * e->cfg.ws * (32 + 26) + (size_t)(std::max(e->cfg.idt / 2, 1) + VT_DEV_HROWS) * 8 + 8;
+        const size_t per = (size_t)4 * e->cfg.ws * (32 + 26) + (size_t)(std::max(e->cfg.idt / 2, 1) + VT_DEV_HROWS) * 8 + 12 + 32;
         const size_t want = per * ((n + 63) / 64 * 64);
         size_t mfree = 0, mtotal = 0;
         if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess && want > mfree)
@@ -1677,8 +1679,9 @@ int lt_set_particles(lt_engine* e, const lt_particles* p) {
                       "(%zu bytes each: spline table, SIGS task lists, deviates) and %.1f GB are free on device %d: shard the "
                       "particles over more engines", want / 1e9, n, (int)e->cfg.ws, per, mfree / 1e9, e->device);
       }
-      // p2 = 4*ws knots per particle, [wave][knot][lane] records {x, y, yp, sigma}
-      TRY(dev_alloc(e, e->vt_tab, (size_t)4 * e->cfg.ws * ((n + 63) / 64 * 64) * 32));
+      // p2 = 4*ws knots per particle, [wave][knot][lane] records {x, y, yp}
+      TRY(dev_alloc(e, e->vt_tab, (size_t)4 * e->cfg.ws * ((n + 63) / 64 * 64) * (sizeof(VtRec) + 8)));   // {x, y, yp} | tension factors
+      TRY(dev_alloc(e, e->vt_bits, ((n + 63) / 64) * 4 * 64 * 8));
       // task lists of the SIGS iterations
       const size_t waves = (n + 63) / 64;
       // (room for every interval of every lane: 4*ws - 1 per profile.  ~9 % of them are listed on the bench
@@ -2355,7 +2358,7 @@ int lt_test_pip_index_host(const double* px, const double* py, const int32_t* po
  * table layout [wave][knot][lane], and the walk's cached-interval evaluation (vt_seek + hval_prepared /
  * hpval_prepared) at 8 points per profile.  in: per profile (n, x[124], y[124], t[8]) = 257 doubles; out: per
  * profile yp[124], sigma[124], SigErr, hval[8], hpval[8] = 265 doubles. */
-__global__ void k_test_spline_n(const double* in, double* out, double4* tab, int nprof, int maxn) {
+__global__ void k_test_spline_n(const double* in, double* out, ltd::VtRec* tab, double* sigp, int nprof, int maxn) {
   using namespace ltd;
   libm_tables_load<LM_EXP>();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2364,58 +2367,63 @@ __global__ void k_test_spline_n(const double* in, double* out, double4* tab, int
   double* o = out + (size_t)i * 265;
   const int n = (int)r[0];
   const double *X = r + 1, *Y = r + 125, *T = r + 249;
-  double4* t = tab + (size_t)(i >> 6) * (size_t)maxn * VT_TS + (size_t)(i & 63);
+  VtRec* t = tab + (size_t)(i >> 6) * (size_t)maxn * VT_TS + (size_t)(i & 63);
+  double* sgp = sigp + (size_t)(i >> 6) * (size_t)maxn * VT_TS + (size_t)(i & 63);
+  VtBits bits{0ull, 0ull, 0ull, 0ull};
   // YPC1 in the stream's order
   double Sp = 0.0, DXp = 0.0, YPp = 0.0;
   bool fail = false;
-  for (int k = 1; k <= n; k++) t[(size_t)(k - 1) * VT_TS] = make_double4(X[k - 1], Y[k - 1], 0.0, 0.0);
+  for (int k = 1; k <= n; k++) { t[(size_t)(k - 1) * VT_TS] = VtRec{X[k - 1], Y[k - 1], 0.0}; sgp[(size_t)(k - 1) * VT_TS] = 0.0; }
   for (int k = 2; k <= n && !fail; k++) {
     const double DX = X[k - 1] - X[k - 2];
     if (DX <= 0.0) { fail = true; break; }
     const double S = div_prep(Y[k - 1] - Y[k - 2], prep_div(DX));
     const Divisor dsum = prep_div(DXp + DX);
-    if (k == 3) { YPp = ypc1_end_b(Sp, Sp + div_prep(DXp * (Sp - S), dsum)); t[0].z = YPp; }
-    if (k >= 3) { const double YPc = ypc1_mid_b(DXp, DX, dsum, Sp, S); t[(size_t)(k - 2) * VT_TS].z = YPc; YPp = YPc; }
-    if (k == n) t[(size_t)(k - 1) * VT_TS].z = ypc1_end_b(S, S + div_prep(DX * (S - Sp), dsum));
+    if (k == 3) { YPp = ypc1_end_b(Sp, Sp + div_prep(DXp * (Sp - S), dsum)); t[0].yp = YPp; }
+    if (k >= 3) { const double YPc = ypc1_mid_b(DXp, DX, dsum, Sp, S); t[(size_t)(k - 2) * VT_TS].yp = YPc; YPp = YPc; }
+    if (k == n) t[(size_t)(k - 1) * VT_TS].yp = ypc1_end_b(S, S + div_prep(DX * (S - Sp), dsum));
     Sp = S; DXp = DX;
   }
   int sigerr = 0;
   if (!fail) {
     for (int k = 0; k < n - 1 && !sigerr; k++) {   // SIGS returns at the first failure: later tensions stay 0
-      const double4 a = t[(size_t)k * VT_TS], b = t[(size_t)(k + 1) * VT_TS];
+      const VtRec a = t[(size_t)k * VT_TS], b = t[(size_t)(k + 1) * VT_TS];
       const double S = (b.y - a.y) / (b.x - a.x);
       double sg = 0.0;
-      if (!sigs_eval_zero(S, a.z, b.z)) {
+      if (!sigs_eval_zero(S, a.yp, b.yp)) {   // a listed interval: its bit, its factor in the plane
         double TT = 0.0;
         bool failed = false;
-        const int kind = sigs_classify(S, a.z, b.z, sg, TT);
+        const int kind = sigs_classify(S, a.yp, b.yp, sg, TT);
         if (kind == SIGK_NEWTON) sg = sigs_newton(TT, failed);
-        else if (kind == SIGK_SECANT) sg = sigs_secant(S, a.z, b.z);
+        else if (kind == SIGK_SECANT) sg = sigs_secant(S, a.yp, b.yp);
         if (failed) { sigerr = 1; sg = 0.0; }
+        const unsigned long long bit = 1ull << (k & 63);
+        if (k < 64) bits.w0 |= bit; else if (k < 128) bits.w1 |= bit; else if (k < 192) bits.w2 |= bit; else bits.w3 |= bit;
+        sgp[(size_t)k * VT_TS] = sg;
       }
-      t[(size_t)k * VT_TS].w = sg;
     }
   }
-  for (int k = 0; k < n; k++) { o[k] = t[(size_t)k * VT_TS].z; o[124 + k] = t[(size_t)k * VT_TS].w; }
+  for (int k = 0; k < n; k++) { o[k] = t[(size_t)k * VT_TS].yp; o[124 + k] = sgp[(size_t)k * VT_TS]; }
   o[248] = (double)sigerr;
   VtInterval ci;
-  ci.I = 0; ci.X1 = ci.X2 = ci.Y1 = ci.Y2 = ci.P1 = ci.P2 = ci.SG = ci.SGhi = 0.0;
+  ci.I = 0; ci.X1 = ci.X2 = ci.Y1 = ci.Y2 = ci.P1 = ci.P2 = ci.SG = 0.0;
   ci.S = ci.D1 = ci.D2 = ci.SM = ci.CM = ci.CMM = 0.0; ci.dx.b = 1.0; ci.dx.y = 1.0;
   for (int j = 0; j < 8; j++) {
-    vt_seek(ci, T[j], n, t);
+    vt_seek(ci, T[j], n, t, sgp, bits);
     o[249 + j] = hval_prepared(T[j], ci);
     o[257 + j] = hpval_prepared(T[j], ci);
   }
 }
 int lt_test_spline_n(const double* in, int32_t nprof, double* out) {
   if (!in || !out || nprof < 0) return LT_ERR_ARG;
-  double *di, *dout; double4* tab;
+  double *di, *dout; ltd::VtRec* tab;
   const size_t bi = (size_t)nprof * 257 * 8 + 8, bo = (size_t)nprof * 265 * 8 + 8;
-  const size_t tb = (size_t)((nprof + 63) / 64) * 124 * 64 * 32 + 32;
+  const size_t cells = (size_t)((nprof + 63) / 64) * 124 * 64;
+  const size_t tb = cells * (sizeof(ltd::VtRec) + 8) + 32;
   if (hipMalloc(&di, bi) != hipSuccess || hipMalloc(&dout, bo) != hipSuccess || hipMalloc(&tab, tb) != hipSuccess) return LT_ERR_NOMEM;
   (void)hipMemcpy(di, in, (size_t)nprof * 257 * 8, hipMemcpyHostToDevice);
   (void)hipMemset(dout, 0, bo);
-  if (nprof) hipLaunchKernelGGL(k_test_spline_n, dim3((unsigned)((nprof + 63) / 64)), dim3(64), 0, 0, di, dout, tab, (int)nprof, 124);
+  if (nprof) hipLaunchKernelGGL(k_test_spline_n, dim3((unsigned)((nprof + 63) / 64)), dim3(64), 0, 0, di, dout, tab, (double*)(tab + cells), (int)nprof, 124);
   const hipError_t rc = hipDeviceSynchronize();
   (void)hipMemcpy(out, dout, (size_t)nprof * 265 * 8, hipMemcpyDeviceToHost);
   (void)hipFree(di); (void)hipFree(dout); (void)hipFree(tab);

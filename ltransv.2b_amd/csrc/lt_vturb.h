@@ -25,16 +25,29 @@ LT_DEV double draw_norm(const StepParams& P, unsigned long long idx) {
 
 // HVAL / HPVAL on a spline table in memory (element k of array a at a[k*stride]),
 // tension_module.f90:980-1253.  `il` caches the last interval like INTRVL's SAVE IL.
-// (tab: the records {x, y, yp, sigma} of one particle, knot k at tab[k * VT_TS]; zero_sig: TSPSI failed
-// before SIGS ran)
-#define VT_TS 64  // table layout [wave][knot][lane]: a wave's records of one knot are 2 KB contiguous
-// what k_vt_table stores as the tension factor of an interval it LISTS for k_vt_sigs (which overwrites it): not zero,
-// so that k_vt_walk_fast -- which may run beside k_vt_sigs -- stops at such an interval whether or not its factor has
-// been written yet.  (A listed interval's factor comes out zero only when T rounds to <= 2 in sigs_classify; such a
-// walk then goes to k_vt_walk, whose cubic form is the same expression: same sums either way.)
-#define VT_SIG_PENDING 1.0
+// (tab: the records {x, y, yp} of one particle, knot k at tab[k * VT_TS].  Used where TSPSI failed before SIGS ran:
+// every tension factor is zero)
+#define VT_TS 64  // table layout [wave][knot][lane]: a wave's records of one knot are 1.5 KB contiguous
+// The tension factor of an interval is not in the record (r05: nine in ten are zero, and a quarter of the table's bytes
+// were theirs).  k_vt_table sets bit k of the particle's 256 (vt_bits) for every interval (k, k+1) it LISTS for
+// k_vt_sigs, which writes the factor to vt_sig[same index as the record]: k_vt_walk_fast -- which may run beside
+// k_vt_sigs -- stops at a listed interval whether or not its factor has been written yet, k_vt_walk reads the factor
+// where the bit is set and takes zero elsewhere.  (A listed interval's factor comes out zero only when T rounds to
+// <= 2 in sigs_classify; such a walk then goes to k_vt_walk, whose cubic form is the same expression: same sums
+// either way.)
+struct VtBits { unsigned long long w0, w1, w2, w3; };
+LT_DEV VtBits vt_bits_load(const StepParams& P, int n) {
+  const unsigned long long* b = P.vt_bits + (size_t)(n >> 6) * 4 * 64 + (size_t)(n & 63);
+  VtBits r;
+  r.w0 = b[0]; r.w1 = b[64]; r.w2 = b[128]; r.w3 = b[192];
+  return r;
+}
+LT_DEV bool vt_bit(const VtBits& b, int k) {   // k = 0-based knot, < 256 (ws <= 64: lt_create)
+  const unsigned long long w = (k < 128) ? ((k < 64) ? b.w0 : b.w1) : ((k < 192) ? b.w2 : b.w3);
+  return ((w >> (k & 63)) & 1ull) != 0ull;
+}
 template <bool DERIV>
-LT_DEV double hval_table(double T, int n, const double4* tab, bool zero_sig, int& il) {
+LT_DEV double hval_table(double T, int n, const VtRec* tab, int& il) {
   int I;
   if (T < tab[0].x) I = 1;
   else if (T > tab[(size_t)(n - 1) * VT_TS].x) I = n - 1;
@@ -52,8 +65,8 @@ LT_DEV double hval_table(double T, int n, const double4* tab, bool zero_sig, int
     }
     I = il;
   }
-  const double4 ra = tab[(size_t)(I - 1) * VT_TS], rb = tab[(size_t)I * VT_TS];
-  const double X1 = ra.x, X2 = rb.x, Y1 = ra.y, Y2 = rb.y, P1 = ra.z, P2 = rb.z, SG = zero_sig ? 0.0 : ra.w;
+  const VtRec ra = tab[(size_t)(I - 1) * VT_TS], rb = tab[(size_t)I * VT_TS];
+  const double X1 = ra.x, X2 = rb.x, Y1 = ra.y, Y2 = rb.y, P1 = ra.yp, P2 = rb.yp, SG = 0.0;
   if (X2 - X1 <= 0.0) return 0.0;  // IER = -2
   if (DERIV) return hpval_interval(T, X1, X2, Y1, Y2, P1, P2, SG);
   return hval_interval(T, X1, X2, Y1, Y2, P1, P2, SG);
@@ -119,7 +132,6 @@ LT_DEV void polintd3x3(const StepParams& P, double ya1, double ya2, double ya3,
 struct VtInterval {
   int I;
   double X1, X2, Y1, Y2, P1, P2, SG;
-  double SGhi;  // tension factor of the interval above (stored with the upper knot)
   double S, D1, D2, SM, CM, CMM;
   Divisor dx;
 };
@@ -181,9 +193,9 @@ LT_DEV double hpval_prepared(double T, const VtInterval& c) {
                 SIG * ((E1 * EMS - E2) * D1 + (E1 - E2 * EMS) * D2)) / E;
   }
 }
-// (a move to the neighbouring interval loads ONE 32-byte record -- the new knot; the knot shared with
+// (a move to the neighbouring interval loads ONE 24-byte record -- the new knot; the knot shared with
 // the old interval is kept)
-LT_DEV bool vt_seek_move(VtInterval& c, double T, int n, const double4* tab) {
+LT_DEV bool vt_seek_move(VtInterval& c, double T, int n, const VtRec* tab) {
   bool moved = false;
   if (c.I == 0) {  // first use: the start of vt_seek_lite (the table is strictly increasing wherever this is called)
     const double xa = tab[0].x, xb = tab[(size_t)(n - 1) * VT_TS].x;
@@ -192,36 +204,40 @@ LT_DEV bool vt_seek_move(VtInterval& c, double T, int n, const double4* tab) {
     if (lo < 1) lo = 1;
     if (lo > n - 1) lo = n - 1;
     c.I = lo;
-    const double4 ra = tab[(size_t)(lo - 1) * VT_TS], rb = tab[(size_t)lo * VT_TS];
-    c.X1 = ra.x; c.Y1 = ra.y; c.P1 = ra.z; c.SG = ra.w;
-    c.X2 = rb.x; c.Y2 = rb.y; c.P2 = rb.z; c.SGhi = rb.w;
+    const VtRec ra = tab[(size_t)(lo - 1) * VT_TS], rb = tab[(size_t)lo * VT_TS];
+    c.X1 = ra.x; c.Y1 = ra.y; c.P1 = ra.yp;
+    c.X2 = rb.x; c.Y2 = rb.y; c.P2 = rb.yp;
     moved = true;
   }
   while (T < c.X1 && c.I > 1) {
     c.I -= 1;
-    const double4 r = tab[(size_t)(c.I - 1) * VT_TS];
-    c.X2 = c.X1; c.Y2 = c.Y1; c.P2 = c.P1; c.SGhi = c.SG;
-    c.X1 = r.x; c.Y1 = r.y; c.P1 = r.z; c.SG = r.w;
+    const VtRec r = tab[(size_t)(c.I - 1) * VT_TS];
+    c.X2 = c.X1; c.Y2 = c.Y1; c.P2 = c.P1;
+    c.X1 = r.x; c.Y1 = r.y; c.P1 = r.yp;
     moved = true;
   }
   while (T >= c.X2 && c.I < n - 1) {
     c.I += 1;
-    const double4 r = tab[(size_t)c.I * VT_TS];
-    c.X1 = c.X2; c.Y1 = c.Y2; c.P1 = c.P2; c.SG = c.SGhi;
-    c.X2 = r.x; c.Y2 = r.y; c.P2 = r.z; c.SGhi = r.w;
+    const VtRec r = tab[(size_t)c.I * VT_TS];
+    c.X1 = c.X2; c.Y1 = c.Y2; c.P1 = c.P2;
+    c.X2 = r.x; c.Y2 = r.y; c.P2 = r.yp;
     moved = true;
   }
   return moved;
 }
-LT_DEV void vt_seek(VtInterval& c, double T, int n, const double4* tab) {
-  if (vt_seek_move(c, T, n, tab)) vt_prepare(c);
+// (sig: the particle's column of vt_sig, indexed like tab; read where the interval's bit is set)
+LT_DEV void vt_seek(VtInterval& c, double T, int n, const VtRec* tab, const double* sig, const VtBits& bits) {
+  if (vt_seek_move(c, T, n, tab)) {
+    c.SG = vt_bit(bits, c.I - 1) ? sig[(size_t)(c.I - 1) * VT_TS] : 0.0;
+    vt_prepare(c);
+  }
 }
 // The walk of a particle whose SIGS failed (SigErr: linint instead of HVAL / HPVAL, ver_turb_module.f90:296-331) on
 // the same cached interval.  linint's bisection (interpolation_module: the j with xa(j) <= x < xa(j+1), the end
 // intervals beyond the ends) and the stepping find the same interval of a strictly increasing table -- and the table is
 // one whenever YPC1 went through, which it did if SIGS ran.  (A bisection from scratch is seven dependent loads, twice
 // per sub-step: the 0.03 % of the particles that take this path were the longest waves of k_vt_walk, 0.2 ms of the step.)
-LT_DEV void vt_seek_plain(VtInterval& c, double T, int n, const double4* tab) { (void)vt_seek_move(c, T, n, tab); }
+LT_DEV void vt_seek_plain(VtInterval& c, double T, int n, const VtRec* tab) { (void)vt_seek_move(c, T, n, tab); }
 LT_DEV void linint_interval(const VtInterval& c, double x, double& y, double& m) {
   m = (c.Y1 - c.Y2) / (c.X1 - c.X2);
   const double b = c.Y1 - m * c.X1;
@@ -247,8 +263,9 @@ LT_DEV void linint_interval(const VtInterval& c, double x, double& y, double& m)
 // the YPC1 derivative of knot k-1 is formed as soon as knot k exists, the interval (k-2, k-1)
 // is classified as soon as both its end derivatives exist -- its tension factor is zero (the
 // usual case), or it goes to the wave's task list -- and knot k-2 goes to
-// HBM as ONE 32-byte record {x, y, yp, sigma}, [wave][knot][lane]: the table is written once, in
-// 2 KB rows per wave and knot (per-lane runs of 32-byte records, [particle][knot], cost 3.6x their
+// HBM as ONE 24-byte record {x, y, yp}, [wave][knot][lane] (r02-r04: 32 bytes with the tension factor; r05: the
+// listed intervals as a bit per knot, their factors in a plane of their own, above): the table is written once, in
+// 1.5 KB rows per wave and knot (per-lane runs of records, [particle][knot], cost 3.6x their
 // size in HBM writes: profiles/r02_calib), and never read back by the build; the walk loads one
 // record per move to a neighbouring interval.  (Four separate arrays, re-read by a SIGS kernel and
 // gathered 8 bytes at a time by the walk, moved 14.9 GB per step for 3.5 GB of algorithmic traffic.)
@@ -262,7 +279,10 @@ template <typename SlabT, int VT, bool FD>
 __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
   __shared__ double lev[6 * LT_LEV_STRIDE];
   __shared__ double wring[3][8][256];
+  __shared__ unsigned long long fbits[4][256];   // the lane's listed intervals (vt_bits), gathered here: no registers
   for (int i = threadIdx.x; i < 6 * LT_LEV_STRIDE; i += blockDim.x) lev[i] = P.lev[i];
+#pragma unroll
+  for (int w = 0; w < 4; w++) fbits[w][threadIdx.x] = 0ull;
   exp_table_load();
   if (blockIdx.x == 0 && threadIdx.x == 0) *P.vt_wl_count = 0;  // the walk kernels' list (they run after this one)
 #ifndef LT_VT_NO_XCD_MAP
@@ -390,8 +410,8 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
 #pragma unroll
     for (int j = 5; j <= 8; j++) wring[s][j & 7][threadIdx.x] = NEWY_AT(s, NEWX(s, j));
   }
-  // table layout: [wave][knot][lane] records {x, y, yp, sigma}; knot k-2 is written at iteration k
-  double4* tab = P.vt_tab + (size_t)(na >> 6) * (size_t)p2 * VT_TS + (size_t)(na & 63);
+  // table layout: [wave][knot][lane] records {x, y, yp}; knot k-2 is written at iteration k
+  VtRec* tab = P.vt_tab + (size_t)(na >> 6) * (size_t)p2 * VT_TS + (size_t)(na & 63);
   // streaming YPC1 / SIGS state: the two previous knots, the two previous chord slopes, YP(k-2)
   double xm1 = 0.0, ym1 = 0.0, xm2 = 0.0, ym2 = 0.0, Sp = 0.0, DXp = 0.0, YPp = 0.0;
   bool ypc_fail = false;
@@ -401,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
   // one interval of SIGS (tension_module.f90:448-776) as soon as its end derivatives exist: tension
   // zero, or onto the task list (the known-SBIG case goes through the list too: rare)
   // (the screening as lane masks, lt_math.h: LaneMask; every lane of the wave is here)
-  auto SIGMA = [&](bool on, double S, double S1, double S2, int where) -> double {
+  auto SIGMA = [&](bool on, double S, double S1, double S2, int where) -> bool {
     const LaneMask m = lm(on) & ~sigs_eval_zero_mask(S, S1, S2);
     if (lm_lane(m)) {   // (the list has room for every interval of the wave: lt_set_particles)
       const int idx = ntask + __popcll(m & ((1ull << lane) - 1ull));
@@ -409,7 +429,8 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
       Q.wl[qb + idx] = (unsigned short)((where << 6) | lane);
     }
     ntask += __popcll(m);
-    return lm_lane(m) ? VT_SIG_PENDING : 0.0;  // what the owner stores with the knot (k_vt_sigs writes the listed ones' later)
+    if (lm_lane(m)) fbits[where >> 6][threadIdx.x] |= 1ull << (where & 63);   // (k_vt_sigs writes the factor to vt_sig)
+    return lm_lane(m);
   };
   // newx(k+7) of the knot in hand is newx(k+8) of the one before: kept (the reference recomputes each newx
   // three times: as the end of the 8-point window, as its last-but-one point, and as its start)
@@ -480,25 +501,24 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
     const bool ok = live && !fail_now;
     VTICK(2);
     // interval (k-2, k-1): chord slope S_{k-2} (still in Sp), derivatives YP(k-2), YP(k-1)
-    const double sgA = SIGMA(ok && (MID || k >= 3), Sp, YPp, YPc, k - 3);
+    (void)SIGMA(ok && (MID || k >= 3), Sp, YPp, YPc, k - 3);
     // (the last interval (N-1, N) with YP(N-1), YP(N))
-    double sgB = 0.0;
-    if (!MID) sgB = SIGMA(ok && k == p2, S, YPc, YPn, p2 - 2);
+    if (!MID) (void)SIGMA(ok && k == p2, S, YPc, YPn, p2 - 2);
     VTICK(3);
     if (act) {
       if (ok) {
-        if (MID || k >= 3) tab[(size_t)(k - 3) * VT_TS] = make_double4(xm2, ym2, YPp, sgA);           // knot k-2, interval (k-2, k-1)
+        if (MID || k >= 3) tab[(size_t)(k - 3) * VT_TS] = VtRec{xm2, ym2, YPp};           // knot k-2, interval (k-2, k-1)
         if (!MID && k == p2) {
-          tab[(size_t)(p2 - 2) * VT_TS] = make_double4(xm1, ym1, YPc, sgB);
-          tab[(size_t)(p2 - 1) * VT_TS] = make_double4(xk, yk, YPn, 0.0);
+          tab[(size_t)(p2 - 2) * VT_TS] = VtRec{xm1, ym1, YPc};
+          tab[(size_t)(p2 - 1) * VT_TS] = VtRec{xk, yk, YPn};
         }
       } else if (fail_now) {
-        if (MID || k >= 3) tab[(size_t)(k - 3) * VT_TS] = make_double4(xm2, ym2, (MID || k >= 4) ? YPp : 0.0, 0.0);
-        if (MID || k >= 2) tab[(size_t)(k - 2) * VT_TS] = make_double4(xm1, ym1, 0.0, 0.0);
-        tab[(size_t)(k - 1) * VT_TS] = make_double4(xk, yk, 0.0, 0.0);
+        if (MID || k >= 3) tab[(size_t)(k - 3) * VT_TS] = VtRec{xm2, ym2, (MID || k >= 4) ? YPp : 0.0};
+        if (MID || k >= 2) tab[(size_t)(k - 2) * VT_TS] = VtRec{xm1, ym1, 0.0};
+        tab[(size_t)(k - 1) * VT_TS] = VtRec{xk, yk, 0.0};
         ypc_fail = true;
       } else {  // after a failure: abscissa and ordinate only
-        tab[(size_t)(k - 1) * VT_TS] = make_double4(xk, yk, 0.0, 0.0);
+        tab[(size_t)(k - 1) * VT_TS] = VtRec{xk, yk, 0.0};
       }
       if (ok && (MID || k >= 2)) {
         if (MID || k >= 3) YPp = YPc;
@@ -533,6 +553,11 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
 #ifdef LT_VT_ADV_STATS
   if (lane == 0) { atomicAdd(&g_tim[6], (unsigned long long)adv_exec); atomicAdd(&g_tim[7], (unsigned long long)adv_lanes); atomicAdd(&g_tim[5], 1ull); }
 #endif
+  if ((size_t)wave * 64 < (size_t)P.numpar) {   // the lane's listed intervals (a YPC1 failure: the walks ignore them)
+    unsigned long long* vb = P.vt_bits + (size_t)wave * 4 * 64 + (size_t)lane;
+#pragma unroll
+    for (int w = 0; w < 4; w++) vb[(size_t)w * 64] = fbits[w][threadIdx.x];
+  }
   if (lane == 0 && (size_t)wave * 64 < (size_t)P.numpar) {   // (the last workgroup may hold waves beyond the particles)
     Q.count[wave] = (ntask < Q.cap) ? ntask : Q.cap;
     if (ntask) atomicAdd(&P.counters[CNT_VT_QUEUED], (unsigned long long)ntask);
@@ -546,7 +571,7 @@ __global__ __launch_bounds__(256, 2) void k_vt_table(const StepParams P) {
 #endif  // LT_VT_DEFINE_A
 
 // The SIGS iterations (tension_module.f90:531-760) of the listed intervals, one wave per list, 64 at a
-// time; the tension factor goes into the knot's record, a failed convexity iteration (SigErr) into the
+// time; the tension factor goes to vt_sig at the knot's index, a failed convexity iteration (SigErr) into the
 // particle's flag word.
 #ifdef LT_VT_DEFINE_B
 __global__ __launch_bounds__(256) void k_vt_sigs(const StepParams P) {
@@ -586,7 +611,7 @@ __global__ __launch_bounds__(256) void k_vt_sigs(const StepParams P) {
     if (need) sg = sgn;
     else if (kind == SIGK_SECANT) sg = sigs_secant(S, S1, S2);
     if (have) {
-      P.vt_tab[((size_t)wave * (size_t)p2 + (wl >> 6)) * VT_TS + (wl & 63u)].w = sg;
+      P.vt_sig[((size_t)wave * (size_t)p2 + (wl >> 6)) * VT_TS + (wl & 63u)] = sg;
       if (lm_lane(NEED & FAILED)) {
         // SigErr: every evaluation of this particle's walk is linint's (ver_turb_module.f90:296-331).  k_vt_walk_fast
         // may be running beside this kernel and may not see the flag: the particle goes onto k_vt_walk's list from
@@ -680,11 +705,11 @@ __global__ __launch_bounds__(256) void k_vt_norm(const StepParams P) {
 #endif
 struct VtLite {          // the cached interval without the tension-dependent parts
   int I;
-  double X1, X2, Y1, Y2, P1, P2, SG, SGhi;
+  double X1, X2, Y1, Y2, P1, P2;
   double S, D1, D2;
   Divisor dx;
 };
-LT_DEV void vt_seek_lite(VtLite& c, double T, int n, const double4* tab) {
+LT_DEV void vt_seek_lite(VtLite& c, double T, int n, const VtRec* tab) {
   bool moved = false;
   if (c.I == 0) {
     // first use.  The table is strictly increasing here (k_vt_walk_fast does not take a table YPC1 rejected), so
@@ -697,23 +722,23 @@ LT_DEV void vt_seek_lite(VtLite& c, double T, int n, const double4* tab) {
     if (lo < 1) lo = 1;
     if (lo > n - 1) lo = n - 1;
     c.I = lo;
-    const double4 ra = tab[(size_t)(lo - 1) * VT_TS], rb = tab[(size_t)lo * VT_TS];
-    c.X1 = ra.x; c.Y1 = ra.y; c.P1 = ra.z; c.SG = ra.w;
-    c.X2 = rb.x; c.Y2 = rb.y; c.P2 = rb.z; c.SGhi = rb.w;
+    const VtRec ra = tab[(size_t)(lo - 1) * VT_TS], rb = tab[(size_t)lo * VT_TS];
+    c.X1 = ra.x; c.Y1 = ra.y; c.P1 = ra.yp;
+    c.X2 = rb.x; c.Y2 = rb.y; c.P2 = rb.yp;
     moved = true;
   }
   while (T < c.X1 && c.I > 1) {
     c.I -= 1;
-    const double4 r = tab[(size_t)(c.I - 1) * VT_TS];
-    c.X2 = c.X1; c.Y2 = c.Y1; c.P2 = c.P1; c.SGhi = c.SG;
-    c.X1 = r.x; c.Y1 = r.y; c.P1 = r.z; c.SG = r.w;
+    const VtRec r = tab[(size_t)(c.I - 1) * VT_TS];
+    c.X2 = c.X1; c.Y2 = c.Y1; c.P2 = c.P1;
+    c.X1 = r.x; c.Y1 = r.y; c.P1 = r.yp;
     moved = true;
   }
   while (T >= c.X2 && c.I < n - 1) {
     c.I += 1;
-    const double4 r = tab[(size_t)c.I * VT_TS];
-    c.X1 = c.X2; c.Y1 = c.Y2; c.P1 = c.P2; c.SG = c.SGhi;
-    c.X2 = r.x; c.Y2 = r.y; c.P2 = r.z; c.SGhi = r.w;
+    const VtRec r = tab[(size_t)c.I * VT_TS];
+    c.X1 = c.X2; c.Y1 = c.Y2; c.P1 = c.P2;
+    c.X2 = r.x; c.Y2 = r.y; c.P2 = r.yp;
     moved = true;
   }
   if (moved) {  // vt_prepare without SNHCSH
@@ -741,7 +766,8 @@ __global__ __launch_bounds__(LT_VT_WALKFAST_BLOCK) void k_vt_walk_fast(const Ste
   const size_t N = (size_t)P.numpar;
   double* wsd = P.ws_d + n;
   const int p2 = 4 * P.ws;
-  const double4* tab = P.vt_tab + (size_t)(n >> 6) * (size_t)p2 * VT_TS + (size_t)(n & 63);
+  const VtRec* tab = P.vt_tab + (size_t)(n >> 6) * (size_t)p2 * VT_TS + (size_t)(n & 63);
+  const VtBits bits = vt_bits_load(P, n);   // the listed intervals of this particle: a walk stops there
   const double P_depth = wsd[(size_t)WS_PDEPTH * N], P_zc = wsd[(size_t)WS_PZ1 * N];
   const double P_zetac = wsd[(size_t)WS_ZETA1 * N];
   const double background = (double)1.0E-6f, deltat = 2.0;
@@ -749,7 +775,7 @@ __global__ __launch_bounds__(LT_VT_WALKFAST_BLOCK) void k_vt_walk_fast(const Ste
   const double* dev = VT_DEV_BASE(P, n, loop) + (size_t)VT_DEV_HROWS * 64;
   double ParZc = P_zc;
   VtLite ci;
-  ci.I = 0; ci.X1 = ci.X2 = ci.Y1 = ci.Y2 = ci.P1 = ci.P2 = ci.SG = ci.SGhi = 0.0;
+  ci.I = 0; ci.X1 = ci.X2 = ci.Y1 = ci.Y2 = ci.P1 = ci.P2 = 0.0;
   ci.S = ci.D1 = ci.D2 = 0.0; ci.dx.b = 1.0; ci.dx.y = 1.0;
   // (a table that is not a proper spline is walked by k_vt_walk from the first sub-step)
   bool stopped = (fl & (FL_VT_YPCFAIL | FL_VT_SIGERR)) != 0;
@@ -766,7 +792,7 @@ __global__ __launch_bounds__(LT_VT_WALKFAST_BLOCK) void k_vt_walk_fast(const Ste
     if (!(ParZc < P_depth || ParZc > P_zetac)) {
       vt_seek_lite(ci, ParZc, p2, tab);
       EX_NOTE();
-      tens = !(fabs(ci.SG) < 1.e-9);
+      tens = vt_bit(bits, ci.I - 1);
       const double B1 = div_prep(ci.X2 - ParZc, ci.dx), B2 = 1.0 - B1;  // HPVAL's cubic form, :1222
       Kprimec = ci.P1 + B2 * (ci.D1 + ci.D2 - 3.0 * B1 * (ci.D2 - ci.D1));
     }
@@ -776,7 +802,7 @@ __global__ __launch_bounds__(LT_VT_WALKFAST_BLOCK) void k_vt_walk_fast(const Ste
     if (!tens && !(Z3rdc < P_depth || Z3rdc > P_zetac)) {
       vt_seek_lite(ci, Z3rdc, p2, tab);
       EX_NOTE();
-      tens = !(fabs(ci.SG) < 1.e-9);
+      tens = vt_bit(bits, ci.I - 1);
       const double U = Z3rdc - ci.X1;                                   // HVAL's cubic form, :1083
       const double B2 = div_prep(U, ci.dx), B1 = 1.0 - B2;
       KH3rdc = ci.Y1 + U * (ci.P1 + B2 * (ci.D1 + B1 * (ci.D1 - ci.D2)));
@@ -841,7 +867,9 @@ __global__ __launch_bounds__(LT_VT_WALK_BLOCK) void k_vt_walk(const StepParams P
   const size_t N = (size_t)P.numpar;
   double* wsd = P.ws_d + n;
   const int p2 = 4 * P.ws;
-  const double4* tab = P.vt_tab + (size_t)(n >> 6) * (size_t)p2 * VT_TS + (size_t)(n & 63);
+  const VtRec* tab = P.vt_tab + (size_t)(n >> 6) * (size_t)p2 * VT_TS + (size_t)(n & 63);
+  const double* sig = P.vt_sig + (size_t)(n >> 6) * (size_t)p2 * VT_TS + (size_t)(n & 63);
+  const VtBits bits = vt_bits_load(P, n);
   const double P_depth = wsd[(size_t)WS_PDEPTH * N], P_zc = wsd[(size_t)WS_PZ1 * N];
   const double P_zetac = wsd[(size_t)WS_ZETA1 * N];
   // :282-335 random displacement model, idt/2 sub-steps of 2 s
@@ -851,7 +879,7 @@ __global__ __launch_bounds__(LT_VT_WALK_BLOCK) void k_vt_walk(const StepParams P
   double ParZc = sigerr ? P_zc : wsd[(size_t)WS_TURBV * N];   // left there by k_vt_walk_fast
   int il = 1;
   VtInterval ci;
-  ci.I = 0; ci.X1 = ci.X2 = ci.Y1 = ci.Y2 = ci.P1 = ci.P2 = ci.SG = ci.SGhi = 0.0;
+  ci.I = 0; ci.X1 = ci.X2 = ci.Y1 = ci.Y2 = ci.P1 = ci.P2 = ci.SG = 0.0;
   ci.S = ci.D1 = ci.D2 = ci.SM = ci.CM = ci.CMM = 0.0; ci.dx.b = 1.0; ci.dx.y = 1.0;
   const bool cached = (sigerr == 0) && !ypc_fail;
 #ifdef LT_VT_EXCURSION
@@ -874,17 +902,17 @@ __global__ __launch_bounds__(LT_VT_WALK_BLOCK) void k_vt_walk(const StepParams P
 #endif
     if (!(ParZc < P_depth || ParZc > P_zetac)) {
       if (cached) {
-        vt_seek(ci, ParZc, p2, tab);
+        vt_seek(ci, ParZc, p2, tab, sig, bits);
         EX_NOTE();
         ST_NOTE();
         Kprimec = hpval_prepared(ParZc, ci);
       } else if (sigerr == 0) {
-        Kprimec = hval_table<true>(ParZc, p2, tab, ypc_fail, il);
+        Kprimec = hval_table<true>(ParZc, p2, tab, il);      // (ypc_fail: SIGS never ran)
       } else if (!ypc_fail) {
         vt_seek_plain(ci, ParZc, p2, tab);
         double yy;
         linint_interval(ci, ParZc, yy, Kprimec);
-      } else { double yy; linint_n(&tab[0].x, &tab[0].y, p2, 4 * VT_TS, ParZc, yy, Kprimec); }
+      } else { double yy; linint_n(&tab[0].x, &tab[0].y, p2, 3 * VT_TS, ParZc, yy, Kprimec); }
     }
     const double KprimeZc = -1.0 * Kprimec * deltat;
     const double Z3rdc = ParZc + 0.5 * KprimeZc;
@@ -893,17 +921,17 @@ __global__ __launch_bounds__(LT_VT_WALK_BLOCK) void k_vt_walk(const StepParams P
       KH3rdc = background;
     } else {
       if (cached) {
-        vt_seek(ci, Z3rdc, p2, tab);
+        vt_seek(ci, Z3rdc, p2, tab, sig, bits);
         EX_NOTE();
         ST_NOTE();
         KH3rdc = hval_prepared(Z3rdc, ci);
       } else if (sigerr == 0) {
-        KH3rdc = hval_table<false>(Z3rdc, p2, tab, ypc_fail, il);
+        KH3rdc = hval_table<false>(Z3rdc, p2, tab, il);
       } else if (!ypc_fail) {
         vt_seek_plain(ci, Z3rdc, p2, tab);
         double mm;
         linint_interval(ci, Z3rdc, KH3rdc, mm);
-      } else { double mm; linint_n(&tab[0].x, &tab[0].y, p2, 4 * VT_TS, Z3rdc, KH3rdc, mm); }
+      } else { double mm; linint_n(&tab[0].x, &tab[0].y, p2, 3 * VT_TS, Z3rdc, KH3rdc, mm); }
       if (KH3rdc < background) KH3rdc = background;
     }
     // (2/r * KH3rd * deltat)**0.5 with r = 1
