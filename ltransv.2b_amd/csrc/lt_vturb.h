@@ -195,7 +195,10 @@ LT_DEV double hpval_prepared(double T, const VtInterval& c) {
 }
 // (a move to the neighbouring interval loads ONE 24-byte record -- the new knot; the knot shared with
 // the old interval is kept)
-LT_DEV bool vt_seek_move(VtInterval& c, double T, int n, const VtRec* tab) {
+// (SIG: with the interval's tension factor -- sig: the particle's column of vt_sig, indexed like tab, read where the
+// interval's bit is set, in the same round trip as the record)
+template <bool SIG>
+LT_DEV bool vt_seek_move(VtInterval& c, double T, int n, const VtRec* tab, const double* sig, const VtBits& bits) {
   bool moved = false;
   if (c.I == 0) {  // first use: the start of vt_seek_lite (the table is strictly increasing wherever this is called)
     const double xa = tab[0].x, xb = tab[(size_t)(n - 1) * VT_TS].x;
@@ -205,6 +208,7 @@ LT_DEV bool vt_seek_move(VtInterval& c, double T, int n, const VtRec* tab) {
     if (lo > n - 1) lo = n - 1;
     c.I = lo;
     const VtRec ra = tab[(size_t)(lo - 1) * VT_TS], rb = tab[(size_t)lo * VT_TS];
+    if (SIG) c.SG = vt_bit(bits, lo - 1) ? sig[(size_t)(lo - 1) * VT_TS] : 0.0;
     c.X1 = ra.x; c.Y1 = ra.y; c.P1 = ra.yp;
     c.X2 = rb.x; c.Y2 = rb.y; c.P2 = rb.yp;
     moved = true;
@@ -212,6 +216,7 @@ LT_DEV bool vt_seek_move(VtInterval& c, double T, int n, const VtRec* tab) {
   while (T < c.X1 && c.I > 1) {
     c.I -= 1;
     const VtRec r = tab[(size_t)(c.I - 1) * VT_TS];
+    if (SIG) c.SG = vt_bit(bits, c.I - 1) ? sig[(size_t)(c.I - 1) * VT_TS] : 0.0;
     c.X2 = c.X1; c.Y2 = c.Y1; c.P2 = c.P1;
     c.X1 = r.x; c.Y1 = r.y; c.P1 = r.yp;
     moved = true;
@@ -219,25 +224,24 @@ LT_DEV bool vt_seek_move(VtInterval& c, double T, int n, const VtRec* tab) {
   while (T >= c.X2 && c.I < n - 1) {
     c.I += 1;
     const VtRec r = tab[(size_t)c.I * VT_TS];
+    if (SIG) c.SG = vt_bit(bits, c.I - 1) ? sig[(size_t)(c.I - 1) * VT_TS] : 0.0;
     c.X1 = c.X2; c.Y1 = c.Y2; c.P1 = c.P2;
     c.X2 = r.x; c.Y2 = r.y; c.P2 = r.yp;
     moved = true;
   }
   return moved;
 }
-// (sig: the particle's column of vt_sig, indexed like tab; read where the interval's bit is set)
 LT_DEV void vt_seek(VtInterval& c, double T, int n, const VtRec* tab, const double* sig, const VtBits& bits) {
-  if (vt_seek_move(c, T, n, tab)) {
-    c.SG = vt_bit(bits, c.I - 1) ? sig[(size_t)(c.I - 1) * VT_TS] : 0.0;
-    vt_prepare(c);
-  }
+  if (vt_seek_move<true>(c, T, n, tab, sig, bits)) vt_prepare(c);
 }
 // The walk of a particle whose SIGS failed (SigErr: linint instead of HVAL / HPVAL, ver_turb_module.f90:296-331) on
 // the same cached interval.  linint's bisection (interpolation_module: the j with xa(j) <= x < xa(j+1), the end
 // intervals beyond the ends) and the stepping find the same interval of a strictly increasing table -- and the table is
 // one whenever YPC1 went through, which it did if SIGS ran.  (A bisection from scratch is seven dependent loads, twice
 // per sub-step: the 0.03 % of the particles that take this path were the longest waves of k_vt_walk, 0.2 ms of the step.)
-LT_DEV void vt_seek_plain(VtInterval& c, double T, int n, const VtRec* tab) { (void)vt_seek_move(c, T, n, tab); }
+LT_DEV void vt_seek_plain(VtInterval& c, double T, int n, const VtRec* tab) {
+  (void)vt_seek_move<false>(c, T, n, tab, nullptr, VtBits{0ull, 0ull, 0ull, 0ull});
+}
 LT_DEV void linint_interval(const VtInterval& c, double x, double& y, double& m) {
   m = (c.Y1 - c.Y2) / (c.X1 - c.X2);
   const double b = c.Y1 - m * c.X1;
