@@ -27,6 +27,24 @@ def test_resort_every_step_changes_nothing(name):
         assert out[every]["stats"] == out[-1]["stats"]
 
 
+@pytest.mark.parametrize("name", ["tiny_turb", "tiny_settle"])
+def test_order_inside_the_tiles_changes_nothing(name, monkeypatch):
+    """the internal order follows a Z curve inside each tile of elements (lt_set_grid); LT_TILE_ORDER=rows is the order
+    of the earlier rounds, LT_TILE=4 makes the small test grid span several tiles: same arrays, bit for bit"""
+    out = {}
+    for tag, env in (("z", {}), ("rows", {"LT_TILE_ORDER": "rows"}), ("z4", {"LT_TILE": "4"}), ("rows4", {"LT_TILE": "4", "LT_TILE_ORDER": "rows"})):
+        for k in ("LT_TILE_ORDER", "LT_TILE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out[tag] = cases.run_case(cases.build_case(name, resort_every=3), ltrans_amd.Engine, {}, n_external=2)
+    for tag in ("rows", "z4", "rows4"):
+        for k in FIELDS:
+            if k in out["z"] and out["z"][k] is not None:
+                assert np.array_equal(out[tag][k], out["z"][k]), (tag, k)
+        assert out[tag]["stats"] == out["z"]["stats"]
+
+
 def test_resort_with_reupload_between_steps():
     """lt_set_particles / lt_get_particles after a re-sort use the refreshed host copy of the order."""
     case = cases.build_case("tiny_turb", resort_every=1)
