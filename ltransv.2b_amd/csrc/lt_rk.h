@@ -768,6 +768,133 @@ LT_DEV double wcts_itpi_rho(const StepParams& P, const double* lev, const Column
   return (vb + vc * 4 + vf) / 6.0;
 }
 
+// The same for a whole wave (r05): the salinity / temperature fits of k_beh_pre.  The straight transcription above runs
+// SIGS' convexity Newton iteration inside each of its nine intervals (three time slots x three intervals), every time for
+// as many trips as the slowest lane needs, with a tenth to a quarter of the lanes in it: 80 % of the kernel.  Here the
+// intervals that need the iteration are first LISTED (their T, in LDS, packed by wave ballots), the list is iterated 64
+// at a time by the wave-level loop k_rk and k_vt_sigs use (sigs_newton_w: same operations, same cycle detection), and a
+// second pass over the slots picks the results up: the tension factor of the evaluation interval, and SigErr (linint
+// instead of HVAL, :2636-2644) if ANY iteration of the fit failed -- SIGS returns at the first failure, and whichever
+// interval it was the fit falls back.  Every lane of the wave is here; `want` says which lanes have a fit.
+struct BehScratch {
+  double T[9 * 64];            // the listed intervals' T = MAX(D1/D2, D2/D1)
+  double sg[9][64];            // tension factor per (slot * 3 + interval, lane)
+  unsigned short own[9 * 64];  // (slot * 3 + interval) << 6 | lane
+  unsigned int fail[64];       // bit slot * 3 + interval: the iteration failed (SigErr)
+};
+template <typename SlabT> struct __attribute__((aligned(4 * sizeof(SlabT)))) Slots4 { SlabT v[LT_SLOTS]; };
+template <typename SlabT>
+LT_DEV double wcts_itpi_rho_w(const StepParams& P, const double* lev, const Column& C, int4 rn, const QuadWeights& w,
+                              const SlabT* F, int deplvl, unsigned fsm, bool want, BehScratch& bs) {
+  static_assert(LT_SLOTS == 4, "one aligned access per (node, level) holds the four time slots");
+  const int lane = threadIdx.x & 63;
+  // the fits' operands, once: X = the level depths, Y = the field at the particle, YP = YPC1's derivatives, per slot.
+  // (the four time slots of a (node, level) are 16 contiguous bytes in this layout, [node][level][slot]: one access
+  // instead of three)
+  double X[3][4], Y[3][4], YP[3][4];
+  int ier[3] = {0, 0, 0};
+  if (want) {
+    const int ps[3] = {P.tb, P.tc, P.tf};
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+      const int k = deplvl + l;
+      const Slots4<SlabT> q1 = *(const Slots4<SlabT>*)(F + ((size_t)(rn.x - 1) * P.us + (k - 1)) * LT_SLOTS);
+      const Slots4<SlabT> q2 = *(const Slots4<SlabT>*)(F + ((size_t)(rn.y - 1) * P.us + (k - 1)) * LT_SLOTS);
+      const Slots4<SlabT> q3 = *(const Slots4<SlabT>*)(F + ((size_t)(rn.z - 1) * P.us + (k - 1)) * LT_SLOTS);
+      const Slots4<SlabT> q4 = *(const Slots4<SlabT>*)(F + ((size_t)(rn.w - 1) * P.us + (k - 1)) * LT_SLOTS);
+#pragma unroll
+      for (int s = 0; s < 3; s++) {
+        const int c = ps[s];   // (uniform)
+        auto pick = [c](const Slots4<SlabT>& q) -> double {
+          return (double)((c == 0) ? q.v[0] : (c == 1) ? q.v[1] : (c == 2) ? q.v[2] : q.v[3]);
+        };
+        double f1 = pick(q1), f2 = pick(q2), f3 = pick(q3), f4 = pick(q4);
+        if (fsm != 15u) freeslip_sub(0, fsm, 15u, f1, f2, f3, f4);
+        Y[s][l] = apply_interp(w, f1, f2, f3, f4);
+        X[s][l] = level_z(lev, k, C.zeta[s], C.h, P.hc, P.Vtransform);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 3; s++) ypc1_4(X[s], Y[s], YP[s], ier[s]);
+  }
+  bs.fail[lane] = 0u;
+  int ntask = 0;   // wave-uniform
+  // ---- first pass: list the intervals that need the Newton iteration
+#pragma unroll
+  for (int s = 0; s < 3; s++) {
+#pragma unroll
+    for (int iv = 0; iv < 3; iv++) {
+      double T = 0.0;
+      bool need = false;
+      if (want && ier[s] == 0) {
+        double sg0;
+        need = sigs_classify((Y[s][iv + 1] - Y[s][iv]) / (X[s][iv + 1] - X[s][iv]), YP[s][iv], YP[s][iv + 1], sg0, T) == SIGK_NEWTON;
+      }
+      const LaneMask m = lm(need);
+      if (need) {
+        const int idx = ntask + __popcll(m & ((1ull << lane) - 1ull));
+        bs.T[idx] = T;
+        bs.own[idx] = (unsigned short)(((s * 3 + iv) << 6) | lane);
+      }
+      ntask += __popcll(m);
+    }
+  }
+  // ---- the listed iterations, 64 at a time
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const ExpAcc ea = exp_acc();
+#pragma unroll 1
+  for (int t0 = 0; t0 < ntask; t0 += 64) {
+    const bool have = t0 + lane < ntask;
+    const double T = have ? bs.T[t0 + lane] : 0.0;
+    const unsigned o = have ? bs.own[t0 + lane] : 0u;
+    double sgn;
+    LaneMask FAILED;
+    const LaneMask NEED = lm(have);
+    sigs_newton_w(T, NEED, sgn, FAILED, ea);
+    if (have) {
+      bs.sg[o >> 6][o & 63u] = sgn;
+      if (lm_lane(FAILED)) atomicOr(&bs.fail[o & 63u], 1u << (o >> 6));
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // ---- second pass: the value of each slot's fit (spline4_eval with the tension factors in hand)
+  if (!want) return 0.0;
+  const unsigned failbits = bs.fail[lane];
+  double Pv[3];
+#pragma unroll
+  for (int s = 0; s < 3; s++) {
+    const double T = C.Pz[s];
+    if (ier[s] != 0) YP[s][0] = YP[s][1] = YP[s][2] = YP[s][3] = 0.0;     // (as spline4_eval: a degenerate column)
+    if (ier[s] == 0 && ((failbits >> (3 * s)) & 7u) != 0u) { Pv[s] = linint4(X[s], Y[s], T); continue; }
+    int I = (T < X[s][1]) ? 1 : (T < X[s][2]) ? 2 : 3;
+    if (T > X[s][3]) I = 3;
+    const double x1 = (I == 1) ? X[s][0] : (I == 2) ? X[s][1] : X[s][2];
+    const double x2 = (I == 1) ? X[s][1] : (I == 2) ? X[s][2] : X[s][3];
+    const double y1 = (I == 1) ? Y[s][0] : (I == 2) ? Y[s][1] : Y[s][2];
+    const double y2 = (I == 1) ? Y[s][1] : (I == 2) ? Y[s][2] : Y[s][3];
+    const double p1 = (I == 1) ? YP[s][0] : (I == 2) ? YP[s][1] : YP[s][2];
+    const double p2 = (I == 1) ? YP[s][1] : (I == 2) ? YP[s][2] : YP[s][3];
+    double sg = 0.0;
+    if (ier[s] == 0) {
+      double Tq;
+      const int kind = sigs_classify((y2 - y1) / (x2 - x1), p1, p2, sg, Tq);
+      if (kind == SIGK_NEWTON) sg = bs.sg[s * 3 + (I - 1)][lane];
+      else if (kind == SIGK_SECANT) sg = sigs_secant((y2 - y1) / (x2 - x1), p1, p2);
+    }
+    Pv[s] = (x2 - x1 <= 0.0) ? 0.0 : hval_interval(T, x1, x2, y1, y2, p1, p2, sg);
+  }
+  double e1 = Pv[0], e2 = Pv[1], e3 = Pv[2];
+  if (P.p == 1) { e2 = Pv[0]; e3 = Pv[1]; }
+  const double vb = polintd3(P.ex0, P.ex1, P.ex2, e1, e2, e3, P.ix0);
+  const double vc = polintd3(P.ex0, P.ex1, P.ex2, e1, e2, e3, P.ix1);
+  const double vf = polintd3(P.ex0, P.ex1, P.ex2, e1, e2, e3, P.ix2);
+  return (vb + vc * 4 + vf) / 6.0;
+}
+
 // Everything of behave() (behavior_module.f90:181-551) and of the SaltTempOn block
 // (LTRANS.f90:1062-1076) that does not depend on the random deviates or on the RK4 result:
 // swimming speed, stage changes, the C. ariakensis timer, the salinity at the particle, the
@@ -777,12 +904,15 @@ LT_DEV double wcts_itpi_rho(const StepParams& P, const double* lev, const Column
 template <typename SlabT>
 __global__ __launch_bounds__(256) void k_beh_pre(const StepParams P) {
   __shared__ double lev[6 * LT_LEV_STRIDE];
+  __shared__ BehScratch bscr[4];
   for (int i = threadIdx.x; i < 6 * LT_LEV_STRIDE; i += blockDim.x) lev[i] = P.lev[i];
   exp_table_load();
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= P.numpar) return;
+  // (every lane of a wave stays to the end of the salinity fits: they are done by the wave, wcts_itpi_rho_w; a lane
+  // without a tracked particle works on particle 0's numbers and stores nothing)
+  const int n0 = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = n0 < P.numpar && (P.ws_i[n0 < P.numpar ? n0 : 0] & FL_ACT) != 0;
+  const int n = live ? n0 : 0;
   int fl = P.ws_i[n];
-  if (!(fl & FL_ACT)) return;
   const size_t N = (size_t)P.numpar;
   double* wsd = P.ws_d + n;
   const double X = P.par[(size_t)pX * N + n], Y = P.par[(size_t)pY * N + n];
@@ -796,9 +926,9 @@ __global__ __launch_bounds__(256) void k_beh_pre(const StepParams P) {
     C.Pz[s] = wsd[(size_t)(WS_PZ0 + s) * N];
   }
   const double P_depth = -C.h, P_zc = C.Pz[1], P_zetac = C.zeta[1];
-  int beh = (P.Behavior != 0) ? P.P_behave[n] : 0;
+  int beh = (live && P.Behavior != 0) ? P.P_behave[n] : 0;
   double tim = 0.0;
-  if (P.Behavior != 0) {
+  if (live && P.Behavior != 0) {
     // :214-215 swimming speed at the current age
     double sw3 = P.P_swim[n + 2 * N];
     bool dirty = false;
@@ -814,20 +944,29 @@ __global__ __launch_bounds__(256) void k_beh_pre(const StepParams P) {
     }
   }
   // salinity (and temperature) at the particle :233-246, LTRANS.f90:1062-1076
-  const bool want_S = (beh == 4) || (beh == 5 && tim == 0.0) || (beh == 7);
+  const bool want_S = live && ((beh == 4) || (beh == 5 && tim == 0.0) || (beh == 7) || P.SaltTempOn);
   double P_S = 0.0;
-  if (want_S || P.SaltTempOn) {
-    const int4 rn = P.RE[P.P_r_element[n] - 1];
-    const Quad q = load_quad_rho(P.rnode, rn);
-    const QuadWeights w = quad_weights(X, Y, q.x, q.y);
-    const int deplvl = level_window(lev, P.us, Zpar, C.zeta[0], C.zeta[1], C.zeta[2], C.h, P.hc, P.Vtransform);
-    const unsigned fsm = P.FreeSlip ? P.fsR[P.P_r_element[n] - 1] : 15u;
-    P_S = wcts_itpi_rho<SlabT>(P, lev, C, rn, w, (const SlabT*)P.S, deplvl, fsm);
-    if (P.SaltTempOn) {
-      P.P_Salt[n] = P_S;
-      P.P_Temp[n] = wcts_itpi_rho<SlabT>(P, lev, C, rn, w, (const SlabT*)P.T, deplvl, fsm);
+  {
+    BehScratch& bs = bscr[threadIdx.x >> 6];
+    int4 rn = make_int4(1, 1, 1, 1);
+    QuadWeights w;
+    w.regime = 1; w.node_hit = 0; w.t = w.u = w.W1 = w.W2 = w.W3 = w.W4 = 0.0;
+    int deplvl = 1;
+    unsigned fsm = 15u;
+    if (want_S) {
+      rn = P.RE[P.P_r_element[n] - 1];
+      const Quad q = load_quad_rho(P.rnode, rn);
+      w = quad_weights(X, Y, q.x, q.y);
+      deplvl = level_window(lev, P.us, Zpar, C.zeta[0], C.zeta[1], C.zeta[2], C.h, P.hc, P.Vtransform);
+      fsm = P.FreeSlip ? P.fsR[P.P_r_element[n] - 1] : 15u;
+    }
+    if (__ballot(want_S)) P_S = wcts_itpi_rho_w<SlabT>(P, lev, C, rn, w, (const SlabT*)P.S, deplvl, fsm, want_S, bs);
+    if (P.SaltTempOn) {      // (uniform)
+      const double P_T = wcts_itpi_rho_w<SlabT>(P, lev, C, rn, w, (const SlabT*)P.T, deplvl, fsm, want_S, bs);
+      if (live) { P.P_Salt[n] = P_S; P.P_Temp[n] = P_T; }
     }
   }
+  if (!live) return;
   bool directed = false, random = false;
   double thr1 = 0.0, thr2 = 0.0;
   // TYPE 1 :256-283
