@@ -1039,7 +1039,7 @@ void launch_rk(lt_engine* e, const StepParams& P, unsigned blocks) {
   const unsigned rkblocks = ((unsigned)(((size_t)blocks * 256 + LT_RK_BLOCK - 1) / LT_RK_BLOCK) + 7u) & ~7u;
 #endif
   static const unsigned dynlds = getenv("LT_RK_DYNLDS") ? (unsigned)atoi(getenv("LT_RK_DYNLDS")) : 0u;  // occupancy experiments
-  launch_k_rk(e->cfg.slab_storage == LT_SLAB_F32, e->cfg.Vtransform, rkblocks, dynlds, e->stream, P);
+  launch_k_rk(e->cfg.slab_storage == LT_SLAB_F32, e->cfg.Vtransform, e->cfg.FreeSlip != 0, rkblocks, dynlds, e->stream, P);
 }
 
 }  // namespace

@@ -226,11 +226,17 @@ LT_DEV void run_tasks(WaveScratch& ws, int nchk, int nev, int lane, int first) {
 // particle is not tracked (act = false) only take part in the cooperative pass.
 // Per-particle constants of the water column are read from the step workspace
 // (coalesced, L2-resident) where needed instead of living in registers.
-template <typename SlabT, int VT>
+// FS (free slip, hydrodynamic_module.f90:1934-1994, 2329-2520; an instantiation of its own, so that the kernel of every
+// other run is the code it was): fsbits = the lane's element masks fsU | fsV << 4 | fsVU << 8 | fsR << 12 -- bit k of a
+// mask: node k+1 of the element is water.  A lane whose element has a land node substitutes its values before every
+// interpolation, on the element's node order, and takes the general form of the interpolation (r05; before, such a
+// particle-step went to k_rk_slow: 5.2 ns each against 0.8 -- a run with a fifth of its particles in coastal elements
+// took 2.0 ms per step instead of 1.0).
+template <typename SlabT, int VT, bool FS>
 LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& ws, bool act, int n,
                           int er, int eu, int ev_, double h, const Divisor& dv, double Xs, double Ys, double Zs, int version,
                           double& Uad, double& Vad, double& Wad, int& sigerr_count, bool& slow,
-                          StageIn& SI, StageTail& ST, bool first_stage, bool last_stage) {
+                          StageIn& SI, StageTail& ST, bool first_stage, bool last_stage, unsigned fsbits) {
   const double* rtab = lev;
   const double* wtab = lev + 3 * LT_LEV_STRIDE;
   const int lane = threadIdx.x & 63;
@@ -360,11 +366,21 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
     d12 = prep_div(DX1 + DX2); d23 = prep_div(DX2 + DX3);
   };
   // horizontal interpolation of the 4 levels of the slot in `raw`
-  auto interp = [&](const QuadWeights& w, double (&Y)[4]) {
+  auto interp = [&](const QuadWeights& w, double (&Y)[4], int fskind, unsigned fsm, unsigned fsd) {
 #pragma unroll
     for (int l = 0; l < 4; l++) {
       const double v1 = (double)raw[4 * l + 0], v2 = (double)raw[4 * l + 1], v3 = (double)raw[4 * l + 2];
       Y[l] = v1 + (v2 - v1) * w.t + (v3 - v1) * w.u;
+    }
+    if (FS && (fsm & 15u) != 15u) {   // free slip, an element with a land node: substitute, then the general form
+#pragma unroll
+      for (int l = 0; l < 4; l++) {
+        double a = (double)raw[4 * l + 0], b = (double)raw[4 * l + 1], c = (double)raw[4 * l + 2], d = (double)raw[4 * l + 3];
+        if (w.regime == 2) { double t_ = a; a = c; c = t_; t_ = b; b = d; d = t_; }   // (rotate_raw: back to the element's order)
+        freeslip_sub(fskind, fsm, fsd, a, b, c, d);
+        Y[l] = apply_interp(w, a, b, c, d);
+      }
+      return;
     }
     if (w.regime >= 3) {  // the stage position has left the start element (a few % of the lanes)
 #pragma unroll
@@ -481,8 +497,12 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
     for (int s = 0; s < 3; s++) {
       const int ps = (s == 0) ? P.tb : (s == 1) ? P.tc : P.tf;
       const double zeta = wsd[(size_t)(WS_ZETA0 + s) * N];
-      double val = apply_interp(wl, fldv(F, nd.x, L, k, ps), fldv(F, nd.y, L, k, ps),
-                                fldv(F, nd.z, L, k, ps), fldv(F, nd.w, L, k, ps));
+      double f1 = fldv(F, nd.x, L, k, ps), f2 = fldv(F, nd.y, L, k, ps), f3 = fldv(F, nd.z, L, k, ps), f4 = fldv(F, nd.w, L, k, ps);
+      if (FS) {
+        const unsigned fsm = (var == 0) ? (fsbits & 15u) : (var == 1) ? ((fsbits >> 4) & 15u) : ((fsbits >> 12) & 15u);
+        if (fsm != 15u) freeslip_sub((var == 0) ? 1 : (var == 1) ? 2 : 0, fsm, (fsbits >> 8) & 15u, f1, f2, f3, f4);
+      }
+      double val = apply_interp(wl, f1, f2, f3, f4);
       double ztop = level_at(qt, zeta, h, VT);
       ws.res[var * 3 + s][lane] = val * log10_call((Zs - wzb1) / P.z0) / log10_call((ztop - wzb1) / P.z0);
     }
@@ -517,11 +537,11 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
       const double Pzs = pz;
       geometry(zt);
       double Y[4];
-      interp(wU, Y);
+      interp(wU, Y, 1, fsbits & 15u, 15u);
       request(FbV, eV, L, s);            // V's values of this slot arrive while U is fitted
       fit(Y, s, Pzs);
       make_room();
-      interp(wV, Y);
+      interp(wV, Y, 2, (fsbits >> 4) & 15u, (fsbits >> 8) & 15u);
       if (s < 2) { request(FbU, eU, L, s + 1); request_zp(s + 1); }
       fit(Y, 3 + s, Pzs);
     }
@@ -555,7 +575,7 @@ LT_DEV void find_currents(const StepParams& P, const double* lev, WaveScratch& w
       const double Pzs = pz;
       geometry(zt);
       double Y[4];
-      interp(w, Y);
+      interp(w, Y, 0, (fsbits >> 12) & 15u, 15u);
       if (s < 2) { request(Fb, e, L, s + 1); request_zp(s + 1); }
       fit(Y, 6 + s, Pzs);
     }
@@ -1051,7 +1071,7 @@ __global__ __launch_bounds__(256) void k_beh_pre(const StepParams P) {
 #ifndef LT_RK_BLOCK
 #define LT_RK_BLOCK 64   // one wave per block: a finished wave frees its slot at once (256-lane blocks: +3 % kernel time)
 #endif
-template <typename SlabT, int VT, int WAVES_PER_SIMD>
+template <typename SlabT, int VT, int WAVES_PER_SIMD, bool FS = false>
 __global__ __launch_bounds__(LT_RK_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES_PER_SIMD, WAVES_PER_SIMD)))
 void k_rk(const StepParams P) {
   __shared__ double lev[6 * LT_LEV_STRIDE];
@@ -1109,9 +1129,13 @@ void k_rk(const StepParams P) {
   int er = 1, eu = 1, ev_ = 1;
   if (act) { er = er0; eu = eu0; ev_ = ev0; }
   // free slip: an element with a land node has its values substituted before every interpolation
-  // (:1934-1994, 2329-2520); those few particles take the straight transcription of k_rk_slow
+  // (:1934-1994, 2329-2520): by the FS instantiation in place (find_currents); the plain one, should it be launched
+  // for such a run, hands those particles to the straight transcription of k_rk_slow
   bool act_fast = act;
-  if (P.FreeSlip && act && ((P.fsR[er - 1] & P.fsU[eu - 1] & P.fsV[ev_ - 1]) != 15u)) {
+  unsigned fsbits = 0xffffu;
+  if (FS) {
+    if (act) fsbits = (unsigned)P.fsU[eu - 1] | ((unsigned)P.fsV[ev_ - 1] << 4) | ((unsigned)P.fsVU[eu - 1] << 8) | ((unsigned)P.fsR[er - 1] << 12);
+  } else if (P.FreeSlip && act && ((P.fsR[er - 1] & P.fsU[eu - 1] & P.fsV[ev_ - 1]) != 15u)) {
     slow = true;
     act_fast = false;
   }
@@ -1129,8 +1153,8 @@ void k_rk(const StepParams P) {
     // (h made opaque per stage: otherwise every h-dependent level coefficient is hoisted
     // out of the stage loop and held in registers for the whole kernel)
     asm volatile("" : "+v"(h));
-    find_currents<SlabT, VT>(P, lev, ws, act_fast, n, er, eu, ev_, h, dv, Xs, Ys, Zs, version, Uad, Vad, Wad, sigerr_count, slow,
-                             SI, ST, st == 0, st == 3);
+    find_currents<SlabT, VT, FS>(P, lev, ws, act_fast, n, er, eu, ev_, h, dv, Xs, Ys, Zs, version, Uad, Vad, Wad, sigerr_count, slow,
+                                 SI, ST, st == 0, st == 3, fsbits);
     if (st == 0) { sumU = Uad; sumV = Vad; sumW = Wad; }
     else if (st == 3) { sumU = sumU + Uad; sumV = sumV + Vad; sumW = sumW + Wad; }
     else { sumU = sumU + 2.0 * Uad; sumV = sumV + 2.0 * Vad; sumW = sumW + 2.0 * Wad; }

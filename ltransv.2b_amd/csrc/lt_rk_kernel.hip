@@ -25,18 +25,24 @@
 
 namespace ltd {
 
-template <typename SlabT>
+template <typename SlabT, bool FS>
 static void launch_k_rk_t(int Vtransform, unsigned grid, unsigned dynlds, hipStream_t stream, const StepParams& P) {
   switch (Vtransform) {
-    case 1: hipLaunchKernelGGL((k_rk<SlabT, 1, LT_RK_WAVES>), dim3(grid), dim3(LT_RK_BLOCK), dynlds, stream, P); break;
-    case 2: hipLaunchKernelGGL((k_rk<SlabT, 2, LT_RK_WAVES>), dim3(grid), dim3(LT_RK_BLOCK), dynlds, stream, P); break;
-    default: hipLaunchKernelGGL((k_rk<SlabT, 3, LT_RK_WAVES>), dim3(grid), dim3(LT_RK_BLOCK), dynlds, stream, P); break;
+    case 1: hipLaunchKernelGGL((k_rk<SlabT, 1, LT_RK_WAVES, FS>), dim3(grid), dim3(LT_RK_BLOCK), dynlds, stream, P); break;
+    case 2: hipLaunchKernelGGL((k_rk<SlabT, 2, LT_RK_WAVES, FS>), dim3(grid), dim3(LT_RK_BLOCK), dynlds, stream, P); break;
+    default: hipLaunchKernelGGL((k_rk<SlabT, 3, LT_RK_WAVES, FS>), dim3(grid), dim3(LT_RK_BLOCK), dynlds, stream, P); break;
   }
 }
 
-void launch_k_rk(bool f32, int Vtransform, unsigned grid, unsigned dynlds, hipStream_t stream, const StepParams& P) {
-  if (f32) launch_k_rk_t<float>(Vtransform, grid, dynlds, stream, P);
-  else launch_k_rk_t<double>(Vtransform, grid, dynlds, stream, P);
+// (FreeSlip runs take the instantiation with the substitution in its interpolations; every other run the plain one)
+void launch_k_rk(bool f32, int Vtransform, bool freeslip, unsigned grid, unsigned dynlds, hipStream_t stream, const StepParams& P) {
+  if (freeslip) {
+    if (f32) launch_k_rk_t<float, true>(Vtransform, grid, dynlds, stream, P);
+    else launch_k_rk_t<double, true>(Vtransform, grid, dynlds, stream, P);
+  } else {
+    if (f32) launch_k_rk_t<float, false>(Vtransform, grid, dynlds, stream, P);
+    else launch_k_rk_t<double, false>(Vtransform, grid, dynlds, stream, P);
+  }
 }
 
 template <typename SlabT>

@@ -20,8 +20,8 @@
 
 namespace ltd {
 struct StepParams;
-// k_rk<float|double, Vtransform, LT_RK_WAVES> on `grid` workgroups of LT_RK_BLOCK lanes
-void launch_k_rk(bool f32, int Vtransform, unsigned grid, unsigned dynlds, hipStream_t stream, const StepParams& P);
+// k_rk<float|double, Vtransform, LT_RK_WAVES, free slip> on `grid` workgroups of LT_RK_BLOCK lanes
+void launch_k_rk(bool f32, int Vtransform, bool freeslip, unsigned grid, unsigned dynlds, hipStream_t stream, const StepParams& P);
 // the VTurb kernels of that unit (lt_vturb.h, LT_VT_DEFINE_A), 256-lane workgroups over `blocks` x 256 particles
 void launch_k_vt_table(bool f32, int Vtransform, bool fastdiv, unsigned blocks, hipStream_t stream, const StepParams& P);
 void launch_k_vt_norm(unsigned blocks, hipStream_t stream, const StepParams& P);
