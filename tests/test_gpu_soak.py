@@ -14,6 +14,7 @@ from ltrans_amd import roms_synth as rs
 pytestmark = pytest.mark.gpu
 
 NSEEDS = int(os.environ.get("LT_SOAK_SEEDS", "1"))
+NMID = int(os.environ.get("LT_SOAK_MID", "0"))      # seeds of the 20000-particle families (the oracle needs a minute each)
 FAMILIES = ["tiny_adv", "tiny_sink", "tiny_vt2", "tiny_vt3", "tiny_turb", "tiny_hturb", "tiny_vturb", "tiny_turb_vt2",
             "tiny_turb_vt3", "tiny_beh1", "tiny_beh2", "tiny_beh3", "tiny_beh4", "tiny_beh5", "tiny_beh7", "tiny_salt",
             "tiny_reflect", "tiny_fs_adv", "tiny_fs_turb", "tiny_fs_salt", "tiny_jump", "tiny_open", "tiny_settle"]
@@ -49,3 +50,16 @@ def test_soak(name, k):
     for f in INTS:
         assert np.array_equal(hip[f], ora[f]), (name, k, f)
     assert hip["stats"]["active"] == ora["stats"]["active"]
+
+
+@pytest.mark.parametrize("k", range(NMID))
+@pytest.mark.parametrize("name", ["mid_adv", "mid_turb"])
+def test_soak_mid(name, k):
+    """the same with 20000 particles (79 workgroups of 256: the kernels' XCD maps with a ragged grid, several generator
+    blocks per step, the re-sort) -- opt-in: LT_SOAK_MID=n"""
+    case = _reseed(cases.build_case(name), k + 1)
+    hip = cases.run_case(case, ltrans_amd.Engine, {}, n_external=2)
+    ora = cases.run_case(case, ltrans_amd.Engine, dict(lib=oracle_lib.load_oracle(), prefix="lto_"), n_external=2)
+    assert np.array_equal(hip["par"], ora["par"]), (name, k, float(np.abs(hip["par"] - ora["par"]).max()))
+    for f in INTS:
+        assert np.array_equal(hip[f], ora[f]), (name, k, f)
